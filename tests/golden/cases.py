@@ -1,0 +1,87 @@
+"""Golden-vector cases shared by ``make_goldens.py`` (build container only: imports the
+reference) and the tests (anywhere: read the committed ``.npz`` files).
+
+A case is a chain of LTM forwards on one or more layers.  Inputs are regenerated from the
+counter-based generator in ``infinite_video_amd.synth`` so fixtures only hold outputs.
+Before the forward of (chunk c, layer l) the torch CPU generator is seeded with
+``call_seed(case, c, l)``; the Gibbs uniforms of that call are therefore
+``torch.rand(512, float64)`` right after the same seeding.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from infinite_video_amd import synth
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+@dataclass
+class Case:
+    name: str
+    variant: str = "VL"            # VL: P=32, d=768 ; VC: P=14*14, d=1024
+    N: int = 64
+    Q: int = 32
+    tau: float = 0.75
+    sticky: bool = True
+    n_layers: int = 2
+    chunk_T: List[int] = field(default_factory=lambda: [8] * 8)   # frames per chunk
+    new_doc_at: Tuple[int, ...] = (0,)                               # chunks that start a document
+    q_scale: float = 1.0
+    seed_base: int = 1000
+    store_full_B: bool = True      # else: every 16th row + per-row sums
+
+    @property
+    def P(self): return 32 if self.variant == "VL" else 196
+    @property
+    def d(self): return 768 if self.variant == "VL" else 1024
+    @property
+    def pool_shape(self): return (32,) if self.variant == "VL" else (14, 14)
+    dm: int = 768
+    H: int = 12
+    dh: int = 64
+
+
+CASES = [
+    Case("cfg1_sticky"),                                              # BASELINE config 1 (numerics gate)
+    Case("cfg1_uniform", sticky=False, seed_base=2000),
+    Case("ragged_reset", chunk_T=[8, 8, 5, 8, 8, 7], new_doc_at=(0, 3), seed_base=3000),
+    Case("peaked", q_scale=8.0, chunk_T=[16] * 4, seed_base=4000),
+    Case("tau09", tau=0.9, N=128, chunk_T=[12] * 3, seed_base=4500, n_layers=1),
+    Case("headline", N=256, chunk_T=[256] * 3, seed_base=5000, store_full_B=False),
+    Case("headline_ragged", N=256, chunk_T=[256, 255, 100], seed_base=5500, n_layers=1, store_full_B=False),
+    Case("vc_shape", variant="VC", Q=96, chunk_T=[16] * 3, seed_base=6000, n_layers=2),
+]
+
+
+def call_seed(case: Case, chunk: int, layer: int) -> int:
+    return case.seed_base + 16 * chunk + layer
+
+
+def call_uniforms(case: Case, chunk: int, layer: int) -> np.ndarray:
+    torch.manual_seed(call_seed(case, chunk, layer))
+    return torch.rand(synth.NB_SAMPLES, dtype=torch.float64).numpy()
+
+
+def case_inputs(case: Case):
+    """(k per chunk, q per layer, projections per layer) as numpy fp32."""
+    ks = [synth.frame_tokens(c, T, case.P, case.d, seed=synth.SEED_K + case.seed_base)
+          for c, T in enumerate(case.chunk_T)]
+    qs = [synth.layer_query(l, case.Q, case.dm, seed=synth.SEED_Q + case.seed_base, scale=case.q_scale)
+          for l in range(case.n_layers)]
+    ws = [synth.layer_projections(l, case.d, case.dm, seed=synth.SEED_W + case.seed_base)
+          for l in range(case.n_layers)]
+    return ks, qs, ws
+
+
+def golden_path(case: Case) -> str:
+    return os.path.join(GOLDEN_DIR, f"{case.name}.npz")
+
+
+def load_golden(case: Case):
+    return np.load(golden_path(case))
