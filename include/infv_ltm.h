@@ -1,0 +1,168 @@
+/*
+ * infv_ltm.h -- C ABI of the MI355X-native long-term-memory (LTM) consolidation path of
+ * infinity-Video (deep-spin/Infinite-Video).  Implemented by libinfv_ltm.so
+ * (infinite-video_amd/csrc/, hand-written HIP for gfx950).
+ *
+ * The reference has no FFI for this path: its operator boundary is the Python nn.Module
+ *     LongTermAttention.forward(k, q, new_doc, layer_n)
+ *         infty-Video-LLaMA/InfVideoLLaMA/models/long_term_attention_gibbs.py:288-346
+ * called once per cross-attention layer per chunk from
+ *     BertSelfAttention.forward   infty-Video-LLaMA/InfVideoLLaMA/models/Qformer.py:216-223.
+ * The entry points below are what a binding for that boundary needs; each cites the
+ * reference lines it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every pointer documented "device" is a HIP device pointer owned by the caller;
+ *     the handle owns only the consolidated memory (coefficients B, their projections,
+ *     the sticky histogram) and its workspaces;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream); no entry point synchronises except export/get calls that
+ *     copy to HOST buffers;
+ *   - return value: 0 on success, negative infv_status on failure; nothing throws across
+ *     the ABI.  infv_ltm_last_error() returns a thread-local description;
+ *   - a handle is not re-entrant (the reference module is mutable, single-threaded state);
+ *   - all floating-point data is fp32, row-major, batch size 1 (reference
+ *     long_term_attention_gibbs.py:208,346).
+ */
+#ifndef INFV_LTM_H
+#define INFV_LTM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INFV_LTM_ABI_VERSION 1
+#define INFV_LTM_MAX_LAYERS 8
+
+typedef enum {
+    INFV_OK = 0,
+    INFV_ERR_INVALID = -1,      /* bad argument / shape */
+    INFV_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels implement */
+    INFV_ERR_NO_PLAN = -3,      /* no plan registered for this chunk length */
+    INFV_ERR_STATE = -4,        /* call not valid in the handle's current state */
+    INFV_ERR_HIP = -5,          /* a HIP runtime call failed (see last_error) */
+    INFV_ERR_NOMEM = -6
+} infv_status;
+
+typedef struct infv_ltm_s* infv_ltm_handle;
+
+/* Constructor knobs = the kwargs the Q-former passes (Qformer.py:135-158) that the active
+ * path reads, plus the frame-pooling shape the reference hard-codes
+ * (long_term_attention_gibbs.py:291,304: 32 x 768; VideoChat2 twin: 196 x 1024). */
+typedef struct {
+    int32_t num_basis;         /* N, attn_num_basis                                    */
+    int32_t n_heads;           /* H                                                    */
+    int32_t head_size;         /* dh (64)                                              */
+    int32_t d_in;              /* d, encoder width of the frame tokens                 */
+    int32_t tokens_per_frame;  /* P                                                    */
+    int32_t n_layers;          /* LTM instances stepped together by this handle (>=1)  */
+    int32_t nb_samples;        /* S = 512 (long_term_attention_gibbs.py:55)            */
+    int32_t sticky;            /* sticky_memories                                      */
+    int32_t max_q;             /* largest query length that will be passed             */
+    int32_t max_batch_chunks;  /* chunks pooled/projected per sub-batch by consolidate */
+} infv_ltm_config;
+
+/* Host-built tables for one chunk length T ("plan").  They are the sparse form of what
+ * get_basis()/compute_G() rebuild on every forward (long_term_attention_gibbs.py:67-165):
+ * with box basis functions F F^T is diagonal, so each row of G has one non-zero
+ * 1/(count+ridge).  All pointers are HOST pointers; the call copies them to the device.
+ *   rows:  for r in [0,rows): box row_box[r] receives val[box] * sum of frames
+ *          [row_begin[r], row_end[r])                      ("new" coefficient rows)
+ *   old:   CSR over boxes of the S resampled-memory slots that land in the box
+ *          (infinite-memory operator only; positions tau*s/S, :137)                      */
+typedef struct {
+    int32_t T;
+    int32_t first_rows;
+    const int32_t* first_row_box;
+    const int32_t* first_row_begin;
+    const int32_t* first_row_end;
+    const float*   first_box_val;     /* [N] */
+    int32_t inf_rows;
+    const int32_t* inf_row_box;
+    const int32_t* inf_row_begin;
+    const int32_t* inf_row_end;
+    const float*   inf_box_val;       /* [N] */
+    const int32_t* inf_old_ptr;       /* [N+1] */
+    const int32_t* inf_old_slot;      /* [inf_old_ptr[N]] values in [0,S) */
+    const float*   readout_w;         /* [N]  trapezoid weight of the 1000-point grid in box n (:264-282) */
+    float          readout_w_out;     /* weight of grid points in no box (t = 1.0)          */
+    int32_t        n_bins;            /* 128 (:163)                                          */
+    const int32_t* edge_box;          /* [n_bins+1] box evaluated at each modified edge, -1 = none (:197-200) */
+    const float*   edge_dx;           /* [n_bins]   fp32 spacing of the modified edges              */
+    const int32_t* bin_box;           /* [n_bins]   box of the unmodified left edge of bin b (:207-208) */
+    const int32_t* uniform_idx;       /* [S] non-sticky resample rows, -1 = zero row (:153-157,212)  */
+} infv_ltm_plan;
+
+/* Borrowed projection weights of one cross-attention layer (device pointers): the layer's
+ * own key/value nn.Linear (Qformer.py:133-134,156-157), read at call time. */
+typedef struct {
+    const float* wk;   /* [dm, d] */
+    const float* bk;   /* [dm]    */
+    const float* wv;   /* [dm, d] */
+    const float* bv;   /* [dm]    */
+} infv_ltm_proj;
+
+int         infv_ltm_abi_version(void);
+const char* infv_ltm_last_error(void);
+
+/* LongTermAttention.__init__ (long_term_attention_gibbs.py:26-65). */
+int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out);
+int infv_ltm_destroy(infv_ltm_handle h);
+
+/* get_basis() (long_term_attention_gibbs.py:67-165), cached per chunk length. */
+int infv_ltm_set_plan(infv_ltm_handle h, const infv_ltm_plan* plan);
+int infv_ltm_has_plan(infv_ltm_handle h, int32_t T);          /* 1 / 0 */
+
+/* new_doc=True (long_term_attention_gibbs.py:300-302): forget the memory. */
+int infv_ltm_reset(infv_ltm_handle h);
+int infv_ltm_has_memory(infv_ltm_handle h);                    /* 1 / 0 */
+
+/* Frame mean-pool, long_term_attention_gibbs.py:304:  k [n_frames, P, d] -> kbar [n_frames, d]. */
+int infv_ltm_pool(infv_ltm_handle h, const float* k, int64_t n_frames, float* kbar, void* stream);
+
+/* One consolidation step of all n_layers instances on one chunk, from pooled frames:
+ * update_inf + proj_key/proj_value + expected_value (long_term_attention_gibbs.py:194-222,
+ * 312-318).  kbar [T,d]; q [L,Q,dm]; proj[L]; u [L,S] float64 Gibbs uniforms (device;
+ * may be NULL when the handle has no memory yet or is not sticky); ctx [L,Q,dm]. */
+int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* q, int32_t Q,
+                  const infv_ltm_proj* proj, const double* u, float* ctx, void* stream);
+
+/* LongTermAttention.forward (long_term_attention_gibbs.py:288-346) for all layers of the
+ * handle on one chunk: reset if new_doc, pool, step.  k [T*P, d]. */
+int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
+                     const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                     void* stream);
+
+/* The per-chunk loop of the eval drivers (run_inference_inf_video_llama_nextqa.py:179-196)
+ * with the LLM/Q-former stubbed: n_chunks chunks of T frames, k [C, T*P, d], the same
+ * q [L,Q,dm] for every chunk, u [C,L,S], ctx [C,L,Q,dm].  new_doc applies to chunk 0.
+ * Pooling and new-row projections are batched over chunks; the memory chain is sequential. */
+int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T,
+                         const float* q, int32_t Q, const infv_ltm_proj* proj, const double* u,
+                         int32_t new_doc, float* ctx, void* stream);
+
+/* Consolidated memory of one layer: B_past [N,d] (long_term_attention_gibbs.py:220) and the
+ * unnormalised sticky bin masses p[n_bins-1] derived from the last scores (:200-202).
+ * Export copies device -> caller's DEVICE buffers (async on stream). */
+int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin_mass, void* stream);
+/* Import + recompute the projected memory with the given weights. */
+int infv_ltm_import_state(infv_ltm_handle h, int32_t layer, const float* B, const float* bin_mass,
+                          const infv_ltm_proj* proj, void* stream);
+/* Recompute projected memory of every layer from B (weights changed since the last step). */
+int infv_ltm_reproject(infv_ltm_handle h, const infv_ltm_proj* proj, void* stream);
+
+/* Diagnostics of the last step of one layer, copied to HOST buffers (synchronises stream):
+ * bins [S] drawn histogram bins, idx [S] resampled rows, probs [n_bins-1] as fed to the draw,
+ * scores [H,Q,N] (any pointer may be NULL). */
+int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* idx, float* probs,
+                      float* scores, void* stream);
+/* Teacher forcing for tests: the next step of `layer` draws from these HOST probs[n_bins-1]
+ * instead of the ones derived from its own scores (one-shot). */
+int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFV_LTM_H */

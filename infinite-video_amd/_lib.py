@@ -1,0 +1,103 @@
+"""ctypes binding of libinfv_ltm.so (C ABI: include/infv_ltm.h).
+
+There is no fallback: if the library is missing or lacks a symbol, importing an operator
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (hipcc,
+``--offload-arch=gfx950``); the built ``.so`` lives next to this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinfv_ltm.so")
+ABI_VERSION = 1
+MAX_LAYERS = 8
+
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_basis", "n_heads", "head_size", "d_in", "tokens_per_frame", "n_layers",
+        "nb_samples", "sticky", "max_q", "max_batch_chunks")]
+
+
+class PlanStruct(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32),
+        ("first_rows", C.c_int32),
+        ("first_row_box", i32p), ("first_row_begin", i32p), ("first_row_end", i32p),
+        ("first_box_val", f32p),
+        ("inf_rows", C.c_int32),
+        ("inf_row_box", i32p), ("inf_row_begin", i32p), ("inf_row_end", i32p),
+        ("inf_box_val", f32p),
+        ("inf_old_ptr", i32p), ("inf_old_slot", i32p),
+        ("readout_w", f32p), ("readout_w_out", C.c_float),
+        ("n_bins", C.c_int32),
+        ("edge_box", i32p), ("edge_dx", f32p), ("bin_box", i32p),
+        ("uniform_idx", i32p),
+    ]
+
+
+class Proj(C.Structure):
+    _fields_ = [("wk", C.c_void_p), ("bk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p)]
+
+
+class LTMError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"infv_ltm error {code}: {msg}")
+        self.code = code
+
+
+_SIGNATURES = {
+    "infv_ltm_abi_version": (C.c_int, []),
+    "infv_ltm_last_error": (C.c_char_p, []),
+    "infv_ltm_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "infv_ltm_destroy": (C.c_int, [C.c_void_p]),
+    "infv_ltm_set_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanStruct)]),
+    "infv_ltm_has_plan": (C.c_int, [C.c_void_p, C.c_int32]),
+    "infv_ltm_reset": (C.c_int, [C.c_void_p]),
+    "infv_ltm_has_memory": (C.c_int, [C.c_void_p]),
+    "infv_ltm_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "infv_ltm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "infv_ltm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_consolidate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_export_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "infv_ltm_import_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Proj), C.c_void_p]),
+    "infv_ltm_reproject": (C.c_int, [C.c_void_p, C.POINTER(Proj), C.c_void_p]),
+    "infv_ltm_get_draw": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, f32p, f32p, C.c_void_p]),
+    "infv_ltm_set_probs": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it is missing -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the LTM path has no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.infv_ltm_abi_version() != ABI_VERSION:
+        raise ImportError(f"libinfv_ltm.so ABI {lib.infv_ltm_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> int:
+    if code < 0:
+        raise LTMError(code, load().infv_ltm_last_error().decode(errors="replace"))
+    return code

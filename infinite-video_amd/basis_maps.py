@@ -1,0 +1,177 @@
+"""Host-side construction of the LTM "plan" for one chunk length.
+
+The reference rebuilds its basis machinery on every forward (``get_basis``,
+reference long_term_attention_gibbs.py:67-165: sample positions, rectangular basis
+evaluation, an N x N inverse on the CPU, Python loops).  The result depends only on
+``(T, N, tau)``, and because the active basis family is rectangular
+(basis_functions.py:214-266) ``F F^T`` is diagonal: every row of the ridge operator ``G`` has
+at most one non-zero, ``1/(count_of_its_box + ridge)``.  This module computes that sparse form
+once per ``(T, N, tau)`` and hands it to the C ABI (``infv_ltm_set_plan``).
+
+Positions and box bounds are evaluated with the same fp32 torch CPU expressions the
+reference uses (``torch.linspace`` etc.), so box membership -- including the half-open
+``lo <= t < hi`` edge cases such as ``t = 1.0`` falling in no box -- is decided on bit-identical
+numbers.  torch is used here only as the fp32 calculator for a few hundred scalars.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import Tuple
+
+import numpy as np
+import torch
+
+NB_SAMPLES = 512      # reference long_term_attention_gibbs.py:55
+RIDGE_PENALTY = 0.5   # :62
+NB_BINS = 128         # :163
+GRID_POINTS = 1000    # :251
+
+
+class UnsupportedBasis(ValueError):
+    """The (T, N, tau) combination does not give a one-non-zero-per-row operator."""
+
+
+def _box_bounds(N: int):
+    # mu/width as built at long_term_attention_gibbs.py:177-181, bounds as basis_functions.py:248-249
+    width = torch.ones(N) / N
+    edges = torch.linspace(0, 1, N + 1)
+    mu = (edges[:-1] + edges[1:]) / 2
+    return mu - width / 2, mu + width / 2
+
+
+def box_of(t: torch.Tensor, N: int) -> np.ndarray:
+    """Index of the box containing each fp32 point, -1 for none."""
+    lo, hi = _box_bounds(N)
+    t = t.to(torch.float32).reshape(-1, 1)
+    inside = (t >= lo) & (t < hi)
+    n_hit = inside.sum(1)
+    if int(n_hit.max()) > 1:
+        raise UnsupportedBasis(f"a sample position lies in two boxes for num_basis={N}")
+    idx = inside.float().argmax(1).to(torch.int32)
+    idx[n_hit == 0] = -1
+    return idx.numpy()
+
+
+def _positions_first(T: int) -> torch.Tensor:          # :104-110
+    if T % 2:
+        shift = 1 / float(T)
+        return torch.linspace(-.5 + shift, 1.5 - shift, 2 * T - 1)
+    shift = 1 / float(2 * T)
+    return torch.linspace(-.5 + shift, 1.5 - shift, 2 * T)
+
+
+def _positions_inf(T: int, tau: float, S: int) -> torch.Tensor:     # :135-150
+    tm_tau = torch.arange(1, S + 1).float() * tau / S
+    tm_l = tau + (1 - tau) * (torch.arange(S + 1, T + S + 1).float() - S) / T
+    if T % 2:
+        shift = 1 / float(T + S)
+        pad = torch.linspace(-.5 + shift, 1.5 - shift, 2 * (T + S) - 1)
+    else:
+        shift = 1 / float(2 * T + S)
+        pad = torch.linspace(-.5 + shift, 1.5 - shift, 2 * (T + S))
+    return torch.cat([pad[pad < 0], tm_tau, tm_l, pad[pad > 1]])
+
+
+def _trimmed(total: int, l: int) -> Tuple[int, int]:
+    """[begin, end) of the rows compute_G keeps (:78-82)."""
+    if l % 2:
+        return (l - 1) // 2, total + (-(l - 1) // 2)
+    return l // 2, total - l // 2
+
+
+def _operator(l: int, positions: torch.Tensor, N: int):
+    box = box_of(positions, N)
+    counts = np.bincount(box[box >= 0], minlength=N).astype(np.float32)
+    box_val = (np.float32(1) / (counts + np.float32(RIDGE_PENALTY))).astype(np.float32)
+    b, e = _trimmed(len(box), l)
+    rows = box[b:e]
+    if len(rows) != l:
+        raise UnsupportedBasis("padding trim does not leave one row per sample")
+    return rows.astype(np.int32), box_val
+
+
+def _frame_ranges(frame_box: np.ndarray):
+    """Group frames by box; frames of a box must be contiguous (positions are monotone)."""
+    row_box, row_begin, row_end = [], [], []
+    i, T = 0, len(frame_box)
+    while i < T:
+        b = int(frame_box[i])
+        j = i
+        while j < T and frame_box[j] == b:
+            j += 1
+        if b >= 0:
+            if b in row_box:
+                raise UnsupportedBasis("frames of one box are not contiguous")
+            row_box.append(b); row_begin.append(i); row_end.append(j)
+        i = j
+    as32 = lambda x: np.asarray(x, dtype=np.int32)
+    return as32(row_box), as32(row_begin), as32(row_end)
+
+
+@dataclass(frozen=True)
+class Plan:
+    T: int
+    N: int
+    tau: float
+    S: int
+    first_row_box: np.ndarray
+    first_row_begin: np.ndarray
+    first_row_end: np.ndarray
+    first_box_val: np.ndarray
+    inf_row_box: np.ndarray
+    inf_row_begin: np.ndarray
+    inf_row_end: np.ndarray
+    inf_box_val: np.ndarray
+    inf_old_ptr: np.ndarray
+    inf_old_slot: np.ndarray
+    readout_w: np.ndarray
+    readout_w_out: float
+    edge_box: np.ndarray
+    edge_dx: np.ndarray
+    bin_box: np.ndarray
+    uniform_idx: np.ndarray
+
+
+@lru_cache(maxsize=64)
+def build_plan(T: int, N: int, tau: float, S: int = NB_SAMPLES) -> Plan:
+    if T < 2:
+        raise UnsupportedBasis("chunks of a single frame are empty in the reference (G[0:-0])")
+    # first-chunk operator
+    frame_box, first_val = _operator(T, _positions_first(T), N)
+    f_box, f_beg, f_end = _frame_ranges(frame_box)
+    # infinite-memory operator: rows = [S resampled old rows ; T new frames]
+    rows, inf_val = _operator(S + T, _positions_inf(T, tau, S), N)
+    old_box, new_box = rows[:S], rows[S:]
+    i_box, i_beg, i_end = _frame_ranges(new_box)
+    order = np.argsort(np.where(old_box >= 0, old_box, N), kind="stable")
+    kept = order[old_box[order] >= 0]
+    old_ptr = np.zeros(N + 1, dtype=np.int32)
+    np.add.at(old_ptr, old_box[kept] + 1, 1)
+    old_ptr = np.cumsum(old_ptr).astype(np.int32)
+    # read-out weights: trapezoid weights of linspace(0,1,1000) summed per box (:264-282)
+    t = torch.linspace(0, 1, GRID_POINTS)
+    dx = (t[1:] - t[:-1]).double().numpy()
+    wt = np.zeros(GRID_POINTS)
+    wt[:-1] += dx / 2
+    wt[1:] += dx / 2
+    gbox = box_of(t, N)
+    w = np.zeros(N)
+    np.add.at(w, gbox[gbox >= 0], wt[gbox >= 0])
+    # sticky histogram (:163,197-199,207-208)
+    bins = torch.linspace(0, 1, NB_BINS + 1)
+    mod = bins.clone()
+    mod[0] = -.000001
+    mod[-1] = 1.000001
+    edge_dx = (mod[1:] - mod[:-1]).numpy().astype(np.float32)
+    # non-sticky resample positions (:153-157): psi(t / tau) for t in tau * s / S
+    t_uni = (torch.arange(1, S + 1).float() * tau / S) / tau
+    return Plan(
+        T=T, N=N, tau=tau, S=S,
+        first_row_box=f_box, first_row_begin=f_beg, first_row_end=f_end, first_box_val=first_val,
+        inf_row_box=i_box, inf_row_begin=i_beg, inf_row_end=i_end, inf_box_val=inf_val,
+        inf_old_ptr=old_ptr, inf_old_slot=kept.astype(np.int32),
+        readout_w=w.astype(np.float32), readout_w_out=float(wt[gbox < 0].sum()),
+        edge_box=box_of(mod, N).astype(np.int32), edge_dx=edge_dx,
+        bin_box=box_of(bins[:-1], N).astype(np.int32), uniform_idx=box_of(t_uni, N).astype(np.int32),
+    )

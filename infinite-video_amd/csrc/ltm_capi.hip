@@ -1,0 +1,457 @@
+// C ABI of libinfv_ltm.so (include/infv_ltm.h): handle, plans, state and the launch sequences.
+#include "../../include/infv_ltm.h"
+#include "ltm_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+using namespace infv;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(INFV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuf() { if (p) (void)hipFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+template <class T>
+hipError_t upload(DeviceBuf& buf, const T* host, size_t n) {
+    hipError_t e = buf.reserve((n ? n : 1) * sizeof(T));
+    if (e != hipSuccess || n == 0) return e;
+    return hipMemcpy(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice);
+}
+
+struct Operator {
+    int rows = 0;
+    DeviceBuf row_box, row_begin, row_end, box_val, box_row, old_ptr, old_slot;
+    bool has_old = false;
+    OperatorView view() const {
+        OperatorView v;
+        v.rows = rows;
+        v.row_box = row_box.as<int32_t>();
+        v.row_begin = row_begin.as<int32_t>();
+        v.row_end = row_end.as<int32_t>();
+        v.box_val = box_val.as<float>();
+        v.box_row = box_row.as<int32_t>();
+        v.old_ptr = has_old ? old_ptr.as<int32_t>() : nullptr;
+        v.old_slot = has_old ? old_slot.as<int32_t>() : nullptr;
+        return v;
+    }
+};
+
+struct Plan {
+    int T = 0;
+    Operator first, inf;
+    DeviceBuf w, edge_box, edge_dx, bin_box, uniform_idx;
+    float w_out = 0.f;
+    int n_bins = 0;
+    StickyView sticky() const {
+        StickyView s;
+        s.n_bins = n_bins;
+        s.edge_box = edge_box.as<int32_t>();
+        s.edge_dx = edge_dx.as<float>();
+        s.bin_box = bin_box.as<int32_t>();
+        return s;
+    }
+};
+
+}  // namespace
+
+struct infv_ltm_s {
+    infv_ltm_config cfg;
+    int N, H, dh, d, dm, P, L, S, maxQ, maxC;
+    std::map<int, Plan*> plans;
+    DeviceBuf B[2], KV[2];             // [L][N][d], [L][N][2][dm]   ping-pong
+    int cur = 0;
+    bool has_memory = false;
+    int lastQ = 0;                     // query length of the last attend
+    int parts = 0;                     // row count of bin_part per layer, set by the last attend
+    DeviceBuf bin_part;                // [L][max_parts][n_bins]
+    DeviceBuf probs, probs_override, override_flag, bins, idx, scores;
+    DeviceBuf kbar_ws, R_ws, P_ws;     // workspaces
+    int n_bins = 128;
+    ~infv_ltm_s() { for (auto& kv : plans) delete kv.second; }
+};
+
+namespace {
+
+int check_handle(infv_ltm_handle h) {
+    if (!h) return fail(INFV_ERR_INVALID, "null handle");
+    return INFV_OK;
+}
+
+ProjPtrs make_proj(const infv_ltm_proj* proj, int L) {
+    ProjPtrs p;
+    memset(&p, 0, sizeof(p));
+    for (int l = 0; l < L; ++l) { p.wk[l] = proj[l].wk; p.bk[l] = proj[l].bk; p.wv[l] = proj[l].wv; p.bv[l] = proj[l].bv; }
+    return p;
+}
+
+int upload_operator(Operator& op, int N, int rows, const int32_t* row_box, const int32_t* row_begin,
+                    const int32_t* row_end, const float* box_val, const int32_t* old_ptr,
+                    const int32_t* old_slot, int T, int S) {
+    if (rows < 0 || rows > N) return fail(INFV_ERR_INVALID, "plan: rows=%d outside [0,%d]", rows, N);
+    std::vector<int32_t> box_row(N, -1);
+    for (int r = 0; r < rows; ++r) {
+        if (row_box[r] < 0 || row_box[r] >= N || box_row[row_box[r]] != -1)
+            return fail(INFV_ERR_INVALID, "plan: bad or duplicate row_box[%d]=%d", r, row_box[r]);
+        if (row_begin[r] < 0 || row_end[r] > T || row_begin[r] >= row_end[r])
+            return fail(INFV_ERR_INVALID, "plan: bad frame range of row %d", r);
+        box_row[row_box[r]] = r;
+    }
+    op.rows = rows;
+    HIP_TRY(upload(op.row_box, row_box, rows));
+    HIP_TRY(upload(op.row_begin, row_begin, rows));
+    HIP_TRY(upload(op.row_end, row_end, rows));
+    HIP_TRY(upload(op.box_val, box_val, N));
+    HIP_TRY(upload(op.box_row, box_row.data(), N));
+    op.has_old = old_ptr != nullptr;
+    if (old_ptr) {
+        const int nnz = old_ptr[N];
+        if (old_ptr[0] != 0 || nnz < 0 || nnz > S) return fail(INFV_ERR_INVALID, "plan: bad old_ptr");
+        for (int i = 0; i < nnz; ++i)
+            if (old_slot[i] < 0 || old_slot[i] >= S) return fail(INFV_ERR_INVALID, "plan: old_slot out of range");
+        HIP_TRY(upload(op.old_ptr, old_ptr, N + 1));
+        HIP_TRY(upload(op.old_slot, old_slot, nnz));
+    }
+    return INFV_OK;
+}
+
+// draw (if the memory exists) -> update -> attend, for all layers, on one chunk's new rows.
+int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float* Pnew, int splitk,
+               long split_stride, const float* q, int Q, const ProjPtrs& pp, const double* u, float* ctx,
+               hipStream_t stream) {
+    const bool inf = h->has_memory;
+    const Operator& op = inf ? plan.inf : plan.first;
+    const int32_t* idx = nullptr;
+    int idx_stride = 0;
+    if (inf) {
+        if (h->cfg.sticky) {
+            if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
+            if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+            HIP_TRY(launch_draw(h->bin_part.as<float>(), h->parts, h->probs_override.as<float>(),
+                                h->override_flag.as<int32_t>(), plan.sticky(), u, h->S, h->L,
+                                h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream));
+            idx = h->idx.as<int32_t>();
+            idx_stride = h->S;
+        } else {
+            idx = plan.uniform_idx.as<int32_t>();
+            idx_stride = 0;
+        }
+    }
+    const int nxt = h->cur ^ 1;
+    HIP_TRY(launch_update(op.view(), h->N, h->d, h->dm, h->L, h->S, idx, idx_stride, R, Pnew, splitk, split_stride,
+                          h->B[h->cur].as<float>(), h->KV[h->cur].as<float>(), h->B[nxt].as<float>(),
+                          h->KV[nxt].as<float>(), stream));
+    h->cur = nxt;
+    h->has_memory = true;
+    const int parts = attend_parts(Q, h->H);
+    HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
+                          plan.sticky(), ctx, h->bin_part.as<float>(), h->scores.as<float>(), stream));
+    h->parts = parts;
+    h->lastQ = Q;
+    return INFV_OK;
+}
+
+int find_plan(infv_ltm_handle h, int T, Plan** out) {
+    auto it = h->plans.find(T);
+    if (it == h->plans.end()) return fail(INFV_ERR_NO_PLAN, "no plan registered for chunk length T=%d", T);
+    *out = it->second;
+    return INFV_OK;
+}
+
+int check_q(infv_ltm_handle h, int Q) {
+    if (Q <= 0 || Q > h->maxQ) return fail(INFV_ERR_INVALID, "Q=%d outside (0, max_q=%d]", Q, h->maxQ);
+    return INFV_OK;
+}
+
+// project the new rows of `n_chunks` pooled chunks into the workspaces
+int project_chunks(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T,
+                   const ProjPtrs& pp, int* splitk, long* split_stride, hipStream_t stream) {
+    const Operator& op = inf ? plan.inf : plan.first;
+    const long M = (long)n_chunks * op.rows;
+    const long n_cols = (long)h->L * 2 * h->dm;
+    const int sk = project_splitk((int)M, h->d);
+    HIP_TRY(h->R_ws.reserve((size_t)(M ? M : 1) * h->d * sizeof(float)));
+    HIP_TRY(h->P_ws.reserve((size_t)(M ? M : 1) * n_cols * sk * sizeof(float)));
+    HIP_TRY(launch_project(kbar, n_chunks, T, h->d, h->dm, h->L, op.view(), pp, h->R_ws.as<float>(),
+                           h->P_ws.as<float>(), stream));
+    *splitk = sk;
+    *split_stride = M * n_cols;
+    return INFV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int infv_ltm_abi_version(void) { return INFV_LTM_ABI_VERSION; }
+const char* infv_ltm_last_error(void) { return g_err; }
+
+int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
+    if (!cfg || !out) return fail(INFV_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->head_size != kHeadSize) return fail(INFV_ERR_UNSUPPORTED, "head_size=%d (kernels are built for %d)", cfg->head_size, kHeadSize);
+    if (cfg->num_basis <= 0 || cfg->num_basis % 16) return fail(INFV_ERR_UNSUPPORTED, "num_basis=%d must be a positive multiple of 16", cfg->num_basis);
+    if (cfg->n_layers < 1 || cfg->n_layers > INFV_LTM_MAX_LAYERS) return fail(INFV_ERR_INVALID, "n_layers=%d outside [1,%d]", cfg->n_layers, INFV_LTM_MAX_LAYERS);
+    if (cfg->d_in <= 0 || cfg->d_in % 32) return fail(INFV_ERR_UNSUPPORTED, "d_in=%d must be a positive multiple of 32", cfg->d_in);
+    if (cfg->n_heads <= 0 || (cfg->n_heads * cfg->head_size) % 64) return fail(INFV_ERR_UNSUPPORTED, "n_heads*head_size must be a multiple of 64");
+    if (cfg->tokens_per_frame <= 0 || cfg->nb_samples <= 0 || cfg->max_q <= 0) return fail(INFV_ERR_INVALID, "tokens_per_frame, nb_samples, max_q must be positive");
+    infv_ltm_s* h = new (std::nothrow) infv_ltm_s();
+    if (!h) return fail(INFV_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->N = cfg->num_basis; h->H = cfg->n_heads; h->dh = cfg->head_size; h->d = cfg->d_in;
+    h->dm = cfg->n_heads * cfg->head_size; h->P = cfg->tokens_per_frame; h->L = cfg->n_layers;
+    h->S = cfg->nb_samples; h->maxQ = cfg->max_q; h->maxC = cfg->max_batch_chunks > 0 ? cfg->max_batch_chunks : 32;
+    const size_t nb = (size_t)h->L * h->N;
+    const int max_parts = attend_parts(h->maxQ, h->H);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = h->B[i].reserve(nb * h->d * sizeof(float));
+        if (e == hipSuccess) e = h->KV[i].reserve(nb * 2 * h->dm * sizeof(float));
+    }
+    if (e == hipSuccess) e = h->bin_part.reserve((size_t)h->L * max_parts * h->n_bins * sizeof(float));
+    if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
+    if (e == hipSuccess) e = h->probs_override.reserve((size_t)h->L * h->n_bins * sizeof(float));
+    if (e == hipSuccess) e = h->override_flag.reserve((size_t)h->L * sizeof(int32_t));
+    if (e == hipSuccess) e = h->bins.reserve((size_t)h->L * h->S * sizeof(int32_t));
+    if (e == hipSuccess) e = h->idx.reserve((size_t)h->L * h->S * sizeof(int32_t));
+    if (e == hipSuccess) e = h->scores.reserve((size_t)h->L * h->H * h->maxQ * h->N * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->override_flag.p, 0, (size_t)h->L * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(h->bin_part.p, 0, h->bin_part.bytes);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(INFV_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return INFV_OK;
+}
+
+int infv_ltm_destroy(infv_ltm_handle h) {
+    delete h;
+    return INFV_OK;
+}
+
+int infv_ltm_set_plan(infv_ltm_handle h, const infv_ltm_plan* p) {
+    if (int rc = check_handle(h)) return rc;
+    if (!p || p->T < 2) return fail(INFV_ERR_INVALID, "plan: T must be >= 2 (the reference operator is empty for T=1)");
+    if (p->n_bins != h->n_bins) return fail(INFV_ERR_UNSUPPORTED, "plan: n_bins=%d (kernels are built for %d)", p->n_bins, h->n_bins);
+    Plan* plan = new (std::nothrow) Plan();
+    if (!plan) return fail(INFV_ERR_NOMEM, "out of host memory");
+    plan->T = p->T;
+    int rc = upload_operator(plan->first, h->N, p->first_rows, p->first_row_box, p->first_row_begin,
+                             p->first_row_end, p->first_box_val, nullptr, nullptr, p->T, h->S);
+    if (rc == INFV_OK)
+        rc = upload_operator(plan->inf, h->N, p->inf_rows, p->inf_row_box, p->inf_row_begin, p->inf_row_end,
+                             p->inf_box_val, p->inf_old_ptr, p->inf_old_slot, p->T, h->S);
+    if (rc != INFV_OK) { delete plan; return rc; }
+    for (int j = 0; j <= p->n_bins; ++j)
+        if (p->edge_box[j] < -1 || p->edge_box[j] >= h->N) { delete plan; return fail(INFV_ERR_INVALID, "plan: edge_box out of range"); }
+    for (int j = 0; j < p->n_bins; ++j)
+        if (p->bin_box[j] < -1 || p->bin_box[j] >= h->N) { delete plan; return fail(INFV_ERR_INVALID, "plan: bin_box out of range"); }
+    for (int s = 0; s < h->S; ++s)
+        if (p->uniform_idx[s] < -1 || p->uniform_idx[s] >= h->N) { delete plan; return fail(INFV_ERR_INVALID, "plan: uniform_idx out of range"); }
+    plan->w_out = p->readout_w_out;
+    plan->n_bins = p->n_bins;
+    hipError_t e = upload(plan->w, p->readout_w, h->N);
+    if (e == hipSuccess) e = upload(plan->edge_box, p->edge_box, p->n_bins + 1);
+    if (e == hipSuccess) e = upload(plan->edge_dx, p->edge_dx, p->n_bins);
+    if (e == hipSuccess) e = upload(plan->bin_box, p->bin_box, p->n_bins);
+    if (e == hipSuccess) e = upload(plan->uniform_idx, p->uniform_idx, h->S);
+    if (e != hipSuccess) { delete plan; return fail(INFV_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
+    auto it = h->plans.find(p->T);
+    if (it != h->plans.end()) { delete it->second; h->plans.erase(it); }
+    h->plans[p->T] = plan;
+    return INFV_OK;
+}
+
+int infv_ltm_has_plan(infv_ltm_handle h, int32_t T) {
+    if (int rc = check_handle(h)) return rc;
+    return h->plans.count(T) ? 1 : 0;
+}
+
+int infv_ltm_reset(infv_ltm_handle h) {
+    if (int rc = check_handle(h)) return rc;
+    h->has_memory = false;
+    h->parts = 0;
+    return INFV_OK;
+}
+
+int infv_ltm_has_memory(infv_ltm_handle h) {
+    if (int rc = check_handle(h)) return rc;
+    return h->has_memory ? 1 : 0;
+}
+
+int infv_ltm_pool(infv_ltm_handle h, const float* k, int64_t n_frames, float* kbar, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!k || !kbar || n_frames < 0) return fail(INFV_ERR_INVALID, "pool: bad arguments");
+    HIP_TRY(launch_pool(k, kbar, n_frames, h->P, h->d, static_cast<hipStream_t>(stream)));
+    return INFV_OK;
+}
+
+int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* q, int32_t Q,
+                  const infv_ltm_proj* proj, const double* u, float* ctx, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!kbar || !q || !proj || !ctx) return fail(INFV_ERR_INVALID, "step: null argument");
+    if (int rc = check_q(h, Q)) return rc;
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, T, &plan)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const ProjPtrs pp = make_proj(proj, h->L);
+    int sk = 1; long ss = 0;
+    if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, &sk, &ss, stream)) return rc;
+    return chain_step(h, *plan, h->R_ws.as<float>(), h->P_ws.as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
+}
+
+int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
+                     const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!k) return fail(INFV_ERR_INVALID, "forward: null k");
+    if (new_doc) infv_ltm_reset(h);
+    HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
+    if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream)) return rc;
+    return infv_ltm_step(h, h->kbar_ws.as<float>(), T, q, Q, proj, u, ctx, stream);
+}
+
+int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T, const float* q,
+                         int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                         void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!k || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
+    if (int rc = check_q(h, Q)) return rc;
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, T, &plan)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const ProjPtrs pp = make_proj(proj, h->L);
+    const size_t chunk_k = (size_t)T * h->P * h->d;          // floats of one chunk's tokens
+    const size_t chunk_ctx = (size_t)h->L * Q * h->dm;
+    const size_t chunk_u = (size_t)h->L * h->S;
+    if (new_doc) infv_ltm_reset(h);
+    int c = 0;
+    if (!h->has_memory && n_chunks > 0) {                     // first chunk of a document: other operator
+        if (int rc = infv_ltm_forward(h, k, T, q, Q, proj, u, 0, ctx, stream_)) return rc;
+        c = 1;
+    }
+    while (c < n_chunks) {
+        const int nb = (n_chunks - c < h->maxC) ? n_chunks - c : h->maxC;
+        HIP_TRY(h->kbar_ws.reserve((size_t)nb * T * h->d * sizeof(float)));
+        HIP_TRY(launch_pool(k + c * chunk_k, h->kbar_ws.as<float>(), (int64_t)nb * T, h->P, h->d, stream));
+        int sk = 1; long ss = 0;
+        if (int rc = project_chunks(h, *plan, true, h->kbar_ws.as<float>(), nb, T, pp, &sk, &ss, stream)) return rc;
+        const size_t rows = plan->inf.rows;
+        for (int i = 0; i < nb; ++i) {
+            const float* R = h->R_ws.as<float>() + (size_t)i * rows * h->d;
+            const float* Pn = h->P_ws.as<float>() + (size_t)i * rows * h->L * 2 * h->dm;
+            const double* uc = u ? u + (size_t)(c + i) * chunk_u : nullptr;
+            if (int rc = chain_step(h, *plan, R, Pn, sk, ss, q, Q, pp, uc, ctx + (size_t)(c + i) * chunk_ctx, stream)) return rc;
+        }
+        c += nb;
+    }
+    return INFV_OK;
+}
+
+int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin_mass, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
+    if (!h->has_memory) return fail(INFV_ERR_STATE, "no memory to export (B_past is None)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (B) HIP_TRY(hipMemcpyAsync(B, h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d,
+                                  (size_t)h->N * h->d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (bin_mass) {
+        HIP_TRY(launch_sum_parts(h->bin_part.as<float>() + (size_t)layer * h->parts * h->n_bins, h->parts, h->n_bins,
+                                 bin_mass, stream));
+    }
+    return INFV_OK;
+}
+
+int infv_ltm_reproject(infv_ltm_handle h, const infv_ltm_proj* proj, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!proj) return fail(INFV_ERR_INVALID, "reproject: null proj");
+    if (!h->has_memory) return INFV_OK;
+    const ProjPtrs pp = make_proj(proj, h->L);
+    HIP_TRY(launch_reproject(h->B[h->cur].as<float>(), h->N, h->d, h->dm, h->L, pp, h->KV[h->cur].as<float>(),
+                             static_cast<hipStream_t>(stream_)));
+    return INFV_OK;
+}
+
+int infv_ltm_import_state(infv_ltm_handle h, int32_t layer, const float* B, const float* bin_mass,
+                          const infv_ltm_proj* proj, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
+    if (!B || !proj) return fail(INFV_ERR_INVALID, "import: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipMemcpyAsync(h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d, B,
+                           (size_t)h->N * h->d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (h->parts <= 0) h->parts = 1;
+    float* part = h->bin_part.as<float>() + (size_t)layer * h->parts * h->n_bins;
+    HIP_TRY(hipMemsetAsync(part, 0, (size_t)h->parts * h->n_bins * sizeof(float), stream));
+    if (bin_mass)
+        HIP_TRY(hipMemcpyAsync(part, bin_mass, (size_t)(h->n_bins - 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // re-project this layer's memory with its weights
+    ProjPtrs one;
+    memset(&one, 0, sizeof(one));
+    one.wk[0] = proj->wk; one.bk[0] = proj->bk; one.wv[0] = proj->wv; one.bv[0] = proj->bv;
+    HIP_TRY(launch_reproject(h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d, h->N, h->d, h->dm, 1, one,
+                             h->KV[h->cur].as<float>() + (size_t)layer * h->N * 2 * h->dm, stream));
+    h->has_memory = true;
+    return INFV_OK;
+}
+
+int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* idx, float* probs,
+                      float* scores, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (bins) HIP_TRY(hipMemcpy(bins, h->bins.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (idx) HIP_TRY(hipMemcpy(idx, h->idx.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (probs) HIP_TRY(hipMemcpy(probs, h->probs.as<float>() + (size_t)layer * h->n_bins, (h->n_bins - 1) * sizeof(float), hipMemcpyDeviceToHost));
+    if (scores) {
+        if (h->lastQ <= 0) return fail(INFV_ERR_STATE, "no scores yet");
+        const size_t n = (size_t)h->H * h->lastQ * h->N;
+        HIP_TRY(hipMemcpy(scores, h->scores.as<float>() + (size_t)layer * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return INFV_OK;
+}
+
+int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs) {
+    if (int rc = check_handle(h)) return rc;
+    if (layer < 0 || layer >= h->L || !probs) return fail(INFV_ERR_INVALID, "set_probs: bad arguments");
+    HIP_TRY(hipMemcpy(h->probs_override.as<float>() + (size_t)layer * h->n_bins, probs,
+                      (h->n_bins - 1) * sizeof(float), hipMemcpyHostToDevice));
+    const int32_t one = 1;
+    HIP_TRY(hipMemcpy(h->override_flag.as<int32_t>() + layer, &one, sizeof(one), hipMemcpyHostToDevice));
+    return INFV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal interface between the C ABI (ltm_capi.hip) and the gfx950 kernels (ltm_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace infv {
+
+constexpr int kMaxLayers = 8;
+constexpr int kHeadSize = 64;      // dh the attend kernel is written for
+constexpr int kQTile = 16;         // query rows per attend workgroup (one MFMA row tile)
+
+// Device-side view of one ridge operator (first-chunk or infinite-memory) of a plan.
+struct OperatorView {
+    int32_t rows;                 // boxes that receive >=1 new frame
+    const int32_t* row_box;       // [rows]
+    const int32_t* row_begin;     // [rows]
+    const int32_t* row_end;       // [rows]
+    const float* box_val;         // [N]  1/(count+ridge)
+    const int32_t* box_row;       // [N]  row index of box n, -1 if it receives no new frame
+    const int32_t* old_ptr;       // [N+1] or nullptr (first-chunk operator)
+    const int32_t* old_slot;      // CSR payload
+};
+
+struct StickyView {
+    int32_t n_bins;               // 128
+    const int32_t* edge_box;      // [n_bins+1]
+    const float* edge_dx;         // [n_bins]
+    const int32_t* bin_box;       // [n_bins]
+};
+
+struct ProjPtrs {
+    const float* wk[kMaxLayers];
+    const float* bk[kMaxLayers];
+    const float* wv[kMaxLayers];
+    const float* bv[kMaxLayers];
+};
+
+// ---- launchers (all asynchronous on `stream`) -------------------------------------------
+hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream);
+
+// R[c][r][:] = val * sum of the frames of row r of chunk c;  Pnew[sk][c][r][l][kv][dm] = split-K
+// partials of R . W[l][kv]^T  (sk = project_splitk(n_chunks*rows, d) slabs of n_chunks*rows*L*2*dm floats).
+int project_splitk(int M, int K);
+hipError_t launch_project(const float* kbar, int n_chunks, int T, int d, int dm, int n_layers,
+                          const OperatorView& op, const ProjPtrs& proj, float* R, float* Pnew,
+                          hipStream_t stream);
+
+// KV[l][n][0][:] = B[l][n] . Wk[l]^T, KV[l][n][1][:] = B[l][n] . Wv[l]^T (no bias).
+hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
+                            hipStream_t stream);
+
+hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, int32_t* override_flag,
+                       const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
+                       int32_t* bins, int32_t* idx, hipStream_t stream);
+
+// next[l][n] = val_n * sum_{slots s of box n} prev[l][idx[l][s]] + new row of box n, for B and [K'|V'].
+hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
+                         int idx_layer_stride, const float* R, const float* Pnew, int splitk,
+                         long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
+                         float* KV_next, hipStream_t stream);
+
+// scores, count-weighted softmax, read-out and the next sticky histogram partials.
+int attend_parts(int Q, int H);
+hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, const float* KV, const ProjPtrs& proj,
+                         const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
+                         float* bin_part, float* scores, hipStream_t stream);
+
+// bin_mass[j] = sum over parts of bin_part[layer][p][j]
+hipError_t launch_sum_parts(const float* bin_part_layer, int parts, int pitch, float* bin_mass, hipStream_t stream);
+
+}  // namespace infv

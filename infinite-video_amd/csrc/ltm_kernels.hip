@@ -1,0 +1,582 @@
+// gfx950 (MI355X, CDNA4) kernels of the infinity-Video LTM consolidation path.
+//
+// Reference semantics: infty-Video-LLaMA/InfVideoLLaMA/models/long_term_attention_gibbs.py
+// ("LTM.py" below).  With box basis functions the ridge operator G has one non-zero per row,
+// so the reference's dense algebra becomes:
+//     pool      kbar[t]   = mean_p k[t,p]                                    LTM.py:304
+//     rows      R[r]      = val_box(r) * sum_{frames of row r} kbar[f]        LTM.py:189,216-218 (new part of x @ G)
+//     project   Pnew[r]   = R[r] . [Wk;Wv]^T                                  LTM.py:312-313 restricted to new rows
+//     draw      p -> cdf -> bins -> rows idx                                  LTM.py:200-208
+//     update    B'[n]     = val_n * sum_{slots s in box n} B[idx_s] + R[row(n)]      LTM.py:210-216
+//               K'[n], V'[n] likewise from their own previous rows + Pnew (projection is linear,
+//               so projecting the gathered rows == gathering the projected rows)
+//     attend    S = q.(K'+bk)^T/sqrt(dh); alpha = w e^S/(sum w e^S + w_out); ctx = alpha.(V'+bv)
+//               and the next step's sticky bin masses                          LTM.py:224-230,247-248,269-284,200-202
+//
+// Wavefront = 64 lanes everywhere; MFMA shapes are the f32-input ones (exact fp32 fma chains).
+#include "ltm_internal.h"
+
+namespace infv {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ======================================================================================
+// 1. frame mean-pool:  k [n_frames][P][d] -> kbar [n_frames][d]            (LTM.py:304)
+//    One wave per (frame, 256-float column slice): every load instruction of the wave reads
+//    1 KiB contiguous; P loads per lane are independent, so the whole 32 KiB of a unit is in
+//    flight at once.  This is the only HBM-heavy stage of the path (25.2 MB per chunk).
+// ======================================================================================
+template <int UNROLL>
+__global__ __launch_bounds__(256) void pool_frames_kernel(const float* __restrict__ k,
+                                                          float* __restrict__ kbar,
+                                                          long n_units, int P, int d4, int slices) {
+    const int lane = threadIdx.x & 63;
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const long frame = unit / slices;
+    const int c4 = (int)(unit - frame * slices) * 64 + lane;
+    if (c4 >= d4) return;
+    const floatx4* src = reinterpret_cast<const floatx4*>(k) + frame * (long)P * d4 + c4;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + UNROLL <= P; p += UNROLL) {
+        floatx4 v[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) acc += v[i];
+    }
+    for (; p < P; ++p) acc += __builtin_nontemporal_load(src + (long)p * d4);
+    const float fp = (float)P;
+    acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does
+    reinterpret_cast<floatx4*>(kbar)[frame * d4 + c4] = acc;
+}
+
+hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream) {
+    const int d4 = d / 4;
+    const int slices = (d4 + 63) / 64;
+    const long n_units = (long)n_frames * slices;
+    const long blocks = (n_units + 3) / 4;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_frames_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, k, kbar,
+                       n_units, P, d4, slices);
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// 2. new coefficient rows:  R[c][r][:] = val * sum_{f in [begin_r,end_r)} kbar[c][f][:]
+// ======================================================================================
+__global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict__ kbar, int T, int d4,
+                                                         OperatorView op, float* __restrict__ R) {
+    const int r = blockIdx.x, c = blockIdx.y;
+    const int b = op.row_begin[r], e = op.row_end[r];
+    const float val = op.box_val[op.row_box[r]];
+    const floatx4* src = reinterpret_cast<const floatx4*>(kbar) + ((long)c * T) * d4;
+    floatx4* dst = reinterpret_cast<floatx4*>(R) + ((long)c * op.rows + r) * d4;
+    for (int c4 = threadIdx.x; c4 < d4; c4 += blockDim.x) {
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int f = b; f < e; ++f) {
+            const floatx4 v = src[(long)f * d4 + c4];
+            acc.x = fmaf(val, v.x, acc.x); acc.y = fmaf(val, v.y, acc.y);
+            acc.z = fmaf(val, v.z, acc.z); acc.w = fmaf(val, v.w, acc.w);
+        }
+        dst[c4] = acc;
+    }
+}
+
+// ======================================================================================
+// 3. projection GEMM (NT):  C[sk][m][o] = sum_{k in split sk} A[m][k] * Wrow(o)[k]
+//    A [M][K] row-major; Wrow(o) = row (o % dm) of wk/wv of layer layer_base + o/(2dm).
+//    fp32 MFMA 32x32x2, block tile BM x BN x 32, 4 waves as 2x2, register-staged prefetch.
+// ======================================================================================
+constexpr int kBK = 32;
+constexpr int kLdsStride = kBK + 4;   // +1 access width (16 B) against ds_read_b128 conflicts
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
+                                                      ProjPtrs proj, int layer_base, int dm,
+                                                      float* __restrict__ C, int ldc, long split_stride,
+                                                      int k_per_split) {
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave in each dim
+    constexpr int AR = BM / 32, BR = BN / 32;          // rows staged per thread
+    __shared__ float As[BM * kLdsStride];
+    __shared__ float Bs[BN * kLdsStride];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int ntiles = k_per_split / kBK;
+    C += (long)blockIdx.z * split_stride;
+
+    // staging map: thread -> (row0 + 32*i, float4 column c4)
+    const int c4 = tid & 7, row0 = tid >> 3;
+    const float* a_src[AR];
+    const float* b_src[BR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        a_src[i] = (m < M) ? A + (long)m * K + kbeg + c4 * 4 : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int o = n0 + row0 + 32 * i;
+        const int l = layer_base + o / (2 * dm);
+        const int kv = (o / dm) & 1;
+        const float* w = kv ? proj.wv[l] : proj.wk[l];
+        b_src[i] = w + (long)(o % dm) * K + kbeg + c4 * 4;
+    }
+
+    floatx4 a_reg[AR], b_reg[BR];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            a_reg[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + t * kBK)
+                                : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < BR; ++i) b_reg[i] = *reinterpret_cast<const floatx4*>(b_src[i] + t * kBK);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<floatx4*>(&As[(row0 + 32 * i) * kLdsStride + c4 * 4]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<floatx4*>(&Bs[(row0 + 32 * i) * kLdsStride + c4 * 4]) = b_reg[i];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, kk = lane >> 5;     // MFMA 32x32x2: row/col = lane&31, k = lane>>5
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
+        // lane half kk consumes k = 16*kk + s at MFMA step s (any bijection of k works as long
+        // as A and B agree): 4 x ds_read_b128 per operand tile.
+        floatx4 af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                af[i][v] = *reinterpret_cast<const floatx4*>(
+                    &As[(wm * (BM / 2) + i * 32 + li) * kLdsStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                bf[j][v] = *reinterpret_cast<const floatx4*>(
+                    &Bs[(wn * (BN / 2) + j * 32 + li) * kLdsStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j][s >> 2][s & 3],
+                                                                     acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int o = n0 + wn * (BN / 2) + j * 32 + li;
+                if (m < M) C[(long)m * ldc + o] = acc[i][j][r];
+            }
+}
+
+static hipError_t launch_gemm(const float* A, int M, int K, const ProjPtrs& proj, int layer_base, int dm,
+                              int n_cols, float* C, int ldc, int splitk, long split_stride,
+                              hipStream_t stream) {
+    if (M <= 0) return hipSuccess;
+    const int k_per_split = K / splitk;
+    if (M >= 1024) {
+        dim3 grid((M + 127) / 128, n_cols / 128, splitk);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, proj,
+                           layer_base, dm, C, ldc, split_stride, k_per_split);
+    } else {
+        dim3 grid((M + 63) / 64, n_cols / 64, splitk);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, proj, layer_base,
+                           dm, C, ldc, split_stride, k_per_split);
+    }
+    return hipGetLastError();
+}
+
+int project_splitk(int M, int K) {
+    // small-M calls (one chunk) cannot fill 256 CUs with output tiles alone: split K.
+    if (M >= 1024) return 1;
+    int sk = 8;
+    while (sk > 1 && (K % (sk * kBK)) != 0) sk >>= 1;
+    return sk;
+}
+
+hipError_t launch_project(const float* kbar, int n_chunks, int T, int d, int dm, int n_layers,
+                          const OperatorView& op, const ProjPtrs& proj, float* R, float* Pnew,
+                          hipStream_t stream) {
+    if (op.rows == 0 || n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_rows_kernel, dim3(op.rows, n_chunks), dim3(256), 0, stream, kbar, T, d / 4, op, R);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int M = n_chunks * op.rows;
+    const int n_cols = n_layers * 2 * dm;
+    const int sk = project_splitk(M, d);
+    return launch_gemm(R, M, d, proj, 0, dm, n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream);
+}
+
+// ======================================================================================
+// 4. Gibbs / sticky draw, one workgroup per layer                         (LTM.py:202-208)
+//    p_raw[j] = sum over (head, q-tile) partials; normalised twice (LTM.py:203 and
+//    torch.distributions.Categorical); then torch.multinomial's CPU algorithm: fp32
+//    sequential running sum, / total, last bucket forced to 1, lower-bound search of each
+//    float64 uniform.  The cdf arithmetic is bit-exact IEEE fp32, so the draw is bit-exact
+//    given identical probs.
+// ======================================================================================
+__device__ inline double block_sum_256(double v, double* scratch) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin_part, int parts,
+                                                   const float* __restrict__ probs_override,
+                                                   int32_t* __restrict__ override_flag, StickyView sticky,
+                                                   const double* __restrict__ u, int S,
+                                                   float* __restrict__ probs_out, int32_t* __restrict__ bins_out,
+                                                   int32_t* __restrict__ idx_out) {
+    __shared__ double scratch[4];
+    __shared__ float cdf[256];
+    const int l = blockIdx.x, j = threadIdx.x;
+    const int nb = sticky.n_bins - 1;                 // 127 usable bins (LTM.py:202)
+    const int nbp = sticky.n_bins;                    // row pitch of the partial / probs arrays
+    float prob = 0.f;
+    if (override_flag[l]) {
+        if (j < nb) prob = probs_override[l * nbp + j];
+    } else {
+        double acc = 0.0;
+        if (j < nb)
+            for (int p = 0; p < parts; ++p) acc += (double)bin_part[((long)l * parts + p) * nbp + j];
+        const float raw = (float)acc;
+        const float tot1 = (float)block_sum_256((double)raw, scratch);
+        const float p1 = raw / tot1;
+        const float tot2 = (float)block_sum_256((j < nb) ? (double)p1 : 0.0, scratch);
+        prob = p1 / tot2;
+    }
+    if (j < nb) { probs_out[l * nbp + j] = prob; cdf[j] = prob; }
+    __syncthreads();
+    if (j == 0) {
+        override_flag[l] = 0;
+        float run = 0.f;
+        for (int i = 0; i < nb; ++i) { run = run + cdf[i]; cdf[i] = run; }
+        for (int i = 0; i < nb; ++i) cdf[i] = cdf[i] / run;
+        cdf[nb - 1] = 1.f;
+    }
+    __syncthreads();
+    for (int s = j; s < S; s += blockDim.x) {
+        const double us = u[(long)l * S + s];
+        int lo = 0, hi = nb;
+        while (hi - lo > 0) {
+            const int mid = lo + (hi - lo) / 2;
+            if ((double)cdf[mid] < us) lo = mid + 1; else hi = mid;
+        }
+        bins_out[(long)l * S + s] = lo;
+        idx_out[(long)l * S + s] = sticky.bin_box[lo];
+    }
+}
+
+hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, int32_t* override_flag,
+                       const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
+                       int32_t* bins, int32_t* idx, hipStream_t stream) {
+    hipLaunchKernelGGL(draw_kernel, dim3(n_layers), dim3(256), 0, stream, bin_part, parts, probs_override,
+                       override_flag, sticky, u, S, probs, bins, idx);
+    return hipGetLastError();
+}
+
+// ======================================================================================
+// 5. memory update: one workgroup per (box n, layer), three row families at once.
+//    next[n] = val_n * sum_{s in slots(n)} prev[idx[s]]  +  new row of box n
+// ======================================================================================
+__global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int d4, int dm4, int n_layers,
+                                                     int S, const int32_t* __restrict__ idx,
+                                                     int idx_layer_stride, const float* __restrict__ R,
+                                                     const float* __restrict__ Pnew, int splitk,
+                                                     long split_stride4,
+                                                     const float* __restrict__ B_prev,
+                                                     const float* __restrict__ KV_prev,
+                                                     float* __restrict__ B_next, float* __restrict__ KV_next) {
+    const int n = blockIdx.x, l = blockIdx.y;
+    const float val = op.box_val[n];
+    const int row = op.box_row[n];
+    int sb = 0, se = 0;
+    if (op.old_ptr != nullptr && idx != nullptr) { sb = op.old_ptr[n]; se = op.old_ptr[n + 1]; }
+    const int32_t* my_idx = idx ? idx + (long)l * idx_layer_stride : nullptr;
+    const int kv4 = 2 * dm4;                                   // floats4 of a [K'|V'] row
+    const int total4 = d4 + kv4;
+    const floatx4* Bp = reinterpret_cast<const floatx4*>(B_prev) + (long)l * N * d4;
+    const floatx4* KVp = reinterpret_cast<const floatx4*>(KV_prev) + (long)l * N * kv4;
+    floatx4* Bn = reinterpret_cast<floatx4*>(B_next) + ((long)l * N + n) * d4;
+    floatx4* KVn = reinterpret_cast<floatx4*>(KV_next) + ((long)l * N + n) * kv4;
+    const floatx4* R4 = reinterpret_cast<const floatx4*>(R);
+    const floatx4* P4 = reinterpret_cast<const floatx4*>(Pnew);
+    for (int c = threadIdx.x; c < total4; c += blockDim.x) {
+        const bool isB = c < d4;
+        const int cc = isB ? c : c - d4;
+        const int pitch = isB ? d4 : kv4;
+        const floatx4* prev = isB ? Bp : KVp;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = sb; s < se; ++s) {
+            const int src = my_idx[op.old_slot[s]];
+            if (src >= 0) {
+                const floatx4 v = prev[(long)src * pitch + cc];
+                acc.x = fmaf(val, v.x, acc.x); acc.y = fmaf(val, v.y, acc.y);
+                acc.z = fmaf(val, v.z, acc.z); acc.w = fmaf(val, v.w, acc.w);
+            }
+        }
+        if (row >= 0) {
+            if (isB) {
+                acc += R4[(long)row * d4 + cc];
+            } else {
+                const long off = ((long)row * n_layers + l) * kv4 + cc;
+                for (int k = 0; k < splitk; ++k) acc += P4[off + k * split_stride4];
+            }
+        }
+        (isB ? Bn : KVn)[cc] = acc;
+    }
+}
+
+hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
+                         int idx_layer_stride, const float* R, const float* Pnew, int splitk,
+                         long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
+                         float* KV_next, hipStream_t stream) {
+    hipLaunchKernelGGL(update_kernel, dim3(N, n_layers), dim3(256), 0, stream, op, N, d / 4, dm / 4, n_layers, S,
+                       idx, idx_layer_stride, R, Pnew, splitk, split_stride / 4, B_prev, KV_prev, B_next,
+                       KV_next);
+    return hipGetLastError();
+}
+
+hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
+                            hipStream_t stream) {
+    for (int l = 0; l < n_layers; ++l) {
+        hipError_t e = launch_gemm(B + (long)l * N * d, N, d, proj, l, dm, 2 * dm, KV + (long)l * N * 2 * dm,
+                                   2 * dm, 1, 0, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ======================================================================================
+// 6. attend: one workgroup per (head h, 16-row query tile, layer).
+//      S[q][n]  = (q_h[q] . (K'_h[n] + bk_h)) / sqrt(dh)            MFMA 16x16x4 f32, K' from L2
+//      alpha    = w_n e^{S} / (sum_m w_m e^{S_m} + w_out)           wave shuffles, rows in LDS
+//      ctx[q]   = sum_n alpha[q][n] (V'_h[n] + bv_h)                MFMA 16x16x4 f32, V' staged in LDS
+//      bin_part[j] = sum_{rows} trapezoid mass of histogram interval j+1 of the row's density
+// ======================================================================================
+constexpr int kVRows = 128;              // V' rows staged per pass
+constexpr int kVStride = 80;             // row pitch (floats): == 16 mod 32 -> conflict-free b32 column reads
+
+__global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q, int Q, int N, int H,
+                                                     const float* __restrict__ KV, ProjPtrs proj,
+                                                     const float* __restrict__ readout_w, float w_out,
+                                                     StickyView sticky, float* __restrict__ ctx,
+                                                     float* __restrict__ bin_part, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int sstride = N + 2;                          // == 2 mod 32 for N % 32 == 0
+    float* Ssm = lds;                                   // [16][N+2]   scores, then alpha
+    float* Vsm = lds + ((kQTile * sstride + 3) & ~3);   // [128][80]   V' rows of the current pass (16-B aligned)
+    float* Dsm = Vsm + kVRows * kVStride;               // [16][132]   edge densities
+    float* Msm = Dsm + kQTile * 132;                    // [16][128]   per-row bin masses
+    float* cq = Msm + kQTile * 128;                     // [16] q . bk
+    float* asum = cq + 16;                              // [16] sum_n alpha
+
+    const int h = blockIdx.x, qt = blockIdx.y, l = blockIdx.z;
+    const int QT = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dm = H * kHeadSize;
+    const int c = lane & 15, g = lane >> 4;
+    const float scale = 1.0f / sqrtf((float)kHeadSize);
+    const float* ql = q + (long)l * Q * dm;
+    const float* KVl = KV + (long)l * N * 2 * dm;
+    const float* bk = proj.bk[l] + h * kHeadSize;
+    const float* bv = proj.bv[l] + h * kHeadSize;
+
+    // ---- q fragment (A operand): lane (row c, group g) holds q[row][16g + j], j = 0..15 ----
+    float qa[16];
+    {
+        const int row = qt * kQTile + c;
+        if (row < Q) {
+            const floatx4* src = reinterpret_cast<const floatx4*>(ql + (long)row * dm + h * kHeadSize + 16 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const floatx4 t = src[v];
+                qa[4 * v + 0] = t.x * scale; qa[4 * v + 1] = t.y * scale;
+                qa[4 * v + 2] = t.z * scale; qa[4 * v + 3] = t.w * scale;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) qa[j] = 0.f;
+        }
+    }
+    // q . bk per row: lanes of one row are (c, g=0..3); wave 0 computes and shares it.
+    if (wave == 0) {
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part = fmaf(qa[j], bk[16 * g + j], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (g == 0) cq[c] = part;
+    }
+    __syncthreads();
+
+    // ---- scores: n-tiles of 16 boxes round-robin over the 4 waves ----
+    for (int nt = wave; nt < N / 16; nt += 4) {
+        const floatx4* src = reinterpret_cast<const floatx4*>(KVl + (long)(nt * 16 + c) * 2 * dm + h * kHeadSize + 16 * g);
+        floatx4 kb[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) kb[v] = src[v];
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[j], kb[j >> 2][j & 3], acc, 0, 0, 0);
+        // C/D map 16x16: col = lane&15 (box), row = 4*(lane>>4) + reg (query row)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            const float s = acc[r] + cq[row];
+            Ssm[row * sstride + nt * 16 + c] = s;
+            if (scores != nullptr && qt * kQTile + row < Q)
+                scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- row-wise phase: 16 threads per query row ----
+    const int row = tid >> 4, sub = tid & 15;
+    const bool row_valid = (qt * kQTile + row) < Q;
+    float m = -INFINITY;
+    for (int n = sub; n < N; n += 16) m = fmaxf(m, Ssm[row * sstride + n]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // densities at the histogram edges (stabilised by max(m,0): outside edges score 0)
+    const float md = fmaxf(m, 0.f);
+    const int ne = sticky.n_bins + 1;
+    for (int j = sub; j < ne; j += 16) {
+        const int eb = sticky.edge_box[j];
+        const float sc = (eb >= 0) ? Ssm[row * sstride + eb] : 0.f;
+        Dsm[row * 132 + j] = expf(sc - md);
+    }
+    __syncthreads();                                   // all raw-score reads done before alpha overwrites
+    float esum = 0.f;
+    for (int n = sub; n < N; n += 16) {
+        const float e = readout_w[n] * expf(Ssm[row * sstride + n] - m);
+        Ssm[row * sstride + n] = e;
+        esum += e;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
+    const float inv = 1.0f / (esum + w_out * expf(-m));
+    for (int n = sub; n < N; n += 16) Ssm[row * sstride + n] *= inv;
+    if (sub == 0) asum[row] = esum * inv;
+    // trapezoid normaliser of the edge density
+    float z = 0.f;
+    for (int j = sub; j < sticky.n_bins; j += 16)
+        z += (Dsm[row * 132 + j] + Dsm[row * 132 + j + 1]) * sticky.edge_dx[j];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) z += __shfl_xor(z, off);
+    z *= 0.5f;
+    // mass of interval j+1 -> bin j  (cum[j+1]-cum[j], LTM.py:201-202), j = 0..n_bins-2
+    for (int j = sub; j < sticky.n_bins - 1; j += 16) {
+        const float dl = Dsm[row * 132 + j + 1] / z, dr = Dsm[row * 132 + j + 2] / z;
+        Msm[row * 128 + j] = row_valid ? ((dl + dr) * sticky.edge_dx[j + 1]) * 0.5f : 0.f;
+    }
+    __syncthreads();
+    if (tid < sticky.n_bins - 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < kQTile; ++r) t += Msm[r * 128 + tid];
+        bin_part[(((long)l * H + h) * QT + qt) * sticky.n_bins + tid] = t;
+    }
+
+    // ---- read-out: wave w owns output columns [16w, 16w+16) of the head ----
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < N; base += kVRows) {
+        const int rows = min(kVRows, N - base);
+        __syncthreads();                               // previous pass's MFMA reads are done
+        for (int i = tid; i < rows * 16; i += 256) {
+            const int r = i >> 4, c4 = i & 15;
+            const floatx4 v = *reinterpret_cast<const floatx4*>(
+                KVl + (long)(base + r) * 2 * dm + dm + h * kHeadSize + c4 * 4);
+            *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = v;
+        }
+        __syncthreads();
+        for (int t = 0; t < rows / 4; ++t) {
+            const float a = Ssm[c * sstride + base + 4 * t + g];          // alpha[row c][n]
+            const float b = Vsm[(4 * t + g) * kVStride + 16 * wave + c];  // V'[n][col]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        const int qrow = qt * kQTile + rr;
+        if (qrow < Q) {
+            const int col = 16 * wave + c;
+            ctx[((long)l * Q + qrow) * dm + h * kHeadSize + col] = acc[r] + asum[rr] * bv[col];
+        }
+    }
+}
+
+int attend_parts(int Q, int H) { return H * ((Q + kQTile - 1) / kQTile); }
+
+size_t attend_lds_bytes(int N) {
+    const int sstride = N + 2;
+    size_t floats = ((kQTile * sstride + 3) & ~3) + kVRows * kVStride + kQTile * 132 + kQTile * 128 + 64;
+    return floats * sizeof(float);
+}
+
+hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, const float* KV, const ProjPtrs& proj,
+                         const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
+                         float* bin_part, float* scores, hipStream_t stream) {
+    const int QT = (Q + kQTile - 1) / kQTile;
+    const size_t lds = attend_lds_bytes(N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attend_kernel, dim3(H, QT, n_layers), dim3(256), lds, stream, q, Q, N, H, KV, proj,
+                       readout_w, readout_w_out, sticky, ctx, bin_part, scores);
+    return hipGetLastError();
+}
+
+}  // namespace infv
+
+namespace infv {
+__global__ void sum_parts_kernel(const float* __restrict__ part, int parts, int pitch, float* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j >= pitch) return;
+    double acc = 0.0;
+    for (int p = 0; p < parts; ++p) acc += (double)part[(long)p * pitch + j];
+    out[j] = (float)acc;
+}
+hipError_t launch_sum_parts(const float* bin_part_layer, int parts, int pitch, float* bin_mass, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, stream, bin_part_layer, parts, pitch, bin_mass);
+    return hipGetLastError();
+}
+}  // namespace infv

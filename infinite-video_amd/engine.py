@@ -1,0 +1,253 @@
+"""Thin torch-facing wrapper of one ``infv_ltm_handle``: device pointers in, device tensors out.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every number is produced by
+the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .basis_maps import NB_BINS, NB_SAMPLES, Plan, build_plan
+
+ProjTensors = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]   # (wk, bk, wv, bv)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _np_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _check_dev(t: torch.Tensor, device: torch.device, name: str, dtype=torch.float32):
+    if t.device != device:
+        raise ValueError(f"{name} is on {t.device}, engine is on {device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+class LTMEngine:
+    """``n_layers`` LTM instances (one per cross-attention layer) stepped together on one GPU."""
+
+    def __init__(self, num_basis: int, n_heads: int, head_size: int, d_in: int, tokens_per_frame: int,
+                 tau: float, sticky: bool, n_layers: int = 1, max_q: int = 32,
+                 device: Optional[torch.device] = None, nb_samples: int = NB_SAMPLES,
+                 max_batch_chunks: int = 32):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("LTMEngine needs a HIP device (no CPU fallback exists)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.N, self.H, self.dh, self.d, self.P = num_basis, n_heads, head_size, d_in, tokens_per_frame
+        self.dm = n_heads * head_size
+        self.tau, self.sticky, self.L, self.S = float(tau), bool(sticky), n_layers, nb_samples
+        self.max_q = max_q
+        cfg = _lib.Config(num_basis, n_heads, head_size, d_in, tokens_per_frame, n_layers, nb_samples,
+                          int(self.sticky), max_q, max_batch_chunks)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_create(C.byref(cfg), C.byref(handle)))
+        self._h = handle
+        self._plans = {}
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.lib.infv_ltm_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ plans
+    def ensure_plan(self, T: int) -> Plan:
+        if T in self._plans:
+            return self._plans[T]
+        p = build_plan(int(T), self.N, self.tau, self.S)
+        arrs = dict(
+            first_row_box=_np_i32(p.first_row_box), first_row_begin=_np_i32(p.first_row_begin),
+            first_row_end=_np_i32(p.first_row_end), first_box_val=_np_f32(p.first_box_val),
+            inf_row_box=_np_i32(p.inf_row_box), inf_row_begin=_np_i32(p.inf_row_begin),
+            inf_row_end=_np_i32(p.inf_row_end), inf_box_val=_np_f32(p.inf_box_val),
+            inf_old_ptr=_np_i32(p.inf_old_ptr), inf_old_slot=_np_i32(p.inf_old_slot),
+            readout_w=_np_f32(p.readout_w), edge_box=_np_i32(p.edge_box), edge_dx=_np_f32(p.edge_dx),
+            bin_box=_np_i32(p.bin_box), uniform_idx=_np_i32(p.uniform_idx))
+        ip = lambda k: arrs[k].ctypes.data_as(_lib.i32p)
+        fp = lambda k: arrs[k].ctypes.data_as(_lib.f32p)
+        s = _lib.PlanStruct(
+            T=int(T), first_rows=len(p.first_row_box), first_row_box=ip("first_row_box"),
+            first_row_begin=ip("first_row_begin"), first_row_end=ip("first_row_end"),
+            first_box_val=fp("first_box_val"), inf_rows=len(p.inf_row_box), inf_row_box=ip("inf_row_box"),
+            inf_row_begin=ip("inf_row_begin"), inf_row_end=ip("inf_row_end"), inf_box_val=fp("inf_box_val"),
+            inf_old_ptr=ip("inf_old_ptr"), inf_old_slot=ip("inf_old_slot"), readout_w=fp("readout_w"),
+            readout_w_out=p.readout_w_out, n_bins=NB_BINS, edge_box=ip("edge_box"), edge_dx=fp("edge_dx"),
+            bin_box=ip("bin_box"), uniform_idx=ip("uniform_idx"))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_set_plan(self._h, C.byref(s)))
+        self._plans[T] = p
+        return p
+
+    # ------------------------------------------------------------------ helpers
+    def _proj_array(self, projs: Sequence[ProjTensors]):
+        if len(projs) != self.L:
+            raise ValueError(f"expected projections for {self.L} layers, got {len(projs)}")
+        arr = (_lib.Proj * self.L)()
+        for l, (wk, bk, wv, bv) in enumerate(projs):
+            for name, t, shape in (("wk", wk, (self.dm, self.d)), ("bk", bk, (self.dm,)),
+                                   ("wv", wv, (self.dm, self.d)), ("bv", bv, (self.dm,))):
+                _check_dev(t, self.device, f"{name}[{l}]")
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{name}[{l}] has shape {tuple(t.shape)}, expected {shape}")
+            arr[l] = _lib.Proj(wk.data_ptr(), bk.data_ptr(), wv.data_ptr(), bv.data_ptr())
+        return arr
+
+    def _check_q(self, q: torch.Tensor) -> int:
+        _check_dev(q, self.device, "q")
+        if q.dim() != 3 or q.shape[0] != self.L or q.shape[2] != self.dm:
+            raise ValueError(f"q must be [{self.L}, Q, {self.dm}], got {tuple(q.shape)}")
+        if q.shape[1] > self.max_q:
+            raise ValueError(f"Q={q.shape[1]} exceeds max_q={self.max_q}")
+        return int(q.shape[1])
+
+    def _check_u(self, u: Optional[torch.Tensor], lead: Tuple[int, ...]):
+        if u is None:
+            return
+        _check_dev(u, self.device, "u", torch.float64)
+        if tuple(u.shape) != lead + (self.L, self.S):
+            raise ValueError(f"u must be {lead + (self.L, self.S)}, got {tuple(u.shape)}")
+
+    @property
+    def has_memory(self) -> bool:
+        return bool(_lib.check(self.lib.infv_ltm_has_memory(self._h)))
+
+    def reset(self):
+        _lib.check(self.lib.infv_ltm_reset(self._h))
+
+    # ------------------------------------------------------------------ operators
+    def pool(self, k: torch.Tensor) -> torch.Tensor:
+        """k [..., T*P, d] -> frame means [..., T, d]   (reference :304)."""
+        _check_dev(k, self.device, "k")
+        if k.shape[-1] != self.d or k.shape[-2] % self.P:
+            raise ValueError(f"k must be [..., T*{self.P}, {self.d}], got {tuple(k.shape)}")
+        n_frames = k.numel() // (self.P * self.d)
+        out = torch.empty(k.shape[:-2] + (k.shape[-2] // self.P, self.d), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_pool(self._h, _ptr(k), n_frames, _ptr(out), _stream(self.device)))
+        return out
+
+    def step(self, kbar: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
+             u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One chunk from pooled frames kbar [T, d]; q [L, Q, dm]; u [L, S] f64 -> ctx [L, Q, dm]."""
+        _check_dev(kbar, self.device, "kbar")
+        T = int(kbar.shape[0])
+        Q = self._check_q(q)
+        self._check_u(u, ())
+        self.ensure_plan(T)
+        ctx = torch.empty(self.L, Q, self.dm, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_step(self._h, _ptr(kbar), T, _ptr(q), Q, self._proj_array(projs),
+                                               _ptr(u), _ptr(ctx), _stream(self.device)))
+        return ctx
+
+    def forward(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
+                u: Optional[torch.Tensor] = None, new_doc: bool = False) -> torch.Tensor:
+        """LongTermAttention.forward for all layers: k [T*P, d], q [L, Q, dm] -> ctx [L, Q, dm]."""
+        _check_dev(k, self.device, "k")
+        if k.dim() != 2 or k.shape[1] != self.d or k.shape[0] % self.P:
+            raise ValueError(f"k must be [T*{self.P}, {self.d}], got {tuple(k.shape)}")
+        T = k.shape[0] // self.P
+        Q = self._check_q(q)
+        self._check_u(u, ())
+        self.ensure_plan(T)
+        ctx = torch.empty(self.L, Q, self.dm, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_forward(self._h, _ptr(k), T, _ptr(q), Q, self._proj_array(projs),
+                                                  _ptr(u), int(new_doc), _ptr(ctx), _stream(self.device)))
+        return ctx
+
+    def consolidate(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
+                    u: Optional[torch.Tensor] = None, new_doc: bool = True,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Whole-video loop: k [C, T*P, d], q [L, Q, dm], u [C, L, S] -> ctx [C, L, Q, dm]."""
+        _check_dev(k, self.device, "k")
+        if k.dim() != 3 or k.shape[2] != self.d or k.shape[1] % self.P:
+            raise ValueError(f"k must be [C, T*{self.P}, {self.d}], got {tuple(k.shape)}")
+        Cn, T = int(k.shape[0]), k.shape[1] // self.P
+        Q = self._check_q(q)
+        self._check_u(u, (Cn,))
+        self.ensure_plan(T)
+        if out is None:
+            out = torch.empty(Cn, self.L, Q, self.dm, device=self.device, dtype=torch.float32)
+        else:
+            _check_dev(out, self.device, "out")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_consolidate(self._h, _ptr(k), Cn, T, _ptr(q), Q, self._proj_array(projs),
+                                                      _ptr(u), int(new_doc), _ptr(out), _stream(self.device)))
+        return out
+
+    # ------------------------------------------------------------------ state
+    def export_state(self, layer: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(B_past [N, d], unnormalised sticky bin masses [127]) of one layer."""
+        B = torch.empty(self.N, self.d, device=self.device, dtype=torch.float32)
+        mass = torch.empty(NB_BINS, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_export_state(self._h, layer, _ptr(B), _ptr(mass), _stream(self.device)))
+        return B, mass[:NB_BINS - 1]
+
+    def import_state(self, layer: int, B: torch.Tensor, bin_mass: Optional[torch.Tensor], proj: ProjTensors):
+        _check_dev(B, self.device, "B")
+        if tuple(B.shape) != (self.N, self.d):
+            raise ValueError(f"B must be [{self.N}, {self.d}]")
+        if bin_mass is not None:
+            _check_dev(bin_mass, self.device, "bin_mass")
+            if bin_mass.numel() != NB_BINS - 1:
+                raise ValueError(f"bin_mass must have {NB_BINS - 1} entries")
+        p = _lib.Proj(*(t.data_ptr() for t in proj))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_import_state(self._h, layer, _ptr(B), _ptr(bin_mass), C.byref(p),
+                                                       _stream(self.device)))
+
+    def reproject(self, projs: Sequence[ProjTensors]):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_reproject(self._h, self._proj_array(projs), _stream(self.device)))
+
+    def last_draw(self, layer: int, want_scores: bool = False):
+        """(bins [S], idx [S], probs [127][, scores [H,Q,N]]) of the last sticky step (host numpy)."""
+        bins = np.empty(self.S, np.int32)
+        idx = np.empty(self.S, np.int32)
+        probs = np.empty(NB_BINS - 1, np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_get_draw(
+                self._h, layer, bins.ctypes.data_as(_lib.i32p), idx.ctypes.data_as(_lib.i32p),
+                probs.ctypes.data_as(_lib.f32p), None, _stream(self.device)))
+        return bins, idx, probs
+
+    def last_scores(self, layer: int, Q: int) -> np.ndarray:
+        sc = np.empty((self.H, Q, self.N), np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_get_draw(self._h, layer, None, None, None,
+                                                  sc.ctypes.data_as(_lib.f32p), _stream(self.device)))
+        return sc
+
+    def set_probs(self, layer: int, probs: np.ndarray):
+        p = _np_f32(probs)
+        if p.size != NB_BINS - 1:
+            raise ValueError(f"probs must have {NB_BINS - 1} entries")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_set_probs(self._h, layer, p.ctypes.data_as(_lib.f32p)))

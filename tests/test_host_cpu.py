@@ -1,0 +1,98 @@
+"""CPU-only checks of the host logic: plan construction vs the oracle's maps and the
+reference goldens, and that the C-ABI library loads and exports every declared symbol."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from infinite_video_amd import _lib, basis_maps
+from oracle import ltm_oracle as O
+from tests.golden.cases import CASES, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _expand_first(plan):
+    col = np.full(plan.T, -1, np.int32)
+    for b, s, e in zip(plan.first_row_box, plan.first_row_begin, plan.first_row_end):
+        col[s:e] = b
+    return col
+
+
+def _expand_inf(plan):
+    col = np.full(plan.S + plan.T, -1, np.int32)
+    for n in range(plan.N):
+        for s in plan.inf_old_slot[plan.inf_old_ptr[n]:plan.inf_old_ptr[n + 1]]:
+            col[s] = n
+    for b, s, e in zip(plan.inf_row_box, plan.inf_row_begin, plan.inf_row_end):
+        col[plan.S + s:plan.S + e] = b
+    return col
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
+def test_plan_matches_reference_operator_goldens(case):
+    g = load_golden(case)
+    for T in sorted(set(case.chunk_T)):
+        p = basis_maps.build_plan(T, case.N, case.tau)
+        fc, ic = _expand_first(p), _expand_inf(p)
+        np.testing.assert_array_equal(fc, g[f"T{T}_first_col"])
+        np.testing.assert_array_equal(ic, g[f"T{T}_inf_col"])
+        fv = np.where(fc >= 0, p.first_box_val[np.maximum(fc, 0)], 0).astype(np.float32)
+        iv = np.where(ic >= 0, p.inf_box_val[np.maximum(ic, 0)], 0).astype(np.float32)
+        np.testing.assert_array_equal(fv, g[f"T{T}_first_val"])
+        np.testing.assert_array_equal(iv, g[f"T{T}_inf_val"])
+        np.testing.assert_array_equal(p.uniform_idx, g[f"T{T}_uniform_idx"])
+
+
+@pytest.mark.parametrize("T,N,tau", [(8, 64, .75), (7, 64, .75), (16, 64, .5), (256, 256, .75), (255, 256, .75),
+                                     (2, 16, .9), (100, 128, .3), (32, 1024, .75)])
+def test_plan_matches_oracle_maps(T, N, tau):
+    p = basis_maps.build_plan(T, N, tau)
+    m = O.build_maps(T, N, tau)
+    np.testing.assert_array_equal(_expand_first(p), m.first_col)
+    np.testing.assert_array_equal(_expand_inf(p), m.inf_col)
+    np.testing.assert_array_equal(p.readout_w, m.w)
+    assert p.readout_w_out == pytest.approx(m.w_out, abs=0)
+    mod, edge_box, bin_box = O.sticky_bin_rows(N)
+    np.testing.assert_array_equal(p.edge_box, edge_box)
+    np.testing.assert_array_equal(p.bin_box, bin_box[:128])
+    np.testing.assert_array_equal(p.edge_dx, (mod[1:] - mod[:-1]).astype(np.float32))
+    np.testing.assert_array_equal(p.uniform_idx, m.uniform_idx)
+    # every slot / frame accounted for exactly once; last frame (t = 1.0) dropped
+    assert p.inf_old_ptr[-1] == len(p.inf_old_slot)
+    assert _expand_inf(p)[-1] == -1
+
+
+def test_plan_rejects_single_frame_chunks():
+    with pytest.raises(basis_maps.UnsupportedBasis):
+        basis_maps.build_plan(1, 64, .75)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/infv_ltm.h <-> libinfv_ltm.so <-> the ctypes table, without touching a GPU."""
+    header = open(os.path.join(ROOT, "include", "infv_ltm.h")).read()
+    declared = set(re.findall(r"\b(infv_ltm_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.infv_ltm_abi_version() == _lib.ABI_VERSION
+    # argument validation needs no device
+    assert lib.infv_ltm_create(None, None) == -1
+    assert b"null" in lib.infv_ltm_last_error()
+    cfg = _lib.Config(64, 12, 32, 768, 32, 1, 512, 1, 32, 8)      # head_size 32: unsupported
+    h = ctypes.c_void_p()
+    assert lib.infv_ltm_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+    assert lib.infv_ltm_has_plan(None, 8) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "infinite-video_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
