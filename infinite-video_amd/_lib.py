@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so.7; libinfv_ltm.so needs the same SONAME.  torch must be
+# imported first so that both share ONE HIP runtime (the stream handles torch hands us belong to
+# it); loading ours first would bind /opt/rocm's copy and leave torch's streams foreign.
+import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinfv_ltm.so")
 ABI_VERSION = 1
