@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frame-chunks/sec consolidated (max_int=256, num_basis=256, d=768).
+
+One "step" = one pass of the LTM consolidation path over a synthetic video of ``--chunks``
+chunks (default 2048, BASELINE.json configs[1]/[2]): every chunk's frame tokens [256*32, 768]
+are mean-pooled, regressed onto 256 box bases, the sticky (Gibbs-sampled) memory of BOTH video
+Q-former LTM layers is updated and read out.  The Q-former/LLM are stubbed (the op is called
+directly; with alpha=1.0 the reference bypasses it, Qformer.py:220-223).  Inputs are resident
+in HBM before the timed region.  With N > 1 ranks the video is cut into contiguous blocks
+(strong scaling: total work fixed), each rank consolidates its block as its own document and one
+RCCL all-gather exchanges the consolidated memories (infinite_video_amd.video_memory).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md), the graded roofline
+T, P, D, N, H, DH, Q, L, TAU, S = 256, 32, 768, 256, 12, 64, 32, 2, 0.75, 512
+DM = H * DH
+BYTES_K = 4 * T * P * D                                            # 25 165 824
+BYTES_POOL_PER_CHUNK = BYTES_K + 4 * T * D                         # pool kernel: read k, write kbar
+BYTES_LAYER = 4 * 2 * N * D + 4 * 2 * (D * DM + DM) + 4 * 2 * Q * DM + 4 * 2 * H * Q * N
+BYTES_PER_CHUNK = BYTES_K + L * BYTES_LAYER                        # 39 727 104
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunks", type=int, default=2048, help="chunks of the synthetic video (whole job)")
+    ap.add_argument("--batch-chunks", type=int, default=32, help="chunks pooled/projected per sub-batch")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(budget_s: float):
+    """Reference-shaped CPU port (oracle.DenseOracle) on the host cores: steady-state sticky
+    chunks of the headline shape, 2 LTM layers per chunk sharing one k."""
+    from infinite_video_amd import synth
+    from oracle.ltm_oracle import DenseOracle
+    layers = []
+    for l in range(L):
+        wk, bk, wv, bv = synth.layer_projections(l, D, DM)
+        pk, pv = torch.nn.Linear(D, DM), torch.nn.Linear(D, DM)
+        with torch.no_grad():
+            pk.weight.copy_(torch.from_numpy(wk)); pk.bias.copy_(torch.from_numpy(bk))
+            pv.weight.copy_(torch.from_numpy(wv)); pv.bias.copy_(torch.from_numpy(bv))
+        layers.append(DenseOracle(N, H, DH, TAU, True, pk, pv))
+    qs = [torch.from_numpy(synth.layer_query(l, Q, DM)).unsqueeze(0) for l in range(L)]
+    torch.manual_seed(synth.SEED_U)
+    done, elapsed, c = 0, 0.0, 0
+    with torch.no_grad():
+        while True:
+            k = torch.from_numpy(synth.frame_tokens(c, T, P, D)).unsqueeze(0)
+            t0 = time.perf_counter()
+            for l in range(L):
+                layers[l].forward(k, qs[l], new_doc=(c == 0))
+            dt = time.perf_counter() - t0
+            if c > 0:                      # chunk 0 is the new-document warm-up (no sticky step)
+                done += 1
+                elapsed += dt
+            c += 1
+            if (elapsed >= budget_s and done >= 2) or done >= 64:
+                break
+    return {"value": done / elapsed, "unit": "frame-chunks/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{done} steady-state sticky chunks (T=256,N=256,2 layers) after 1 warm-up chunk, "
+                      f"oracle.DenseOracle (reference-shaped ATen sequence), {elapsed:.1f}s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the LTM path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    from infinite_video_amd.video_memory import consolidate_video, shard_range
+
+    start, stop = shard_range(args.chunks, world, rank)
+    c_local = stop - start
+    eng = LTMEngine(N, H, DH, D, P, tau=TAU, sticky=True, n_layers=L, max_q=Q, device=dev,
+                    max_batch_chunks=args.batch_chunks)
+    projs = [tuple(torch.from_numpy(a).to(dev) for a in synth.layer_projections(l, D, DM)) for l in range(L)]
+    q = torch.from_numpy(np.stack([synth.layer_query(l, Q, DM) for l in range(L)])).to(dev)
+    u = torch.from_numpy(synth.gibbs_uniforms(args.chunks, L)[start:stop]).to(dev)
+    # synthetic frame tokens ~ N(0,1), distinct per chunk (51.5 GB at 2048 chunks: far beyond the
+    # 256 MiB Infinity Cache, so the pool really streams from HBM)
+    k = torch.empty(c_local, T * P, D, device=dev, dtype=torch.float32)
+    gen = torch.Generator(device=dev).manual_seed(synth.SEED_K + start)
+    for i in range(0, c_local, 64):
+        k[i:i + 64].normal_(generator=gen)
+    torch.cuda.synchronize()
+
+    def one_step():
+        return consolidate_video(eng, k, q, projs, u)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx, mem = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(ctx).all()), "non-finite consolidation output"
+
+    # ---- roofline leg: one more pass with HIP events around every kernel launch ----
+    eng.profile(True)
+    eng.consolidate(k, q, projs, u, new_doc=True)
+    prof = eng.profile_read()
+    eng.profile(False)
+    pool_n, pool_ms = prof["pool"]
+    pool_bytes = c_local * BYTES_POOL_PER_CHUNK
+    achieved = pool_bytes / (pool_ms * 1e-3) / 1e9 if pool_ms > 0 else 0.0
+    roofline = {
+        "kernel": "pool_frames_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "launches": pool_n, "avg_launch_ms": pool_ms / max(pool_n, 1),
+        "bytes_per_full_launch": min(args.batch_chunks, c_local) * BYTES_POOL_PER_CHUNK,
+        "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
+        "kernel_ms_per_pass": {name: round(ms, 3) for name, (n, ms) in prof.items()},
+    }
+
+    if rank == 0:
+        value = args.chunks * args.steps / elapsed
+        out = {
+            "metric": "frame-chunks/sec consolidated (max_int=256, num_basis=256, d=768)",
+            "value": value, "unit": "frame-chunks/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.chunks}-chunk synthetic video, max_int=256 frames x 32 tokens x 768, "
+                                   "num_basis=256, tau=0.75, sticky, 2 video-Q-former LTM layers, "
+                                   "Q=32 queries, LLM/Q-former stubbed (BASELINE configs[1]/[2])",
+                       "chunks": args.chunks, "chunks_per_gpu": c_local, "layer_steps_per_s": value * L,
+                       "parallelism": f"chunk-block sharding x{world} + 1 all-gather of consolidated memory"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

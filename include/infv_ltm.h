@@ -162,6 +162,21 @@ int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* 
  * instead of the ones derived from its own scores (one-shot). */
 int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs);
 
+/* Measurement (bench.py's roofline leg): while enabled, every kernel launch the handle issues
+ * is bracketed by HIP events on the launch stream.  profile_read synchronises, returns the
+ * number of launches and their summed device time for one kernel family, and clears it. */
+typedef enum {
+    INFV_KERNEL_POOL = 0,     /* frame mean-pool (the HBM-bound kernel)   */
+    INFV_KERNEL_ROWS = 1,     /* new coefficient rows                     */
+    INFV_KERNEL_PROJECT = 2,  /* fp32 MFMA projection GEMM                */
+    INFV_KERNEL_DRAW = 3,     /* Gibbs draw                               */
+    INFV_KERNEL_UPDATE = 4,   /* memory update                            */
+    INFV_KERNEL_ATTEND = 5,   /* scores / softmax / read-out              */
+    INFV_KERNEL_COUNT = 6
+} infv_kernel;
+int infv_ltm_profile_enable(infv_ltm_handle h, int32_t on);
+int infv_ltm_profile_read(infv_ltm_handle h, int32_t kernel, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,10 @@ _SIGNATURES = {
     "infv_ltm_reproject": (C.c_int, [C.c_void_p, C.POINTER(Proj), C.c_void_p]),
     "infv_ltm_get_draw": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, f32p, f32p, C.c_void_p]),
     "infv_ltm_set_probs": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
+    "infv_ltm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "infv_ltm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
+KERNELS = ("pool", "rows", "project", "draw", "update", "attend")
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None

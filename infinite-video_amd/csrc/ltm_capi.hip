@@ -85,6 +85,28 @@ struct Plan {
     }
 };
 
+struct Profiler {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[INFV_KERNEL_COUNT];
+    ~Profiler() { clear_all(); }
+    void clear(int k) {
+        for (auto& p : ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        ev[k].clear();
+    }
+    void clear_all() { for (int k = 0; k < INFV_KERNEL_COUNT; ++k) clear(k); }
+};
+
+// Brackets one launch with events when profiling is on.
+struct Timed {
+    Profiler& prof; int kernel; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+    Timed(Profiler& p, int k, hipStream_t s) : prof(p), kernel(k), stream(s) {
+        if (prof.on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, stream);
+    }
+    ~Timed() {
+        if (prof.on && a && b) { (void)hipEventRecord(b, stream); prof.ev[kernel].emplace_back(a, b); }
+    }
+};
+
 }  // namespace
 
 struct infv_ltm_s {
@@ -100,6 +122,7 @@ struct infv_ltm_s {
     DeviceBuf probs, probs_override, override_flag, bins, idx, scores;
     DeviceBuf kbar_ws, R_ws, P_ws;     // workspaces
     int n_bins = 128;
+    Profiler prof;
     ~infv_ltm_s() { for (auto& kv : plans) delete kv.second; }
 };
 
@@ -159,6 +182,7 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
         if (h->cfg.sticky) {
             if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
             if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+            Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
             HIP_TRY(launch_draw(h->bin_part.as<float>(), h->parts, h->probs_override.as<float>(),
                                 h->override_flag.as<int32_t>(), plan.sticky(), u, h->S, h->L,
                                 h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream));
@@ -170,14 +194,20 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
         }
     }
     const int nxt = h->cur ^ 1;
+    {
+    Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
     HIP_TRY(launch_update(op.view(), h->N, h->d, h->dm, h->L, h->S, idx, idx_stride, R, Pnew, splitk, split_stride,
                           h->B[h->cur].as<float>(), h->KV[h->cur].as<float>(), h->B[nxt].as<float>(),
                           h->KV[nxt].as<float>(), stream));
+    }
     h->cur = nxt;
     h->has_memory = true;
     const int parts = attend_parts(Q, h->H);
+    {
+    Timed t_(h->prof, INFV_KERNEL_ATTEND, stream);
     HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
                           plan.sticky(), ctx, h->bin_part.as<float>(), h->scores.as<float>(), stream));
+    }
     h->parts = parts;
     h->lastQ = Q;
     return INFV_OK;
@@ -204,8 +234,15 @@ int project_chunks(infv_ltm_handle h, const Plan& plan, bool inf, const float* k
     const int sk = project_splitk((int)M, h->d);
     HIP_TRY(h->R_ws.reserve((size_t)(M ? M : 1) * h->d * sizeof(float)));
     HIP_TRY(h->P_ws.reserve((size_t)(M ? M : 1) * n_cols * sk * sizeof(float)));
-    HIP_TRY(launch_project(kbar, n_chunks, T, h->d, h->dm, h->L, op.view(), pp, h->R_ws.as<float>(),
+    {
+    Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
+    HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws.as<float>(), stream));
+    }
+    {
+    Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
+    HIP_TRY(launch_project(n_chunks, h->d, h->dm, h->L, op.view(), pp, h->R_ws.as<float>(),
                            h->P_ws.as<float>(), stream));
+    }
     *splitk = sk;
     *split_stride = M * n_cols;
     return INFV_OK;
@@ -315,6 +352,7 @@ int infv_ltm_has_memory(infv_ltm_handle h) {
 int infv_ltm_pool(infv_ltm_handle h, const float* k, int64_t n_frames, float* kbar, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!k || !kbar || n_frames < 0) return fail(INFV_ERR_INVALID, "pool: bad arguments");
+    Timed t_(h->prof, INFV_KERNEL_POOL, static_cast<hipStream_t>(stream));
     HIP_TRY(launch_pool(k, kbar, n_frames, h->P, h->d, static_cast<hipStream_t>(stream)));
     return INFV_OK;
 }
@@ -365,7 +403,10 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     while (c < n_chunks) {
         const int nb = (n_chunks - c < h->maxC) ? n_chunks - c : h->maxC;
         HIP_TRY(h->kbar_ws.reserve((size_t)nb * T * h->d * sizeof(float)));
+        {
+        Timed t_(h->prof, INFV_KERNEL_POOL, stream);
         HIP_TRY(launch_pool(k + c * chunk_k, h->kbar_ws.as<float>(), (int64_t)nb * T, h->P, h->d, stream));
+        }
         int sk = 1; long ss = 0;
         if (int rc = project_chunks(h, *plan, true, h->kbar_ws.as<float>(), nb, T, pp, &sk, &ss, stream)) return rc;
         const size_t rows = plan->inf.rows;
@@ -451,6 +492,29 @@ int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs) {
                       (h->n_bins - 1) * sizeof(float), hipMemcpyHostToDevice));
     const int32_t one = 1;
     HIP_TRY(hipMemcpy(h->override_flag.as<int32_t>() + layer, &one, sizeof(one), hipMemcpyHostToDevice));
+    return INFV_OK;
+}
+
+int infv_ltm_profile_enable(infv_ltm_handle h, int32_t on) {
+    if (int rc = check_handle(h)) return rc;
+    h->prof.on = on != 0;
+    if (!on) h->prof.clear_all();
+    return INFV_OK;
+}
+
+int infv_ltm_profile_read(infv_ltm_handle h, int32_t kernel, int64_t* launches, double* total_ms) {
+    if (int rc = check_handle(h)) return rc;
+    if (kernel < 0 || kernel >= INFV_KERNEL_COUNT || !launches || !total_ms) return fail(INFV_ERR_INVALID, "profile_read: bad arguments");
+    double ms = 0.0;
+    for (auto& p : h->prof.ev[kernel]) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+        ms += t;
+    }
+    *launches = (int64_t)h->prof.ev[kernel].size();
+    *total_ms = ms;
+    h->prof.clear(kernel);
     return INFV_OK;
 }
 

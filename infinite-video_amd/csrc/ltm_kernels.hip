@@ -223,13 +223,16 @@ int project_splitk(int M, int K) {
     return sk;
 }
 
-hipError_t launch_project(const float* kbar, int n_chunks, int T, int d, int dm, int n_layers,
-                          const OperatorView& op, const ProjPtrs& proj, float* R, float* Pnew,
-                          hipStream_t stream) {
+hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
+                       hipStream_t stream) {
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(build_rows_kernel, dim3(op.rows, n_chunks), dim3(256), 0, stream, kbar, T, d / 4, op, R);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
+                          const float* R, float* Pnew, hipStream_t stream) {
+    if (op.rows == 0 || n_chunks == 0) return hipSuccess;
     const int M = n_chunks * op.rows;
     const int n_cols = n_layers * 2 * dm;
     const int sk = project_splitk(M, d);

@@ -251,3 +251,17 @@ class LTMEngine:
             raise ValueError(f"probs must have {NB_BINS - 1} entries")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_set_probs(self._h, layer, p.ctypes.data_as(_lib.f32p)))
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on: bool):
+        """Bracket every kernel launch of this engine with HIP events (bench.py's roofline leg)."""
+        _lib.check(self.lib.infv_ltm_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """{kernel: (launches, total device ms)} since profiling was enabled; synchronises."""
+        out = {}
+        for i, name in enumerate(_lib.KERNELS):
+            n, ms = C.c_int64(), C.c_double()
+            _lib.check(self.lib.infv_ltm_profile_read(self._h, i, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out

@@ -1,0 +1,93 @@
+"""Per-chunk inference loop and its multi-GPU sharding.
+
+Single GPU: the loop of the reference eval drivers
+(eval_code/eval/run_inference_inf_video_llama_nextqa.py:179-196 -- ``new_video`` true on the
+first chunk only, one consolidation per chunk, mean of the per-chunk outputs at :194) with the
+Q-former/LLM stubbed, i.e. the LTM operator called directly on each chunk's frame tokens.
+
+Multi GPU: one process per GPU; a video of C chunks is cut into
+contiguous blocks, rank r consolidates its block as its own document (``new_doc`` on its first
+chunk, an independent sticky chain per layer), and ONE all-gather (RCCL over xGMI when the
+process group is "nccl") exchanges each rank's consolidated memory -- B_past per layer, the
+sticky bin masses, and the local SUM of per-chunk outputs with its chunk count -- before the
+LLM forward.  The reference's final reduction is a plain mean over chunks and ``llama_proj`` is
+linear (infinityqa.py:342), so summing before the gather is exact up to fp32 rounding.
+There is no other collective on the data path.
+
+The Gibbs uniforms are keyed by GLOBAL chunk index, so rank r's result equals a single-GPU
+run on the sub-video made of rank r's chunks.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_chunks: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block of chunk indices owned by ``rank`` (first ``n_chunks % world`` ranks get one more)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank outside world")
+    base, rem = divmod(n_chunks, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+@dataclass
+class ConsolidatedMemory:
+    """What the ranks exchange: index 0 of every tensor is the owning rank."""
+    B: torch.Tensor          # [R, L, N, d]   coefficient matrices (B_past)
+    bin_mass: torch.Tensor   # [R, L, 127]    unnormalised sticky bin masses
+    ctx_sum: torch.Tensor    # [R, L, Q, dm]  sum over the rank's chunks of the per-chunk outputs
+    count: torch.Tensor      # [R]            chunks consolidated by the rank
+
+    def mean_embedding(self) -> torch.Tensor:
+        """Mean over ALL chunks of the video of the per-chunk outputs, [L, Q, dm]
+        (the reference's torch.mean(torch.stack(video_embs)) at nextqa.py:194)."""
+        return self.ctx_sum.sum(0) / self.count.sum()
+
+
+def pack_local_memory(engine, ctx_local: torch.Tensor) -> torch.Tensor:
+    """Flatten this rank's consolidated memory into one fp32 payload (one collective, not four)."""
+    L = engine.L
+    parts = []
+    masses = []
+    for l in range(L):
+        B, mass = engine.export_state(l)
+        parts.append(B.reshape(-1))
+        masses.append(mass.reshape(-1))
+    count = torch.full((1,), float(ctx_local.shape[0]), device=ctx_local.device, dtype=torch.float32)
+    return torch.cat(parts + masses + [ctx_local.sum(0).reshape(-1), count])
+
+
+def unpack_memory(payload: torch.Tensor, world: int, L: int, N: int, d: int, Q: int, dm: int) -> ConsolidatedMemory:
+    payload = payload.reshape(world, -1)
+    nB, nM, nC = L * N * d, L * 127, L * Q * dm
+    if payload.shape[1] != nB + nM + nC + 1:
+        raise ValueError("payload size does not match the memory layout")
+    return ConsolidatedMemory(
+        B=payload[:, :nB].reshape(world, L, N, d),
+        bin_mass=payload[:, nB:nB + nM].reshape(world, L, 127),
+        ctx_sum=payload[:, nB + nM:nB + nM + nC].reshape(world, L, Q, dm),
+        count=payload[:, -1])
+
+
+def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Sequence,
+                      u_local: Optional[torch.Tensor], group=None) -> Tuple[torch.Tensor, ConsolidatedMemory]:
+    """Consolidate this rank's block of chunks and all-gather the consolidated memory.
+
+    k_local [C_local, T*P, d]; q [L, Q, dm]; u_local [C_local, L, S] (rows keyed by global chunk id).
+    Returns (per-chunk outputs of this rank [C_local, L, Q, dm], gathered ConsolidatedMemory).
+    Works without an initialised process group (world = 1, no collective)."""
+    ctx = engine.consolidate(k_local, q, projs, u_local, new_doc=True)
+    payload = pack_local_memory(engine, ctx)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=payload.dtype)
+        dist.all_gather_into_tensor(gathered, payload, group=group)
+    else:
+        gathered = payload
+    mem = unpack_memory(gathered, world, engine.L, engine.N, engine.d, q.shape[1], engine.dm)
+    return ctx, mem
