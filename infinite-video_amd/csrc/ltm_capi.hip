@@ -118,9 +118,14 @@ struct infv_ltm_s {
     bool has_memory = false;
     int lastQ = 0;                     // query length of the last attend
     int parts = 0;                     // row count of bin_part per layer, set by the last attend
-    DeviceBuf bin_part;                // [L][max_parts][n_bins]
-    DeviceBuf probs, probs_override, override_flag, bins, idx, scores;
+    DeviceBuf bin_part[2];             // [L][max_parts][n_bins]  sticky partials (ping-pong in the fast path)
+    int pc = 0;                        // which bin_part holds the latest partials
+    DeviceBuf probs, probs_override, bins, idx, scores;
+    unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     DeviceBuf kbar_ws, R_ws, P_ws;     // workspaces
+    // fast path (consolidate): bias-free scores, softmax weights and their row sums, ping-pong
+    DeviceBuf Sp[2], alpha[2], asum[2], cqbuf, Snew_ws;
+    int sc = 0;
     int n_bins = 128;
     Profiler prof;
     ~infv_ltm_s() { for (auto& kv : plans) delete kv.second; }
@@ -183,9 +188,10 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
             if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
             if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
             Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
-            HIP_TRY(launch_draw(h->bin_part.as<float>(), h->parts, h->probs_override.as<float>(),
-                                h->override_flag.as<int32_t>(), plan.sticky(), u, h->S, h->L,
+            HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(),
+                                h->override_mask, plan.sticky(), u, h->S, h->L,
                                 h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream));
+            h->override_mask = 0;
             idx = h->idx.as<int32_t>();
             idx_stride = h->S;
         } else {
@@ -206,7 +212,7 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
     {
     Timed t_(h->prof, INFV_KERNEL_ATTEND, stream);
     HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
-                          plan.sticky(), ctx, h->bin_part.as<float>(), h->scores.as<float>(), stream));
+                          plan.sticky(), ctx, h->bin_part[h->pc].as<float>(), h->scores.as<float>(), stream));
     }
     h->parts = parts;
     h->lastQ = Q;
@@ -277,15 +283,20 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->B[i].reserve(nb * h->d * sizeof(float));
         if (e == hipSuccess) e = h->KV[i].reserve(nb * 2 * h->dm * sizeof(float));
     }
-    if (e == hipSuccess) e = h->bin_part.reserve((size_t)h->L * max_parts * h->n_bins * sizeof(float));
+    const size_t nsq = (size_t)h->L * h->H * h->maxQ * h->N;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = h->bin_part[i].reserve((size_t)h->L * max_parts * h->n_bins * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(h->bin_part[i].p, 0, h->bin_part[i].bytes);
+        if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
+        if (e == hipSuccess) e = h->alpha[i].reserve(nsq * sizeof(float));
+        if (e == hipSuccess) e = h->asum[i].reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
+    }
+    if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
     if (e == hipSuccess) e = h->probs_override.reserve((size_t)h->L * h->n_bins * sizeof(float));
-    if (e == hipSuccess) e = h->override_flag.reserve((size_t)h->L * sizeof(int32_t));
     if (e == hipSuccess) e = h->bins.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (e == hipSuccess) e = h->idx.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (e == hipSuccess) e = h->scores.reserve((size_t)h->L * h->H * h->maxQ * h->N * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(h->override_flag.p, 0, (size_t)h->L * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemset(h->bin_part.p, 0, h->bin_part.bytes);
     if (e != hipSuccess) {
         delete h;
         return fail(INFV_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e));
@@ -381,6 +392,72 @@ int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* 
     return infv_ltm_step(h, h->kbar_ws.as<float>(), T, q, Q, proj, u, ctx, stream);
 }
 
+// One launch of the fused chain kernel: roles S and U for a chunk (if `plan_op` != nullptr) and
+// role C for the chunk whose read-out is pending.
+static int chain_launch(infv_ltm_handle h, const Plan& plan, const Operator* op, bool inf, const float* R,
+                        const float* Pnew, int splitk, long split_stride, const float* Snew, int Q,
+                        const ProjPtrs& pp, const double* u, float* ctx_pending, hipStream_t stream) {
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    const int QT = (Q + kQTile - 1) / kQTile;
+    a.N = h->N; a.H = h->H; a.Q = Q; a.QT = QT; a.L = h->L; a.S = h->S; a.d4 = h->d / 4; a.dm4 = h->dm / 4;
+    a.st = plan.sticky();
+    a.w = plan.w.as<float>(); a.w_out = plan.w_out;
+    for (int l = 0; l < h->L; ++l) a.bv[l] = pp.bv[l];
+    a.B_prev = h->B[h->cur].as<float>(); a.KV_prev = h->KV[h->cur].as<float>();
+    a.alpha_cur = h->alpha[h->sc].as<float>(); a.asum_cur = h->asum[h->sc].as<float>();
+    a.ctx_out = ctx_pending;
+    a.nC = ctx_pending ? h->H * QT * h->L : 0;
+    if (op != nullptr) {
+        a.op = op->view();
+        a.rows = op->rows; a.rows_max = op->rows;
+        a.draw_mode = inf ? (h->cfg.sticky ? 1 : 2) : 0;
+        if (a.draw_mode == 1) {
+            if (!u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
+            if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
+        }
+        a.part_prev = h->bin_part[h->pc].as<float>(); a.part_next = h->bin_part[h->pc ^ 1].as<float>();
+        a.parts = h->parts;
+        a.probs_override = h->probs_override.as<float>(); a.override_mask = h->override_mask;
+        a.u = u; a.uniform_idx = plan.uniform_idx.as<int32_t>();
+        a.probs_out = h->probs.as<float>(); a.bins_out = h->bins.as<int32_t>(); a.idx_out = h->idx.as<int32_t>();
+        a.Sp_prev = h->Sp[h->sc].as<float>(); a.Sp_next = h->Sp[h->sc ^ 1].as<float>();
+        a.Snew = Snew; a.cq = h->cqbuf.as<float>();
+        a.alpha_next = h->alpha[h->sc ^ 1].as<float>(); a.asum_next = h->asum[h->sc ^ 1].as<float>();
+        a.scores_out = h->scores.as<float>();
+        a.R = R; a.Pnew = Pnew; a.splitk = splitk; a.split_stride4 = split_stride / 4;
+        a.B_next = h->B[h->cur ^ 1].as<float>(); a.KV_next = h->KV[h->cur ^ 1].as<float>();
+        a.nS = h->H * QT * h->L;
+        a.nU = chain_u_blocks(h->N, h->L);
+    } else {
+        a.rows = a.rows_max = 0;
+    }
+    {
+        Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
+        HIP_TRY(launch_chain(a, stream));
+    }
+    if (op != nullptr) {
+        if (a.draw_mode == 1) h->override_mask = 0;
+        h->cur ^= 1; h->pc ^= 1; h->sc ^= 1;
+        h->has_memory = true;
+        h->parts = attend_parts(Q, h->H);
+        h->lastQ = Q;
+    }
+    return INFV_OK;
+}
+
+// batched new-row scores of `n_chunks` projected chunks (P_ws) into Snew_ws
+static int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const float* q, int Q,
+                        const ProjPtrs& pp, int sk, long ss, bool want_cq, hipStream_t stream) {
+    const long n_cols = (long)h->L * 2 * h->dm;
+    HIP_TRY(h->Snew_ws.reserve((size_t)n_chunks * h->L * h->H * Q * (op.rows ? op.rows : 1) * sizeof(float)));
+    Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
+    HIP_TRY(launch_new_scores(q, Q, h->H, h->L, n_chunks, op.rows, h->P_ws.as<float>(), (long)op.rows * n_cols, n_cols,
+                              2L * h->dm, sk, ss, pp, h->Snew_ws.as<float>(), want_cq ? h->cqbuf.as<float>() : nullptr,
+                              stream));
+    return INFV_OK;
+}
+
 int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T, const float* q,
                          int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
                          void* stream_) {
@@ -395,30 +472,62 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     const size_t chunk_ctx = (size_t)h->L * Q * h->dm;
     const size_t chunk_u = (size_t)h->L * h->S;
     if (new_doc) infv_ltm_reset(h);
+    if (n_chunks == 0) return INFV_OK;
+    const int rows_max = plan->first.rows > plan->inf.rows ? plan->first.rows : plan->inf.rows;
+    if (h->S > 1024 || chain_lds_bytes(h->N, h->S, rows_max) > 160 * 1024) {
+        // shapes the fused chain kernel cannot hold in LDS: per-chunk stage kernels
+        for (int c = 0; c < n_chunks; ++c)
+            if (int rc = infv_ltm_forward(h, k + c * chunk_k, T, q, Q, proj, u ? u + c * chunk_u : nullptr, 0,
+                                          ctx + c * chunk_ctx, stream_)) return rc;
+        return INFV_OK;
+    }
     int c = 0;
-    if (!h->has_memory && n_chunks > 0) {                     // first chunk of a document: other operator
-        if (int rc = infv_ltm_forward(h, k, T, q, Q, proj, u, 0, ctx, stream_)) return rc;
+    float* pending = nullptr;                                 // ctx slot of the chunk whose read-out is deferred
+    bool have_cq = false;
+    if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator
+        HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
+        if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
+        int sk = 1; long ss = 0;
+        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, &sk, &ss, stream)) return rc;
+        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, sk, ss, true, stream)) return rc;
+        have_cq = true;
+        if (int rc = chain_launch(h, *plan, &plan->first, false, h->R_ws.as<float>(), h->P_ws.as<float>(), sk, ss,
+                                  h->Snew_ws.as<float>(), Q, pp, nullptr, nullptr, stream)) return rc;
+        pending = ctx;
         c = 1;
+    } else {
+        // continue an existing memory: bias-free scores of the current K' rows under this query
+        Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
+        HIP_TRY(launch_new_scores(q, Q, h->H, h->L, 1, h->N, h->KV[h->cur].as<float>(), 0, 2L * h->dm,
+                                  (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
+                                  stream));
+        have_cq = true;
     }
     while (c < n_chunks) {
         const int nb = (n_chunks - c < h->maxC) ? n_chunks - c : h->maxC;
         HIP_TRY(h->kbar_ws.reserve((size_t)nb * T * h->d * sizeof(float)));
         {
-        Timed t_(h->prof, INFV_KERNEL_POOL, stream);
-        HIP_TRY(launch_pool(k + c * chunk_k, h->kbar_ws.as<float>(), (int64_t)nb * T, h->P, h->d, stream));
+            Timed t_(h->prof, INFV_KERNEL_POOL, stream);
+            HIP_TRY(launch_pool(k + c * chunk_k, h->kbar_ws.as<float>(), (int64_t)nb * T, h->P, h->d, stream));
         }
         int sk = 1; long ss = 0;
         if (int rc = project_chunks(h, *plan, true, h->kbar_ws.as<float>(), nb, T, pp, &sk, &ss, stream)) return rc;
+        if (int rc = batch_scores(h, plan->inf, nb, q, Q, pp, sk, ss, !have_cq, stream)) return rc;
+        have_cq = true;
         const size_t rows = plan->inf.rows;
         for (int i = 0; i < nb; ++i) {
             const float* R = h->R_ws.as<float>() + (size_t)i * rows * h->d;
             const float* Pn = h->P_ws.as<float>() + (size_t)i * rows * h->L * 2 * h->dm;
+            const float* Sn = h->Snew_ws.as<float>() + (size_t)i * h->L * h->H * Q * rows;
             const double* uc = u ? u + (size_t)(c + i) * chunk_u : nullptr;
-            if (int rc = chain_step(h, *plan, R, Pn, sk, ss, q, Q, pp, uc, ctx + (size_t)(c + i) * chunk_ctx, stream)) return rc;
+            if (int rc = chain_launch(h, *plan, &plan->inf, true, R, Pn, sk, ss, Sn, Q, pp, uc, pending, stream)) return rc;
+            pending = ctx + (size_t)(c + i) * chunk_ctx;
         }
         c += nb;
     }
-    return INFV_OK;
+    // flush the last read-out, then bring the K' half of the projected memory up to date
+    if (int rc = chain_launch(h, *plan, nullptr, false, nullptr, nullptr, 1, 0, nullptr, Q, pp, nullptr, pending, stream)) return rc;
+    return infv_ltm_reproject(h, proj, stream_);
 }
 
 int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin_mass, void* stream_) {
@@ -429,7 +538,7 @@ int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin
     if (B) HIP_TRY(hipMemcpyAsync(B, h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d,
                                   (size_t)h->N * h->d * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (bin_mass) {
-        HIP_TRY(launch_sum_parts(h->bin_part.as<float>() + (size_t)layer * h->parts * h->n_bins, h->parts, h->n_bins,
+        HIP_TRY(launch_sum_parts(h->bin_part[h->pc].as<float>() + (size_t)layer * h->parts * h->n_bins, h->parts, h->n_bins,
                                  bin_mass, stream));
     }
     return INFV_OK;
@@ -454,7 +563,7 @@ int infv_ltm_import_state(infv_ltm_handle h, int32_t layer, const float* B, cons
     HIP_TRY(hipMemcpyAsync(h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d, B,
                            (size_t)h->N * h->d * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (h->parts <= 0) h->parts = 1;
-    float* part = h->bin_part.as<float>() + (size_t)layer * h->parts * h->n_bins;
+    float* part = h->bin_part[h->pc].as<float>() + (size_t)layer * h->parts * h->n_bins;
     HIP_TRY(hipMemsetAsync(part, 0, (size_t)h->parts * h->n_bins * sizeof(float), stream));
     if (bin_mass)
         HIP_TRY(hipMemcpyAsync(part, bin_mass, (size_t)(h->n_bins - 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -490,8 +599,7 @@ int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs) {
     if (layer < 0 || layer >= h->L || !probs) return fail(INFV_ERR_INVALID, "set_probs: bad arguments");
     HIP_TRY(hipMemcpy(h->probs_override.as<float>() + (size_t)layer * h->n_bins, probs,
                       (h->n_bins - 1) * sizeof(float), hipMemcpyHostToDevice));
-    const int32_t one = 1;
-    HIP_TRY(hipMemcpy(h->override_flag.as<int32_t>() + layer, &one, sizeof(one), hipMemcpyHostToDevice));
+    h->override_mask |= 1u << layer;
     return INFV_OK;
 }
 

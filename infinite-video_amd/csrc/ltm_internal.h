@@ -50,7 +50,7 @@ hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const Opera
 hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
                             hipStream_t stream);
 
-hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, int32_t* override_flag,
+hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
                        int32_t* bins, int32_t* idx, hipStream_t stream);
 
@@ -65,6 +65,33 @@ int attend_parts(int Q, int H);
 hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, const float* KV, const ProjPtrs& proj,
                          const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
                          float* bin_part, float* scores, hipStream_t stream);
+
+// ---- whole-video fast path (ltm_chain.hip) ----------------------------------------------------
+struct ChainArgs {
+    int N, H, Q, QT, L, S, d4, dm4, rows, rows_max;
+    OperatorView op;
+    StickyView st;
+    int draw_mode;                  // 0: none (first chunk of a document), 1: sticky Gibbs draw, 2: uniform resample
+    const float* part_prev; float* part_next; int parts;
+    const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
+    float* probs_out; int32_t* bins_out; int32_t* idx_out;
+    // role S: score recurrence + softmax weights + next sticky partials
+    const float* Sp_prev; float* Sp_next; const float* Snew; const float* cq; const float* w; float w_out;
+    float* alpha_next; float* asum_next; float* scores_out;
+    // role U: B and V' rows
+    const float* R; const float* Pnew; int splitk; long split_stride4;
+    const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
+    // role C: read-out of the previous chunk
+    const float* alpha_cur; const float* asum_cur; const float* bv[kMaxLayers]; float* ctx_out;
+    int nS, nU, nC;                 // workgroups per role
+};
+size_t chain_lds_bytes(int N, int S, int rows_max);
+int chain_u_blocks(int N, int n_layers);
+hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
+// S'new[c][l][h][q][r] = (q_h[q]/sqrt(dh)) . Kmat(c,r,l)_h ; optionally cq[l][h][q] = q_h[q].bk_h/sqrt(dh)
+hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_chunks, int rows, const float* Kmat,
+                             long chunk_stride, long row_stride, long layer_stride, int splitk, long split_stride,
+                             const ProjPtrs& proj, float* Snew, float* cq, hipStream_t stream);
 
 // bin_mass[j] = sum over parts of bin_part[layer][p][j]
 hipError_t launch_sum_parts(const float* bin_part_layer, int parts, int pitch, float* bin_mass, hipStream_t stream);

@@ -14,12 +14,9 @@
 //               and the next step's sticky bin masses                          LTM.py:224-230,247-248,269-284,200-202
 //
 // Wavefront = 64 lanes everywhere; MFMA shapes are the f32-input ones (exact fp32 fma chains).
-#include "ltm_internal.h"
+#include "ltm_device.h"
 
 namespace infv {
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // ======================================================================================
 // 1. frame mean-pool:  k [n_frames][P][d] -> kbar [n_frames][d]            (LTM.py:304)
@@ -240,73 +237,30 @@ hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const Opera
 }
 
 // ======================================================================================
-// 4. Gibbs / sticky draw, one workgroup per layer                         (LTM.py:202-208)
-//    p_raw[j] = sum over (head, q-tile) partials; normalised twice (LTM.py:203 and
-//    torch.distributions.Categorical); then torch.multinomial's CPU algorithm: fp32
-//    sequential running sum, / total, last bucket forced to 1, lower-bound search of each
-//    float64 uniform.  The cdf arithmetic is bit-exact IEEE fp32, so the draw is bit-exact
-//    given identical probs.
+// 4. Gibbs / sticky draw, one workgroup per layer (draw_core in ltm_device.h; LTM.py:202-208)
 // ======================================================================================
-__device__ inline double block_sum_256(double v, double* scratch) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
-
 __global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin_part, int parts,
                                                    const float* __restrict__ probs_override,
-                                                   int32_t* __restrict__ override_flag, StickyView sticky,
+                                                   unsigned override_mask, StickyView sticky,
                                                    const double* __restrict__ u, int S,
                                                    float* __restrict__ probs_out, int32_t* __restrict__ bins_out,
                                                    int32_t* __restrict__ idx_out) {
     __shared__ double scratch[4];
-    __shared__ float cdf[256];
-    const int l = blockIdx.x, j = threadIdx.x;
-    const int nb = sticky.n_bins - 1;                 // 127 usable bins (LTM.py:202)
-    const int nbp = sticky.n_bins;                    // row pitch of the partial / probs arrays
-    float prob = 0.f;
-    if (override_flag[l]) {
-        if (j < nb) prob = probs_override[l * nbp + j];
-    } else {
-        double acc = 0.0;
-        if (j < nb)
-            for (int p = 0; p < parts; ++p) acc += (double)bin_part[((long)l * parts + p) * nbp + j];
-        const float raw = (float)acc;
-        const float tot1 = (float)block_sum_256((double)raw, scratch);
-        const float p1 = raw / tot1;
-        const float tot2 = (float)block_sum_256((j < nb) ? (double)p1 : 0.0, scratch);
-        prob = p1 / tot2;
-    }
-    if (j < nb) { probs_out[l * nbp + j] = prob; cdf[j] = prob; }
-    __syncthreads();
-    if (j == 0) {
-        override_flag[l] = 0;
-        float run = 0.f;
-        for (int i = 0; i < nb; ++i) { run = run + cdf[i]; cdf[i] = run; }
-        for (int i = 0; i < nb; ++i) cdf[i] = cdf[i] / run;
-        cdf[nb - 1] = 1.f;
-    }
-    __syncthreads();
-    for (int s = j; s < S; s += blockDim.x) {
-        const double us = u[(long)l * S + s];
-        int lo = 0, hi = nb;
-        while (hi - lo > 0) {
-            const int mid = lo + (hi - lo) / 2;
-            if ((double)cdf[mid] < us) lo = mid + 1; else hi = mid;
-        }
-        bins_out[(long)l * S + s] = lo;
-        idx_out[(long)l * S + s] = sticky.bin_box[lo];
-    }
+    __shared__ __attribute__((aligned(16))) float cdf[kBins];
+    __shared__ float total;
+    __shared__ int32_t sidx[1024];
+    const int l = blockIdx.x;
+    draw_core(bin_part + (long)l * parts * kBins, parts, probs_override + l * kBins, (override_mask >> l) & 1u,
+              sticky, u + (long)l * S, S, cdf, sidx, scratch, &total, probs_out + l * kBins,
+              bins_out + (long)l * S, idx_out + (long)l * S);
 }
 
-hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, int32_t* override_flag,
+hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
                        int32_t* bins, int32_t* idx, hipStream_t stream) {
+    if (S > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(draw_kernel, dim3(n_layers), dim3(256), 0, stream, bin_part, parts, probs_override,
-                       override_flag, sticky, u, S, probs, bins, idx);
+                       override_mask, sticky, u, S, probs, bins, idx);
     return hipGetLastError();
 }
 
@@ -385,13 +339,9 @@ hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, 
 // ======================================================================================
 // 6. attend: one workgroup per (head h, 16-row query tile, layer).
 //      S[q][n]  = (q_h[q] . (K'_h[n] + bk_h)) / sqrt(dh)            MFMA 16x16x4 f32, K' from L2
-//      alpha    = w_n e^{S} / (sum_m w_m e^{S_m} + w_out)           wave shuffles, rows in LDS
-//      ctx[q]   = sum_n alpha[q][n] (V'_h[n] + bv_h)                MFMA 16x16x4 f32, V' staged in LDS
-//      bin_part[j] = sum_{rows} trapezoid mass of histogram interval j+1 of the row's density
+//      alpha, next sticky bin masses                                 row_phase   (ltm_device.h)
+//      ctx[q]   = sum_n alpha[q][n] (V'_h[n] + bv_h)                readout_tile (ltm_device.h)
 // ======================================================================================
-constexpr int kVRows = 128;              // V' rows staged per pass
-constexpr int kVStride = 80;             // row pitch (floats): == 16 mod 32 -> conflict-free b32 column reads
-
 __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q, int Q, int N, int H,
                                                      const float* __restrict__ KV, ProjPtrs proj,
                                                      const float* __restrict__ readout_w, float w_out,
@@ -402,8 +352,8 @@ __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q
     float* Ssm = lds;                                   // [16][N+2]   scores, then alpha
     float* Vsm = lds + ((kQTile * sstride + 3) & ~3);   // [128][80]   V' rows of the current pass (16-B aligned)
     float* Dsm = Vsm + kVRows * kVStride;               // [16][132]   edge densities
-    float* Msm = Dsm + kQTile * 132;                    // [16][128]   per-row bin masses
-    float* cq = Msm + kQTile * 128;                     // [16] q . bk
+    float* Msm = Dsm + kQTile * kDPitch;                // [16][128]   per-row bin masses
+    float* cq = Msm + kQTile * kMPitch;                 // [16] q . bk
     float* asum = cq + 16;                              // [16] sum_n alpha
 
     const int h = blockIdx.x, qt = blockIdx.y, l = blockIdx.z;
@@ -459,79 +409,18 @@ __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * g + r;
-            const float s = acc[r] + cq[row];
-            Ssm[row * sstride + nt * 16 + c] = s;
+            const float sv = acc[r] + cq[row];
+            Ssm[row * sstride + nt * 16 + c] = sv;
             if (scores != nullptr && qt * kQTile + row < Q)
-                scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = s;
+                scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = sv;
         }
     }
     __syncthreads();
 
-    // ---- row-wise phase: 16 threads per query row ----
-    const int row = tid >> 4, sub = tid & 15;
-    const bool row_valid = (qt * kQTile + row) < Q;
-    float m = -INFINITY;
-    for (int n = sub; n < N; n += 16) m = fmaxf(m, Ssm[row * sstride + n]);
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    // densities at the histogram edges (stabilised by max(m,0): outside edges score 0)
-    const float md = fmaxf(m, 0.f);
-    const int ne = sticky.n_bins + 1;
-    for (int j = sub; j < ne; j += 16) {
-        const int eb = sticky.edge_box[j];
-        const float sc = (eb >= 0) ? Ssm[row * sstride + eb] : 0.f;
-        Dsm[row * 132 + j] = expf(sc - md);
-    }
-    __syncthreads();                                   // all raw-score reads done before alpha overwrites
-    float esum = 0.f;
-    for (int n = sub; n < N; n += 16) {
-        const float e = readout_w[n] * expf(Ssm[row * sstride + n] - m);
-        Ssm[row * sstride + n] = e;
-        esum += e;
-    }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) esum += __shfl_xor(esum, off);
-    const float inv = 1.0f / (esum + w_out * expf(-m));
-    for (int n = sub; n < N; n += 16) Ssm[row * sstride + n] *= inv;
-    if (sub == 0) asum[row] = esum * inv;
-    // trapezoid normaliser of the edge density
-    float z = 0.f;
-    for (int j = sub; j < sticky.n_bins; j += 16)
-        z += (Dsm[row * 132 + j] + Dsm[row * 132 + j + 1]) * sticky.edge_dx[j];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) z += __shfl_xor(z, off);
-    z *= 0.5f;
-    // mass of interval j+1 -> bin j  (cum[j+1]-cum[j], LTM.py:201-202), j = 0..n_bins-2
-    for (int j = sub; j < sticky.n_bins - 1; j += 16) {
-        const float dl = Dsm[row * 132 + j + 1] / z, dr = Dsm[row * 132 + j + 2] / z;
-        Msm[row * 128 + j] = row_valid ? ((dl + dr) * sticky.edge_dx[j + 1]) * 0.5f : 0.f;
-    }
-    __syncthreads();
-    if (tid < sticky.n_bins - 1) {
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < kQTile; ++r) t += Msm[r * 128 + tid];
-        bin_part[(((long)l * H + h) * QT + qt) * sticky.n_bins + tid] = t;
-    }
+    row_phase(Ssm, sstride, N, min(kQTile, Q - qt * kQTile), readout_w, w_out, sticky, Dsm, Msm, asum,
+              bin_part + (((long)l * H + h) * QT + qt) * kBins);
 
-    // ---- read-out: wave w owns output columns [16w, 16w+16) of the head ----
-    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < N; base += kVRows) {
-        const int rows = min(kVRows, N - base);
-        __syncthreads();                               // previous pass's MFMA reads are done
-        for (int i = tid; i < rows * 16; i += 256) {
-            const int r = i >> 4, c4 = i & 15;
-            const floatx4 v = *reinterpret_cast<const floatx4*>(
-                KVl + (long)(base + r) * 2 * dm + dm + h * kHeadSize + c4 * 4);
-            *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = v;
-        }
-        __syncthreads();
-        for (int t = 0; t < rows / 4; ++t) {
-            const float a = Ssm[c * sstride + base + 4 * t + g];          // alpha[row c][n]
-            const float b = Vsm[(4 * t + g) * kVStride + 16 * wave + c];  // V'[n][col]
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-        }
-    }
+    const floatx4 acc = readout_tile(Ssm, sstride, N, KVl + dm + h * kHeadSize, 2L * dm, Vsm);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r;
@@ -547,7 +436,7 @@ int attend_parts(int Q, int H) { return H * ((Q + kQTile - 1) / kQTile); }
 
 size_t attend_lds_bytes(int N) {
     const int sstride = N + 2;
-    size_t floats = ((kQTile * sstride + 3) & ~3) + kVRows * kVStride + kQTile * 132 + kQTile * 128 + 64;
+    size_t floats = ((kQTile * sstride + 3) & ~3) + kVRows * kVStride + kQTile * kDPitch + kQTile * kMPitch + 64;
     return floats * sizeof(float);
 }
 
