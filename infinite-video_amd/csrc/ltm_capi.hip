@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -53,8 +54,9 @@ hipError_t upload(DeviceBuf& buf, const T* host, size_t n) {
 
 struct Operator {
     int rows = 0;
-    DeviceBuf row_box, row_begin, row_end, box_val, box_row, old_ptr, old_slot;
+    DeviceBuf row_box, row_begin, row_end, box_val, box_row, old_ptr, old_slot, slot_tab;
     bool has_old = false;
+    int tabw = 4;                      // max slots per box, rounded up to a multiple of 4
     OperatorView view() const {
         OperatorView v;
         v.rows = rows;
@@ -65,6 +67,8 @@ struct Operator {
         v.box_row = box_row.as<int32_t>();
         v.old_ptr = has_old ? old_ptr.as<int32_t>() : nullptr;
         v.old_slot = has_old ? old_slot.as<int32_t>() : nullptr;
+        v.slot_tab = has_old ? slot_tab.as<int32_t>() : nullptr;
+        v.tabw = tabw;
         return v;
     }
 };
@@ -117,14 +121,17 @@ struct infv_ltm_s {
     int cur = 0;
     bool has_memory = false;
     int lastQ = 0;                     // query length of the last attend
+    bool last_fast = false;            // last step ran in the fused chain kernel (scores = Sp + cq)
     int parts = 0;                     // row count of bin_part per layer, set by the last attend
     DeviceBuf bin_part[2];             // [L][max_parts][n_bins]  sticky partials (ping-pong in the fast path)
     int pc = 0;                        // which bin_part holds the latest partials
     DeviceBuf probs, probs_override, bins, idx, scores;
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
-    DeviceBuf kbar_ws, R_ws, P_ws;     // workspaces
-    // fast path (consolidate): bias-free scores, softmax weights and their row sums, ping-pong
-    DeviceBuf Sp[2], alpha[2], asum[2], cqbuf, Snew_ws;
+    DeviceBuf kbar_ws, R_ws[2], P_ws[2];   // workspaces; R/P double-buffered (role U lags the projection by a batch edge)
+    int wb = 0;                        // which R/P workspace the last projection filled
+    // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
+    // read two launches later), resolved gather tables (ring of 2, read one launch later)
+    DeviceBuf Sp[2], alpha[3], asum[3], tabring[2], cqbuf, Snew_ws;
     int sc = 0;
     int n_bins = 128;
     Profiler prof;
@@ -169,6 +176,16 @@ int upload_operator(Operator& op, int N, int rows, const int32_t* row_box, const
         if (old_ptr[0] != 0 || nnz < 0 || nnz > S) return fail(INFV_ERR_INVALID, "plan: bad old_ptr");
         for (int i = 0; i < nnz; ++i)
             if (old_slot[i] < 0 || old_slot[i] >= S) return fail(INFV_ERR_INVALID, "plan: old_slot out of range");
+        int mx = 0;
+        for (int n = 0; n < N; ++n) {
+            if (old_ptr[n + 1] < old_ptr[n]) return fail(INFV_ERR_INVALID, "plan: old_ptr not monotone");
+            if (old_ptr[n + 1] - old_ptr[n] > mx) mx = old_ptr[n + 1] - old_ptr[n];
+        }
+        op.tabw = mx < 4 ? 4 : (mx + 3) & ~3;
+        std::vector<int32_t> tab((size_t)N * op.tabw, -1);
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < old_ptr[n + 1] - old_ptr[n]; ++k) tab[(size_t)n * op.tabw + k] = old_slot[old_ptr[n] + k];
+        HIP_TRY(upload(op.slot_tab, tab.data(), tab.size()));
         HIP_TRY(upload(op.old_ptr, old_ptr, N + 1));
         HIP_TRY(upload(op.old_slot, old_slot, nnz));
     }
@@ -216,6 +233,7 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
     }
     h->parts = parts;
     h->lastQ = Q;
+    h->last_fast = false;
     return INFV_OK;
 }
 
@@ -238,16 +256,21 @@ int project_chunks(infv_ltm_handle h, const Plan& plan, bool inf, const float* k
     const long M = (long)n_chunks * op.rows;
     const long n_cols = (long)h->L * 2 * h->dm;
     const int sk = project_splitk((int)M, h->d);
-    HIP_TRY(h->R_ws.reserve((size_t)(M ? M : 1) * h->d * sizeof(float)));
-    HIP_TRY(h->P_ws.reserve((size_t)(M ? M : 1) * n_cols * sk * sizeof(float)));
+    h->wb ^= 1;
+    DeviceBuf& Rw = h->R_ws[h->wb];
+    DeviceBuf& Pw = h->P_ws[h->wb];
+    // growing a workspace frees it: nothing queued may still read it
+    if ((size_t)(M ? M : 1) * h->d * sizeof(float) > Rw.bytes || (size_t)(M ? M : 1) * n_cols * sk * sizeof(float) > Pw.bytes)
+        HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(Rw.reserve((size_t)(M ? M : 1) * h->d * sizeof(float)));
+    HIP_TRY(Pw.reserve((size_t)(M ? M : 1) * n_cols * sk * sizeof(float)));
     {
     Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
-    HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws.as<float>(), stream));
+    HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), Rw.as<float>(), stream));
     }
     {
     Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-    HIP_TRY(launch_project(n_chunks, h->d, h->dm, h->L, op.view(), pp, h->R_ws.as<float>(),
-                           h->P_ws.as<float>(), stream));
+    HIP_TRY(launch_project(n_chunks, h->d, h->dm, h->L, op.view(), pp, Rw.as<float>(), Pw.as<float>(), stream));
     }
     *splitk = sk;
     *split_stride = M * n_cols;
@@ -277,7 +300,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     h->dm = cfg->n_heads * cfg->head_size; h->P = cfg->tokens_per_frame; h->L = cfg->n_layers;
     h->S = cfg->nb_samples; h->maxQ = cfg->max_q; h->maxC = cfg->max_batch_chunks > 0 ? cfg->max_batch_chunks : 32;
     const size_t nb = (size_t)h->L * h->N;
-    const int max_parts = attend_parts(h->maxQ, h->H);
+    const int max_parts = h->H * ((h->maxQ + 7) / 8);      // finest partial granularity (8-row tiles of the fast path)
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = h->B[i].reserve(nb * h->d * sizeof(float));
@@ -288,7 +311,10 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->bin_part[i].reserve((size_t)h->L * max_parts * h->n_bins * sizeof(float));
         if (e == hipSuccess) e = hipMemset(h->bin_part[i].p, 0, h->bin_part[i].bytes);
         if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
-        if (e == hipSuccess) e = h->alpha[i].reserve(nsq * sizeof(float));
+        if (e == hipSuccess) e = h->tabring[i].reserve((size_t)h->L * h->N * 16 * sizeof(int32_t));
+    }
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+        e = h->alpha[i].reserve(nsq * sizeof(float));
         if (e == hipSuccess) e = h->asum[i].reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     }
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
@@ -379,7 +405,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     const ProjPtrs pp = make_proj(proj, h->L);
     int sk = 1; long ss = 0;
     if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, &sk, &ss, stream)) return rc;
-    return chain_step(h, *plan, h->R_ws.as<float>(), h->P_ws.as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
+    return chain_step(h, *plan, h->R_ws[h->wb].as<float>(), h->P_ws[h->wb].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
 }
 
 int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
@@ -392,71 +418,145 @@ int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* 
     return infv_ltm_step(h, h->kbar_ws.as<float>(), T, q, Q, proj, u, ctx, stream);
 }
 
-// One launch of the fused chain kernel: roles S and U for a chunk (if `plan_op` != nullptr) and
-// role C for the chunk whose read-out is pending.
-static int chain_launch(infv_ltm_handle h, const Plan& plan, const Operator* op, bool inf, const float* R,
-                        const float* Pnew, int splitk, long split_stride, const float* Snew, int Q,
-                        const ProjPtrs& pp, const double* u, float* ctx_pending, hipStream_t stream) {
-    ChainArgs a;
-    memset(&a, 0, sizeof(a));
-    const int QT = (Q + kQTile - 1) / kQTile;
-    a.N = h->N; a.H = h->H; a.Q = Q; a.QT = QT; a.L = h->L; a.S = h->S; a.d4 = h->d / 4; a.dm4 = h->dm / 4;
-    a.st = plan.sticky();
-    a.w = plan.w.as<float>(); a.w_out = plan.w_out;
-    for (int l = 0; l < h->L; ++l) a.bv[l] = pp.bv[l];
-    a.B_prev = h->B[h->cur].as<float>(); a.KV_prev = h->KV[h->cur].as<float>();
-    a.alpha_cur = h->alpha[h->sc].as<float>(); a.asum_cur = h->asum[h->sc].as<float>();
-    a.ctx_out = ctx_pending;
-    a.nC = ctx_pending ? h->H * QT * h->L : 0;
-    if (op != nullptr) {
-        a.op = op->view();
-        a.rows = op->rows; a.rows_max = op->rows;
-        a.draw_mode = inf ? (h->cfg.sticky ? 1 : 2) : 0;
-        if (a.draw_mode == 1) {
-            if (!u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
-            if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
-        }
-        a.part_prev = h->bin_part[h->pc].as<float>(); a.part_next = h->bin_part[h->pc ^ 1].as<float>();
-        a.parts = h->parts;
-        a.probs_override = h->probs_override.as<float>(); a.override_mask = h->override_mask;
-        a.u = u; a.uniform_idx = plan.uniform_idx.as<int32_t>();
-        a.probs_out = h->probs.as<float>(); a.bins_out = h->bins.as<int32_t>(); a.idx_out = h->idx.as<int32_t>();
-        a.Sp_prev = h->Sp[h->sc].as<float>(); a.Sp_next = h->Sp[h->sc ^ 1].as<float>();
-        a.Snew = Snew; a.cq = h->cqbuf.as<float>();
-        a.alpha_next = h->alpha[h->sc ^ 1].as<float>(); a.asum_next = h->asum[h->sc ^ 1].as<float>();
-        a.scores_out = h->scores.as<float>();
-        a.R = R; a.Pnew = Pnew; a.splitk = splitk; a.split_stride4 = split_stride / 4;
-        a.B_next = h->B[h->cur ^ 1].as<float>(); a.KV_next = h->KV[h->cur ^ 1].as<float>();
-        a.nS = h->H * QT * h->L;
-        a.nU = chain_u_blocks(h->N, h->L);
-    } else {
-        a.rows = a.rows_max = 0;
-    }
-    {
-        Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
-        HIP_TRY(launch_chain(a, stream));
-    }
-    if (op != nullptr) {
-        if (a.draw_mode == 1) h->override_mask = 0;
-        h->cur ^= 1; h->pc ^= 1; h->sc ^= 1;
-        h->has_memory = true;
-        h->parts = attend_parts(Q, h->H);
-        h->lastQ = Q;
-    }
-    return INFV_OK;
-}
+}  // extern "C"
 
-// batched new-row scores of `n_chunks` projected chunks (P_ws) into Snew_ws
-static int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const float* q, int Q,
-                        const ProjPtrs& pp, int sk, long ss, bool want_cq, hipStream_t stream) {
+// ---- whole-video fast path: 3-stage pipeline over launches (S(k), U(k-1), C(k-2)) --------------
+namespace {
+
+struct PendingU {                    // state update waiting for the next launch
+    bool valid = false;
+    const Operator* op = nullptr;
+    bool gather = false;
+    const float* R = nullptr; const float* Pn = nullptr; int sk = 1; long ss = 0;
+    int tab_slot = 0, alpha_slot = 0;
+    float* ctx = nullptr;
+};
+struct PendingC {                    // read-out waiting for the launch after its state update
+    bool valid = false;
+    int alpha_slot = 0;
+    float* ctx = nullptr;
+};
+struct StepS {                       // critical work of the chunk entering the pipeline
+    const Operator* op; bool inf; const float* Snew; const double* u;
+    const float* R; const float* Pn; int sk; long ss; float* ctx;
+};
+
+struct FastPipe {
+    infv_ltm_handle h; const Plan& plan; int Q; const ProjPtrs& pp; hipStream_t stream;
+    PendingU pu; PendingC pc;
+    long counter = 0;                // chunks that entered the pipeline in this call
+
+    int launch(const StepS* st) {
+        ChainArgs a;
+        memset(&a, 0, sizeof(a));
+        const int QT = (Q + kQTile - 1) / kQTile, QS = chain_s_tiles(Q);
+        a.N = h->N; a.H = h->H; a.Q = Q; a.QT = QT; a.QS = QS; a.L = h->L; a.S = h->S; a.d4 = h->d / 4; a.dm4 = h->dm / 4;
+        a.st = plan.sticky();
+        int alpha_slot = 0, tab_slot = 0;
+        if (st) {
+            ChainRoleS& s = a.s;
+            s.n_blocks = h->H * QS * h->L;
+            s.op = st->op->view();
+            s.draw_mode = st->inf ? (h->cfg.sticky ? 1 : 2) : 0;
+            if (s.draw_mode == 1) {
+                if (!st->u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
+                if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
+            }
+            alpha_slot = (int)(counter % 3);
+            tab_slot = (int)(counter % 2);
+            s.part_prev = h->bin_part[h->pc].as<float>(); s.part_next = h->bin_part[h->pc ^ 1].as<float>();
+            s.parts = h->parts;
+            s.probs_override = h->probs_override.as<float>(); s.override_mask = h->override_mask;
+            s.u = st->u; s.uniform_idx = plan.uniform_idx.as<int32_t>();
+            s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
+            s.tab_out = h->tabring[tab_slot].as<int32_t>();
+            s.Sp_prev = h->Sp[h->sc].as<float>(); s.Sp_next = h->Sp[h->sc ^ 1].as<float>();
+            s.Snew = st->Snew; s.cq = h->cqbuf.as<float>();
+            s.w = plan.w.as<float>(); s.w_out = plan.w_out;
+            s.alpha_out = h->alpha[alpha_slot].as<float>(); s.asum_out = h->asum[alpha_slot].as<float>();
+        }
+        if (pu.valid) {
+            ChainRoleU& u = a.u;
+            u.n_blocks = chain_u_blocks(h->N, h->L);
+            u.op = pu.op->view();
+            u.gather = pu.gather ? 1 : 0;
+            u.tab = h->tabring[pu.tab_slot].as<int32_t>();
+            u.R = pu.R; u.Pnew = pu.Pn; u.splitk = pu.sk; u.split_stride4 = pu.ss / 4;
+            u.B_prev = h->B[h->cur].as<float>(); u.KV_prev = h->KV[h->cur].as<float>();
+            u.B_next = h->B[h->cur ^ 1].as<float>(); u.KV_next = h->KV[h->cur ^ 1].as<float>();
+        }
+        if (pc.valid) {
+            ChainRoleC& c = a.c;
+            c.n_blocks = h->H * QT * h->L;
+            c.alpha = h->alpha[pc.alpha_slot].as<float>(); c.asum = h->asum[pc.alpha_slot].as<float>();
+            c.KV = h->KV[h->cur].as<float>();                 // V' of the chunk whose update ran last launch
+            for (int l = 0; l < h->L; ++l) c.bv[l] = pp.bv[l];
+            c.ctx_out = pc.ctx;
+        }
+        {
+            // timing experiments only (results are wrong when a role is masked out): INFV_CHAIN_ROLES=bitmask S=1 U=2 C=4 noop=8
+            static const int role_mask = [] { const char* e = getenv("INFV_CHAIN_ROLES"); return e ? atoi(e) : 7; }();
+            if (!(role_mask & 1)) a.s.n_blocks = 0;
+            if (!(role_mask & 2)) a.u.n_blocks = 0;
+            if (!(role_mask & 4)) a.c.n_blocks = 0;
+            a.debug_noop = (role_mask & 8) ? 1 : 0;
+            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
+            a.dbg = dbg;
+            static int stamp_calls = 0;
+            if (dbg && (++stamp_calls % 300) == 0) {
+                long long hb[32];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[stamps x10ns] S:");
+                for (int i = 1; i <= 5; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
+                fprintf(stderr, " | U: %lld %lld | C:", hb[9] - hb[8], hb[11] - hb[9]);
+                for (int i = 17; i <= 19; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
+                fprintf(stderr, " | clk %.0f MHz | ends rel S0: S %lld U %lld C %lld\n",
+                        100.0 * (double)(hb[29] - hb[24]) / (double)(hb[5] - hb[0]), hb[5] - hb[0], hb[11] - hb[0], hb[19] - hb[0]);
+            }
+            Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
+            HIP_TRY(launch_chain(a, stream));
+        }
+        // ---- advance the pipeline ----
+        pc.valid = false;
+        if (pu.valid) {
+            h->cur ^= 1;                                      // B / V' now describe pu's chunk
+            pc.valid = true; pc.alpha_slot = pu.alpha_slot; pc.ctx = pu.ctx;
+            pu.valid = false;
+        }
+        if (st) {
+            if (a.s.draw_mode == 1) h->override_mask = 0;
+            h->pc ^= 1; h->sc ^= 1;
+            h->has_memory = true;
+            h->parts = h->H * QS;
+            h->lastQ = Q;
+            h->last_fast = true;
+            pu.valid = true; pu.op = st->op; pu.gather = st->inf;
+            pu.R = st->R; pu.Pn = st->Pn; pu.sk = st->sk; pu.ss = st->ss;
+            pu.tab_slot = tab_slot; pu.alpha_slot = alpha_slot; pu.ctx = st->ctx;
+            ++counter;
+        }
+        return INFV_OK;
+    }
+};
+
+// batched new-row scores of `n_chunks` projected chunks (current P workspace) into Snew_ws
+int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const float* q, int Q,
+                 const ProjPtrs& pp, int sk, long ss, bool want_cq, hipStream_t stream) {
     const long n_cols = (long)h->L * 2 * h->dm;
-    HIP_TRY(h->Snew_ws.reserve((size_t)n_chunks * h->L * h->H * Q * (op.rows ? op.rows : 1) * sizeof(float)));
+    const size_t need = (size_t)n_chunks * h->L * h->H * Q * (op.rows ? op.rows : 1) * sizeof(float);
+    if (need > h->Snew_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(h->Snew_ws.reserve(need));
     Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
-    HIP_TRY(launch_new_scores(q, Q, h->H, h->L, n_chunks, op.rows, h->P_ws.as<float>(), (long)op.rows * n_cols, n_cols,
+    HIP_TRY(launch_new_scores(q, Q, h->H, h->L, n_chunks, op.rows, h->P_ws[h->wb].as<float>(), (long)op.rows * n_cols, n_cols,
                               2L * h->dm, sk, ss, pp, h->Snew_ws.as<float>(), want_cq ? h->cqbuf.as<float>() : nullptr,
                               stream));
     return INFV_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T, const float* q,
                          int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
@@ -474,26 +574,27 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     if (new_doc) infv_ltm_reset(h);
     if (n_chunks == 0) return INFV_OK;
     const int rows_max = plan->first.rows > plan->inf.rows ? plan->first.rows : plan->inf.rows;
-    if (h->S > 1024 || chain_lds_bytes(h->N, h->S, rows_max) > 160 * 1024) {
+    if (!chain_supported(h->N, h->S, rows_max, plan->inf.tabw)) {
         // shapes the fused chain kernel cannot hold in LDS: per-chunk stage kernels
         for (int c = 0; c < n_chunks; ++c)
             if (int rc = infv_ltm_forward(h, k + c * chunk_k, T, q, Q, proj, u ? u + c * chunk_u : nullptr, 0,
                                           ctx + c * chunk_ctx, stream_)) return rc;
         return INFV_OK;
     }
+    FastPipe pipe{h, *plan, Q, pp, stream};
     int c = 0;
-    float* pending = nullptr;                                 // ctx slot of the chunk whose read-out is deferred
     bool have_cq = false;
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator
+        if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
         if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
         int sk = 1; long ss = 0;
         if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, &sk, &ss, stream)) return rc;
         if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, sk, ss, true, stream)) return rc;
         have_cq = true;
-        if (int rc = chain_launch(h, *plan, &plan->first, false, h->R_ws.as<float>(), h->P_ws.as<float>(), sk, ss,
-                                  h->Snew_ws.as<float>(), Q, pp, nullptr, nullptr, stream)) return rc;
-        pending = ctx;
+        const StepS st{&plan->first, false, h->Snew_ws.as<float>(), nullptr, h->R_ws[h->wb].as<float>(),
+                       h->P_ws[h->wb].as<float>(), sk, ss, ctx};
+        if (int rc = pipe.launch(&st)) return rc;
         c = 1;
     } else {
         // continue an existing memory: bias-free scores of the current K' rows under this query
@@ -505,6 +606,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     }
     while (c < n_chunks) {
         const int nb = (n_chunks - c < h->maxC) ? n_chunks - c : h->maxC;
+        if ((size_t)nb * T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(h->kbar_ws.reserve((size_t)nb * T * h->d * sizeof(float)));
         {
             Timed t_(h->prof, INFV_KERNEL_POOL, stream);
@@ -516,19 +618,24 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         have_cq = true;
         const size_t rows = plan->inf.rows;
         for (int i = 0; i < nb; ++i) {
-            const float* R = h->R_ws.as<float>() + (size_t)i * rows * h->d;
-            const float* Pn = h->P_ws.as<float>() + (size_t)i * rows * h->L * 2 * h->dm;
-            const float* Sn = h->Snew_ws.as<float>() + (size_t)i * h->L * h->H * Q * rows;
-            const double* uc = u ? u + (size_t)(c + i) * chunk_u : nullptr;
-            if (int rc = chain_launch(h, *plan, &plan->inf, true, R, Pn, sk, ss, Sn, Q, pp, uc, pending, stream)) return rc;
-            pending = ctx + (size_t)(c + i) * chunk_ctx;
+            const StepS st{&plan->inf, true, h->Snew_ws.as<float>() + (size_t)i * h->L * h->H * Q * rows,
+                           u ? u + (size_t)(c + i) * chunk_u : nullptr,
+                           h->R_ws[h->wb].as<float>() + (size_t)i * rows * h->d,
+                           h->P_ws[h->wb].as<float>() + (size_t)i * rows * h->L * 2 * h->dm, sk, ss,
+                           ctx + (size_t)(c + i) * chunk_ctx};
+            if (int rc = pipe.launch(&st)) return rc;
         }
         c += nb;
     }
-    // flush the last read-out, then bring the K' half of the projected memory up to date
-    if (int rc = chain_launch(h, *plan, nullptr, false, nullptr, nullptr, 1, 0, nullptr, Q, pp, nullptr, pending, stream)) return rc;
+    // drain: U(last) + C(last-1), then C(last); then bring the K' half of the projected memory up to date
+    if (int rc = pipe.launch(nullptr)) return rc;
+    if (int rc = pipe.launch(nullptr)) return rc;
     return infv_ltm_reproject(h, proj, stream_);
 }
+
+}  // extern "C"
+
+extern "C" {
 
 int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin_mass, void* stream_) {
     if (int rc = check_handle(h)) return rc;
@@ -589,7 +696,15 @@ int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* 
     if (scores) {
         if (h->lastQ <= 0) return fail(INFV_ERR_STATE, "no scores yet");
         const size_t n = (size_t)h->H * h->lastQ * h->N;
-        HIP_TRY(hipMemcpy(scores, h->scores.as<float>() + (size_t)layer * n, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (h->last_fast) {
+            std::vector<float> cq((size_t)h->H * h->lastQ);
+            HIP_TRY(hipMemcpy(scores, h->Sp[h->sc].as<float>() + (size_t)layer * n, n * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cq.data(), h->cqbuf.as<float>() + (size_t)layer * cq.size(), cq.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < cq.size(); ++r)
+                for (int j = 0; j < h->N; ++j) scores[r * h->N + j] += cq[r];
+        } else {
+            HIP_TRY(hipMemcpy(scores, h->scores.as<float>() + (size_t)layer * n, n * sizeof(float), hipMemcpyDeviceToHost));
+        }
     }
     return INFV_OK;
 }

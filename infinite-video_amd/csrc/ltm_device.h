@@ -14,12 +14,17 @@ constexpr int kVStride = 80;             // LDS row pitch of the V' stage: == 16
 constexpr int kDPitch = 132;             // LDS row pitch of the edge densities (129 used)
 constexpr int kMPitch = 128;             // LDS row pitch of the per-row bin masses
 
-__device__ inline double block_sum_256(double v, double* scratch) {
+// Sum over the NT threads of the workgroup (NT/64 waves); every thread gets the result.
+template <int NT>
+__device__ inline double block_sum(double v, double* scratch /*LDS[NT/64]*/) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += scratch[i];
+    return t;
 }
 
 // --------------------------------------------------------------------------------------
@@ -30,61 +35,158 @@ __device__ inline double block_sum_256(double v, double* scratch) {
 //   last bucket forced to 1, lower-bound search of each float64 uniform.
 // The scan runs in one lane's registers (127 dependent fp32 adds, IEEE, same order as the CPU),
 // so the draw is bit-exact given identical probabilities.
-// Called by all 256 threads; on return sidx[0..S) (LDS) holds the resampled box of every slot.
+// Called by all NT threads; on return sidx[0..S) (LDS) holds the resampled box of every slot.
+// All global reads (partials, uniforms) are issued up front so the draw costs one memory round trip;
+// bin_box may point to an LDS copy.  Needs S <= SPT * NT.
+// LDS: cdf[kBins] (16-B aligned), sidx[S], gsum[(NT/128)*kBins] doubles, scratch[NT/64] doubles, total[1].
 // --------------------------------------------------------------------------------------
-__device__ inline void draw_core(const float* __restrict__ part, int parts,
-                                 const float* __restrict__ probs_override, bool use_override,
-                                 const StickyView& st, const double* __restrict__ u, int S,
-                                 float* cdf /*LDS[kBins]*/, int32_t* sidx /*LDS[S]*/, double* scratch /*LDS[4]*/,
-                                 float* total /*LDS[1]*/, float* probs_out, int32_t* bins_out, int32_t* idx_out) {
+// ---- wave64 reductions on the DPP datapath (no LDS crossbar): xor-butterfly inside each row of 16
+// lanes (quad_perm, quad_perm, row_half_mirror, row_mirror), then the 4 row sums via v_readlane.
+// Every lane gets the result; the summation order is fixed.
+template <int CTRL>
+__device__ inline float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ inline float wave_sum(float v) {
+    v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);           // row_half_mirror
+    v += dpp_f32<0x140>(v);           // row_mirror
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ inline float wave_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double wave_sum_f64(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// Registers of the draw: wave 0 of the workgroup owns the probabilities (lane j: bins j and j+64),
+// every thread owns up to SPT uniforms.
+template <int SPT>
+struct DrawRegs {
+    double us[SPT];      // this thread's uniforms (slots tid + i*NT)
+    double acc;          // this thread's share (parts p = grp, grp+G, ..) of the mass of bin tid & 127
+    float ovr[2];        // wave 0: teacher-forced probabilities of those bins (if overriding)
+};
+
+// Phase 1: issue every global read of the draw (uniforms, partial masses) -- no LDS, no barrier.
+template <int NT, int SPT>
+__device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int parts,
+                                          const float* __restrict__ probs_override, bool use_override,
+                                          const double* __restrict__ u, int S) {
     constexpr int nb = kBins - 1;
-    const int j = threadIdx.x;
-    float prob = 0.f;
-    if (use_override) {
-        if (j < nb) prob = probs_override[j];
-    } else {
-        double acc = 0.0;
-        if (j < nb) {
-#pragma unroll 8
-            for (int p = 0; p < parts; ++p) acc += (double)part[(long)p * kBins + j];
-        }
-        const float raw = (float)acc;
-        const float tot1 = (float)block_sum_256((double)raw, scratch);
-        const float p1 = raw / tot1;
-        const float tot2 = (float)block_sum_256((j < nb) ? (double)p1 : 0.0, scratch);
-        prob = p1 / tot2;
-    }
-    if (j < kBins) cdf[j] = (j < nb) ? prob : 0.f;
-    if (probs_out != nullptr && j < nb) probs_out[j] = prob;
-    __syncthreads();
-    if (j == 0) {
-        float v[kBins];
+    const int tid = threadIdx.x;
+    DrawRegs<SPT> r;
 #pragma unroll
-        for (int i = 0; i < kBins; i += 4) {
-            const floatx4 t = *reinterpret_cast<const floatx4*>(&cdf[i]);
-            v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    for (int i = 0; i < SPT; ++i) r.us[i] = (tid + i * NT < S) ? u[tid + i * NT] : 2.0;
+    r.acc = 0.0;
+    r.ovr[0] = r.ovr[1] = 0.f;
+    if (use_override) {
+        if (tid < 64) {
+            r.ovr[0] = probs_override[tid];
+            if (tid + 64 < nb) r.ovr[1] = probs_override[tid + 64];
         }
+    } else {
+        constexpr int G = NT / kBins;                   // thread groups that split the partial rows
+        const int j = tid & (kBins - 1), grp = tid / kBins;
+#pragma unroll 4
+        for (int p = grp; p < parts; p += G) r.acc += (double)part[(long)p * kBins + j];   // bin 127 is padding
+    }
+    return r;
+}
+
+// Phase 2: probabilities -> cdf (wave 0, registers only) -> one barrier -> draws (all threads).
+// Ends with a barrier.  cdf[kBins] and sidx[S] live in LDS.
+template <int NT, int SPT>
+__device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, const int32_t* bin_box, int S,
+                                   float* cdf, int32_t* sidx, double* gsum /*LDS[(NT/128)*128]*/, float* probs_out,
+                                   int32_t* bins_out, int32_t* idx_out) {
+    constexpr int nb = kBins - 1;
+    constexpr int G = NT / kBins;
+    const int tid = threadIdx.x;
+    if (!use_override) {
+        gsum[tid] = r.acc;                               // [grp][bin]
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const int j0 = tid, j1 = tid + 64;
+        float p0, p1;
+        if (use_override) {
+            p0 = r.ovr[0]; p1 = r.ovr[1];
+        } else {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) { a0 += gsum[g2 * kBins + j0]; a1 += gsum[g2 * kBins + j1]; }
+            const float raw0 = (float)a0;
+            const float raw1 = (j1 < nb) ? (float)a1 : 0.f;
+            const float tot1 = (float)wave_sum_f64((double)raw0 + (double)raw1);
+            const float q0 = raw0 / tot1, q1 = raw1 / tot1;                       // LTM.py:203
+            const float tot2 = (float)wave_sum_f64((double)q0 + (double)q1);
+            p0 = q0 / tot2; p1 = q1 / tot2;                                       // Categorical's own normalisation
+        }
+        if (j1 >= nb) p1 = 0.f;
+        if (probs_out != nullptr) { probs_out[j0] = p0; if (j1 < nb) probs_out[j1] = p1; }
+        // sequential fp32 running sum in bin order (torch.multinomial, CPU): every lane follows the same
+        // dependent chain (bin i's probability is broadcast from its owner lane with v_readlane) and
+        // drops each partial sum into LDS; nothing else sits on the chain.
         float run = 0.f;
 #pragma unroll
-        for (int i = 0; i < nb; ++i) { run = run + v[i]; v[i] = run; }
+        for (int i = 0; i < 64; ++i) { run = run + readlane_f32(p0, i); cdf[i] = run; }
 #pragma unroll
-        for (int i = 0; i < kBins; i += 4)
-            *reinterpret_cast<floatx4*>(&cdf[i]) = floatx4{v[i], v[i + 1], v[i + 2], v[i + 3]};
-        *total = run;
+        for (int i = 0; i < 63; ++i) { run = run + readlane_f32(p1, i); cdf[64 + i] = run; }
+        const float c0 = cdf[j0], c1 = (j1 < nb) ? cdf[j1] : 0.f;   // same wave: LDS ops complete in order
+        cdf[j0] = c0 / run;
+        if (j1 < nb) cdf[j1] = (j1 == nb - 1) ? 1.f : c1 / run;
+        if (tid == 0) cdf[nb] = 2.f;                                 // pad: never below a uniform
     }
     __syncthreads();
-    if (j < nb) cdf[j] = (j == nb - 1) ? 1.f : cdf[j] / *total;
-    __syncthreads();
-    for (int s = j; s < S; s += 256) {
-        const double us = u[s];
-        int lo = 0, hi = nb;
-        while (hi - lo > 0) {
-            const int mid = lo + (hi - lo) / 2;
-            if ((double)cdf[mid] < us) lo = mid + 1; else hi = mid;
+    // lower bound of u in the non-decreasing cdf == number of entries below u (torch's binary search
+    // returns the same index).  Two levels: 16 coarse entries cdf[8k+7], then the 8 entries of that group.
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const int s = tid + i * NT;
+        if (s < S) {
+            const double us = r.us[i];
+            int grp = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) grp += ((double)cdf[8 * k + 7] < us) ? 1 : 0;
+            int lo = 8 * grp;
+            if (grp < 16) {
+                const floatx4 f0 = *reinterpret_cast<const floatx4*>(&cdf[8 * grp]);
+                const floatx4 f1 = *reinterpret_cast<const floatx4*>(&cdf[8 * grp + 4]);
+                lo += ((double)f0.x < us) + ((double)f0.y < us) + ((double)f0.z < us) + ((double)f0.w < us) +
+                      ((double)f1.x < us) + ((double)f1.y < us) + ((double)f1.z < us);
+            }
+            lo = min(lo, nb - 1);
+            const int box = bin_box[lo];
+            sidx[s] = box;
+            if (bins_out != nullptr) { bins_out[s] = lo; idx_out[s] = box; }
         }
-        const int box = st.bin_box[lo];
-        sidx[s] = box;
-        if (bins_out != nullptr) { bins_out[s] = lo; idx_out[s] = box; }
     }
     __syncthreads();
 }
@@ -138,6 +240,53 @@ __device__ inline void row_phase(float* Ssm, int sstride, int N, int valid_rows,
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < kQTile; ++r) t += Msm[r * kMPitch + tid];
+        part_out[tid] = t;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Same row-wise phase with ONE WAVE PER QUERY ROW (1024-thread workgroups: wave w owns row w).
+// Row reductions are wave reductions; the 16 rows proceed in parallel on the CU's 4 SIMDs.
+// --------------------------------------------------------------------------------------
+__device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_rows, const float* w,
+                                      float w_out, const int32_t* edge_box, const float* edge_dx, float* Dsm,
+                                      float* Msm, float* asum, float* __restrict__ part_out, int rows_in_tile) {
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    float* Srow = Ssm + row * sstride;
+    float* Drow = Dsm + row * kDPitch;
+    float m = -INFINITY;
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, Srow[n]);
+    m = wave_max(m);
+    const float md = fmaxf(m, 0.f);                    // edges outside every box score 0
+    // edge densities feed the Gibbs draw: accurate expf
+    for (int j = lane; j <= kBins; j += 64) {
+        const int eb = edge_box[j];
+        const float sc = (eb >= 0) ? Srow[eb] : 0.f;
+        Drow[j] = expf(sc - md);
+    }
+    __syncthreads();                                   // raw-score reads done before alpha overwrites
+    // softmax weights feed only the read-out (1e-3 budget): hardware exp2
+    float esum = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float e = w[n] * __expf(Srow[n] - m);
+        Srow[n] = e;
+        esum += e;
+    }
+    esum = wave_sum(esum);
+    const float inv = 1.0f / (esum + w_out * __expf(-m));
+    for (int n = lane; n < N; n += 64) Srow[n] *= inv;
+    if (lane == 0) asum[row] = esum * inv;
+    float z = 0.f;
+    for (int j = lane; j < kBins; j += 64) z += (Drow[j] + Drow[j + 1]) * edge_dx[j];
+    const float inv_z = 1.0f / (wave_sum(z) * 0.5f);
+    for (int j = lane; j < kBins - 1; j += 64) {
+        const float dl = Drow[j + 1] * inv_z, dr = Drow[j + 2] * inv_z;
+        Msm[row * kMPitch + j] = (row < valid_rows) ? ((dl + dr) * edge_dx[j + 1]) * 0.5f : 0.f;
+    }
+    __syncthreads();
+    if (tid < kBins - 1) {
+        float t = 0.f;
+        for (int r = 0; r < rows_in_tile; ++r) t += Msm[r * kMPitch + tid];
         part_out[tid] = t;
     }
 }

@@ -19,6 +19,8 @@ struct OperatorView {
     const int32_t* box_row;       // [N]  row index of box n, -1 if it receives no new frame
     const int32_t* old_ptr;       // [N+1] or nullptr (first-chunk operator)
     const int32_t* old_slot;      // CSR payload
+    const int32_t* slot_tab;      // [N][tabw] dense form of the CSR: slot ids of box n, -1 padded (nullptr if no old)
+    int32_t tabw;                 // max slots per box rounded up to a multiple of 4
 };
 
 struct StickyView {
@@ -67,26 +69,46 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
                          float* bin_part, float* scores, hipStream_t stream);
 
 // ---- whole-video fast path (ltm_chain.hip) ----------------------------------------------------
-struct ChainArgs {
-    int N, H, Q, QT, L, S, d4, dm4, rows, rows_max;
+// One launch runs up to three independent roles, each on its own chunk of a 3-stage pipeline:
+//   S(k)   draw k -> score recurrence -> alpha_k, sticky partials_k, publishes idx_k
+//   U(k-1) B and V' rows of chunk k-1 from idx_{k-1}            (no draw: reads what S published)
+//   C(k-2) read-out ctx_{k-2} = alpha_{k-2} . (V'_{k-2} + bv)
+struct ChainRoleS {
+    int n_blocks;                   // H * QS * L, or 0
     OperatorView op;
-    StickyView st;
     int draw_mode;                  // 0: none (first chunk of a document), 1: sticky Gibbs draw, 2: uniform resample
     const float* part_prev; float* part_next; int parts;
     const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
-    float* probs_out; int32_t* bins_out; int32_t* idx_out;
-    // role S: score recurrence + softmax weights + next sticky partials
+    float* probs_out; int32_t* bins_out; int32_t* idx_out;     // [L][128], [L][S], [L][S]  (diagnostics)
+    int32_t* tab_out;               // [L][N*tabw] resolved source box of every (box, slot) for role U
     const float* Sp_prev; float* Sp_next; const float* Snew; const float* cq; const float* w; float w_out;
-    float* alpha_next; float* asum_next; float* scores_out;
-    // role U: B and V' rows
+    float* alpha_out; float* asum_out;
+};
+struct ChainRoleU {
+    int n_blocks;                   // L * ceil(N / boxes per block), or 0
+    OperatorView op;
+    int gather;                     // 0: new rows only (first chunk of a document)
+    const int32_t* tab;             // [L][N*tabw] written by role S one launch earlier
     const float* R; const float* Pnew; int splitk; long split_stride4;
     const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
-    // role C: read-out of the previous chunk
-    const float* alpha_cur; const float* asum_cur; const float* bv[kMaxLayers]; float* ctx_out;
-    int nS, nU, nC;                 // workgroups per role
 };
-size_t chain_lds_bytes(int N, int S, int rows_max);
+struct ChainRoleC {
+    int n_blocks;                   // H * QT * L, or 0
+    const float* alpha; const float* asum; const float* KV; const float* bv[kMaxLayers]; float* ctx_out;
+};
+struct ChainArgs {
+    int N, H, Q, QT, QS, L, S, d4, dm4;   // QT: 16-row tiles (role C), QS: 8-row tiles (role S)
+    StickyView st;
+    ChainRoleS s;
+    ChainRoleU u;
+    ChainRoleC c;
+    int debug_noop;                 // timing experiments: every workgroup returns at once
+    long long* dbg;                 // timing experiments: phase stamps (100 MHz) of one workgroup per role, or nullptr
+};
+size_t chain_lds_bytes(int N, int S, int rows, int tabw);
+bool chain_supported(int N, int S, int rows_max, int tabw);
 int chain_u_blocks(int N, int n_layers);
+int chain_s_tiles(int Q);            // 8-row query tiles of role S (= sticky partial rows per head)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
 // S'new[c][l][h][q][r] = (q_h[q]/sqrt(dh)) . Kmat(c,r,l)_h ; optionally cq[l][h][q] = q_h[q].bk_h/sqrt(dh)
 hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_chunks, int rows, const float* Kmat,

@@ -245,14 +245,15 @@ __global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin
                                                    const double* __restrict__ u, int S,
                                                    float* __restrict__ probs_out, int32_t* __restrict__ bins_out,
                                                    int32_t* __restrict__ idx_out) {
-    __shared__ double scratch[4];
-    __shared__ __attribute__((aligned(16))) float cdf[kBins];
-    __shared__ float total;
+    __shared__ float cdf[kBins];
+    __shared__ double gsum[256];
     __shared__ int32_t sidx[1024];
     const int l = blockIdx.x;
-    draw_core(bin_part + (long)l * parts * kBins, parts, probs_override + l * kBins, (override_mask >> l) & 1u,
-              sticky, u + (long)l * S, S, cdf, sidx, scratch, &total, probs_out + l * kBins,
-              bins_out + (long)l * S, idx_out + (long)l * S);
+    const bool ovr = (override_mask >> l) & 1u;
+    const DrawRegs<4> r = draw_load<256, 4>(bin_part + (long)l * parts * kBins, parts, probs_override + l * kBins,
+                                            ovr, u + (long)l * S, S);
+    draw_finish<256, 4>(r, ovr, sticky.bin_box, S, cdf, sidx, gsum, probs_out + l * kBins, bins_out + (long)l * S,
+                        idx_out + (long)l * S);
 }
 
 hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
@@ -296,13 +297,20 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
         const int pitch = isB ? d4 : kv4;
         const floatx4* prev = isB ? Bp : KVp;
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = sb; s < se; ++s) {
-            const int src = my_idx[op.old_slot[s]];
-            if (src >= 0) {
-                const floatx4 v = prev[(long)src * pitch + cc];
-                acc.x = fmaf(val, v.x, acc.x); acc.y = fmaf(val, v.y, acc.y);
-                acc.z = fmaf(val, v.z, acc.z); acc.w = fmaf(val, v.w, acc.w);
+        for (int s0 = sb; s0 < se; s0 += 4) {           // 4 gathered rows in flight at a time
+            floatx4 v[4];
+            int src[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                src[k] = (s0 + k < se) ? my_idx[op.old_slot[s0 + k]] : -1;
+                v[k] = prev[(long)max(src[k], 0) * pitch + cc];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (src[k] >= 0) {
+                    acc.x = fmaf(val, v[k].x, acc.x); acc.y = fmaf(val, v[k].y, acc.y);
+                    acc.z = fmaf(val, v[k].z, acc.z); acc.w = fmaf(val, v[k].w, acc.w);
+                }
         }
         if (row >= 0) {
             if (isB) {
