@@ -1,0 +1,177 @@
+"""Drop-in ``LongTermAttention`` for infinity-Video on MI355X.
+
+Mirrors the operator surface of the reference module
+
+    infty-Video-LLaMA/InfVideoLLaMA/models/long_term_attention_gibbs.py:25-346   (Video-LLaMA)
+    infty-VideoChat2/models/blip2/long_term_attention_gibbs.py                   (VideoChat2)
+
+same constructor kwargs (as the Q-former passes them, Qformer.py:135-158), same
+``forward(k, q, new_doc, layer_n)``, same mutable attributes (``length``, ``target_len``,
+``B_past``, ``x_past``).  The arithmetic runs in the HIP kernels of ``libinfv_ltm.so``; there is
+no PyTorch fallback -- constructing the module's engine raises if the library or a GPU is missing.
+
+Differences from the reference, all deliberate:
+
+* ``get_basis`` is not rebuilt on every call: the operator tables depend only on
+  ``(T, num_basis, tau)`` and are cached (``basis_maps.build_plan``).
+* The density-pickle side effect of the Video-LLaMA variant (reference :320-345, writes
+  ``./alphas_uniform`` on every call, result unused by the model) is not reproduced.
+* The Gibbs draw consumes torch's global **CPU** generator exactly like the reference's CPU path:
+  512 float64 uniforms for the bin draw, then 512 more for the degenerate in-bin draw (:204-206).
+  Seed it with ``torch.manual_seed`` to reproduce the reference CPU run draw for draw.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .basis_maps import NB_SAMPLES
+from .engine import LTMEngine
+
+# one-entry cache of pooled frames: the Q-former calls every layer's LTM with the same
+# encoder_hidden_states, so the frame tokens (25 MB at the headline shape) are read once per chunk
+_pool_cache = {"key": None, "kbar": None}
+
+
+class LongTermAttention(nn.Module):
+    tokens_per_frame = 32      # reference :291,304 hard-codes k.reshape(B, klen, 32, 768)
+    encoder_width = 768
+
+    def __init__(self, head_size: int, length: int, target_len: int, attn_func: str, attn_num_basis: int,
+                 continuous: bool, attn_drop: float, infinite_memory: bool, n_layers: int,
+                 n_heads: int, affines: bool, mask: bool, mask_type: str, kl_regularizer: bool, proj_key, proj_value,
+                 sigma_0, mu_0, sticky_memories, sigmas, tau, **kwargs):
+        super().__init__()
+        # the attribute set of the reference constructor (:32-65)
+        self.device = 'cuda'
+        self.length = length
+        self.target_len = target_len
+        self.head_size = head_size
+        self.attn_num_basis = attn_num_basis
+        self.continuous = continuous
+        self.attn_func = attn_func
+        self.n_head = n_heads
+        self.sigmas = sigmas
+        self.kl_regularizer = kl_regularizer
+        self.sigma_0 = sigma_0
+        self.mu_0 = mu_0
+        # borrowed references to the cross-attention's own key/value Linear (Qformer.py:156-157);
+        # kept out of this module's parameter list, exactly like a plain attribute would not be... they
+        # are nn.Modules, so they do register -- as in the reference.
+        self.proj_key = proj_key
+        self.proj_value = proj_value
+        self.affines = affines
+        self.sticky_memories = sticky_memories
+        self.mem_threshold = 2048
+        self.infinite_memory = infinite_memory
+        self.nb_samples = NB_SAMPLES
+        self.tau = tau
+        self.count = 0
+        self.x_past = None            # never read by the reference either (:221)
+        self.ridge_penalty = 0.5
+        self.padding = True
+        self.spacing = 'linear'
+        self.d_model = kwargs.get("d_model", n_heads * head_size)
+        if not continuous:
+            raise NotImplementedError("only the continuous-attention path exists in the reference (forward :290)")
+        if attn_func != "softmax":
+            raise NotImplementedError("the active reference path is the softmax density (:248)")
+        if tau is None or attn_num_basis is None:
+            # the image Q-former builds LTM objects with num_basis/tau = None and never calls them
+            # (blip2.py:48-65, infinityqa.py:265); allow construction, refuse forward.
+            self._callable = False
+        else:
+            self._callable = True
+        self._engine: Optional[LTMEngine] = None
+
+    # ------------------------------------------------------------------ engine
+    def _get_engine(self, device: torch.device, Q: int) -> LTMEngine:
+        eng = self._engine
+        if eng is None or eng.device != device or eng.max_q < Q:
+            if eng is not None and eng.has_memory:
+                raise RuntimeError("LongTermAttention moved device or grew its query length mid-document")
+            self._engine = eng = LTMEngine(
+                self.attn_num_basis, self.n_head, self.head_size, self.encoder_width, self.tokens_per_frame,
+                tau=self.tau, sticky=bool(self.sticky_memories), n_layers=1, max_q=max(Q, 32), device=device,
+                nb_samples=self.nb_samples)
+        return eng
+
+    def _proj(self, device):
+        def f32(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+                t = t.to(device=device, dtype=torch.float32).contiguous()
+            return t
+        dm, d = self.n_head * self.head_size, self.encoder_width
+        bk = self.proj_key.bias if self.proj_key.bias is not None else torch.zeros(dm, device=device)
+        bv = self.proj_value.bias if self.proj_value.bias is not None else torch.zeros(dm, device=device)
+        wk, wv = f32(self.proj_key.weight), f32(self.proj_value.weight)
+        if tuple(wk.shape) != (dm, d) or tuple(wv.shape) != (dm, d):
+            raise ValueError(f"proj_key/proj_value must map {d} -> {dm}")
+        return (wk, f32(bk), wv, f32(bv))
+
+    # ------------------------------------------------------------------ reference-visible state
+    @property
+    def B_past(self) -> Optional[torch.Tensor]:
+        """Coefficient matrix [1, N, d] after the last call, ``None`` before the first / after new_doc."""
+        if self._engine is None or not self._engine.has_memory:
+            return None
+        return self._engine.export_state(0)[0].unsqueeze(0)
+
+    @B_past.setter
+    def B_past(self, value):
+        if value is not None:
+            raise AttributeError("B_past can only be cleared (set to None); use engine.import_state to load a memory")
+        if self._engine is not None:
+            self._engine.reset()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, k, q, new_doc, layer_n):
+        """k [1, T*P, d] frame tokens, q [1, Q, H*dh] -> [1, Q, H*dh]   (reference :288-346)."""
+        if not self._callable:
+            raise RuntimeError("this LongTermAttention was built with num_basis/tau = None (image Q-former) "
+                               "and must not be called")
+        if not k.is_cuda:
+            raise RuntimeError("LongTermAttention runs on the HIP device only (no CPU fallback)")
+        if k.size(0) != 1 or q.size(0) != 1:
+            raise ValueError("batch size must be 1 (reference :208,346)")
+        self.device = k.device
+        P, d = self.tokens_per_frame, self.encoder_width
+        if k.size(2) != d or k.size(1) % P:
+            raise ValueError(f"k must be [1, T*{P}, {d}]")
+        klen = k.size(1) // P
+        self.length = klen
+        qlen = q.size(1)
+        eng = self._get_engine(k.device, qlen)
+        if new_doc or not self.infinite_memory:
+            eng.reset()                                   # :300-302 (and the non-infinite branch :310)
+        kf = k[0]
+        if kf.dtype != torch.float32 or not kf.is_contiguous():
+            kf = kf.float().contiguous()
+        key = (k.data_ptr(), k._version, tuple(k.shape), str(k.device), str(k.dtype))
+        if _pool_cache["key"] == key:
+            kbar = _pool_cache["kbar"]
+        else:
+            kbar = eng.pool(kf)                           # :304
+            _pool_cache["key"], _pool_cache["kbar"] = key, kbar
+        u = None
+        if eng.has_memory and self.sticky_memories:
+            # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
+            u = torch.rand(self.nb_samples, dtype=torch.float64)
+            torch.rand(self.nb_samples, dtype=torch.float64)          # the in-bin draw of :206
+            u = u.to(k.device, non_blocking=True).unsqueeze(0)
+        qf = q.detach()
+        if qf.dtype != torch.float32 or not qf.is_contiguous():
+            qf = qf.float().contiguous()
+        ctx = eng.step(kbar, qf, [self._proj(k.device)], u)           # [1, Q, dm]
+        self.count += 1
+        return ctx.to(q.dtype).reshape(1, qlen, -1)
+
+
+class LongTermAttentionVC(LongTermAttention):
+    """VideoChat2 variant: frames are 14x14 UMT-L patches of width 1024 (reference
+    infty-VideoChat2/models/blip2/long_term_attention_gibbs.py:291,304)."""
+    tokens_per_frame = 14 * 14
+    encoder_width = 1024

@@ -1,0 +1,105 @@
+"""Multi-GPU sharding logic on CPU: world_size 2 over gloo, with an oracle-backed stand-in for the
+HIP engine (the product engine has no CPU path; the collective and the bookkeeping are what is
+under test here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from infinite_video_amd import synth
+from infinite_video_amd.video_memory import (consolidate_video, pack_local_memory, shard_range, unpack_memory)
+from oracle.ltm_oracle import ClosedFormOracle
+
+N, H, DH, D, P, T, Q, L, C = 64, 12, 64, 768, 32, 8, 32, 2, 6
+DM = H * DH
+
+
+class OracleEngine:
+    """Same surface as infinite_video_amd.engine.LTMEngine (consolidate / export_state), CPU oracle inside."""
+
+    def __init__(self):
+        self.L, self.N, self.d, self.dm = L, N, D, DM
+        self.ws = [synth.layer_projections(l, D, DM) for l in range(L)]
+        self.layers = [ClosedFormOracle(N, H, DH, .75, True, *self.ws[l], tokens_per_frame=P) for l in range(L)]
+
+    def consolidate(self, k, q, projs, u, new_doc=True):
+        out = np.zeros((k.shape[0], L, Q, DM), np.float32)
+        for c in range(k.shape[0]):
+            for l in range(L):
+                out[c, l] = self.layers[l].step(k[c].numpy(), q[l].numpy(), new_doc=(new_doc and c == 0), u=u[c, l].numpy())
+        return torch.from_numpy(out)
+
+    def export_state(self, l):
+        o = self.layers[l]
+        return torch.from_numpy(o.B_past), torch.from_numpy(o.sticky_p_raw(o.S_prev).astype(np.float32))
+
+
+def _inputs():
+    k = torch.from_numpy(np.stack([synth.frame_tokens(c, T, P, D) for c in range(C)]))
+    q = torch.from_numpy(np.stack([synth.layer_query(l, Q, DM) for l in range(L)]))
+    u = torch.from_numpy(synth.gibbs_uniforms(C, L))
+    return k, q, u
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_pack_unpack_roundtrip_single_process():
+    eng = OracleEngine()
+    k, q, u = _inputs()
+    ctx, mem = consolidate_video(eng, k[:3], q, None, u[:3])
+    assert mem.B.shape == (1, L, N, D) and mem.bin_mass.shape == (1, L, 127) and mem.ctx_sum.shape == (1, L, Q, DM)
+    assert float(mem.count[0]) == 3.0
+    torch.testing.assert_close(mem.mean_embedding(), ctx.mean(0))
+    torch.testing.assert_close(mem.B[0, 1], eng.export_state(1)[0])
+    with pytest.raises(ValueError):
+        unpack_memory(pack_local_memory(eng, ctx)[:-1], 1, L, N, D, Q, DM)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, q, u = _inputs()
+        a, b = shard_range(C, world, rank)
+        ctx, mem = consolidate_video(OracleEngine(), k[a:b], q, None, u[a:b])
+        ret[rank] = (ctx.numpy(), mem.B.numpy(), mem.bin_mass.numpy(), mem.ctx_sum.numpy(), mem.count.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process_subvideos():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    k, q, u = _inputs()
+    for rank in range(2):
+        a, b = shard_range(C, 2, rank)
+        ref = OracleEngine()
+        ctx_ref = ref.consolidate(k[a:b], q, None, u[a:b])        # rank's block == its own document
+        ctx, B, mass, ctx_sum, count = ret[rank]
+        np.testing.assert_array_equal(ctx, ctx_ref.numpy())
+        # every rank holds every rank's memory after the all-gather
+        for other in range(2):
+            B0, m0, s0, c0 = ret[other][1], ret[other][2], ret[other][3], ret[other][4]
+            np.testing.assert_array_equal(B, B0); np.testing.assert_array_equal(mass, m0)
+            np.testing.assert_array_equal(ctx_sum, s0); np.testing.assert_array_equal(count, c0)
+        np.testing.assert_array_equal(B[rank, 0], ref.export_state(0)[0].numpy())
+        np.testing.assert_allclose(ctx_sum[rank], ctx_ref.sum(0).numpy(), rtol=1e-6, atol=1e-6)
+    assert list(ret[0][4]) == [3.0, 3.0]
