@@ -77,7 +77,10 @@ def test_hook_call_and_merge_rules():
     a_long = hook.long_term(k, q, object(), 0, True)
     g = load_golden(case)
     np.testing.assert_allclose(a_long[0].cpu().numpy(), g["c0_l0_ctx"], rtol=0, atol=CTX_TOL)
-    assert hook.long_term_attention.length == k.shape[1] and not a_long.requires_grad
+    # the hook sets length = target_len = p (Qformer.py:218-219); forward then resets length to the
+    # frame count (reference :292)
+    assert hook.long_term_attention.target_len == k.shape[1] and hook.long_term_attention.length == case.chunk_T[0]
+    assert not a_long.requires_grad
     merged = hook.merge(short, a_long, object())
     torch.testing.assert_close(merged, .75 * short + .25 * a_long)
     # alpha == 1.0: the reference never calls the op (Qformer.py:220-223)
