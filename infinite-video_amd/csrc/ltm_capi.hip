@@ -127,15 +127,23 @@ struct infv_ltm_s {
     int pc = 0;                        // which bin_part holds the latest partials
     DeviceBuf probs, probs_override, bins, idx, scores;
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
-    DeviceBuf kbar_ws, R_ws[2], P_ws[2];   // workspaces; R/P double-buffered (role U lags the projection by a batch edge)
-    int wb = 0;                        // which R/P workspace the last projection filled
+    // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
+    // stream while the chain of sub-batch b-1 runs on the caller's stream
+    DeviceBuf kbar_ws, kbar_side, R_ws[2], P_ws[2], Snew_ws[2];
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_p[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
-    DeviceBuf Sp[2], alpha[3], asum[3], tabring[2], cqbuf, Snew_ws;
+    DeviceBuf Sp[2], alpha[3], asum[3], tabring[2], cqbuf;
     int sc = 0;
     int n_bins = 128;
     Profiler prof;
-    ~infv_ltm_s() { for (auto& kv : plans) delete kv.second; }
+    ~infv_ltm_s() {
+        for (auto& kv : plans) delete kv.second;
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        for (int i = 0; i < 2; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); if (ev_c[i]) (void)hipEventDestroy(ev_c[i]); }
+    }
 };
 
 namespace {
@@ -249,28 +257,26 @@ int check_q(infv_ltm_handle h, int Q) {
     return INFV_OK;
 }
 
-// project the new rows of `n_chunks` pooled chunks into the workspaces
+// project the new rows of `n_chunks` pooled chunks into workspace set `set`
 int project_chunks(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T,
-                   const ProjPtrs& pp, int* splitk, long* split_stride, hipStream_t stream) {
+                   const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad = 0) {
     const Operator& op = inf ? plan.inf : plan.first;
     const long M = (long)n_chunks * op.rows;
     const long n_cols = (long)h->L * 2 * h->dm;
     const int sk = project_splitk((int)M, h->d);
-    h->wb ^= 1;
-    DeviceBuf& Rw = h->R_ws[h->wb];
-    DeviceBuf& Pw = h->P_ws[h->wb];
-    // growing a workspace frees it: nothing queued may still read it
-    if ((size_t)(M ? M : 1) * h->d * sizeof(float) > Rw.bytes || (size_t)(M ? M : 1) * n_cols * sk * sizeof(float) > Pw.bytes)
-        HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(Rw.reserve((size_t)(M ? M : 1) * h->d * sizeof(float)));
-    HIP_TRY(Pw.reserve((size_t)(M ? M : 1) * n_cols * sk * sizeof(float)));
+    DeviceBuf& Rw = h->R_ws[set];
+    DeviceBuf& Pw = h->P_ws[set];
+    const size_t needR = (size_t)(M ? M : 1) * h->d * sizeof(float), needP = (size_t)(M ? M : 1) * n_cols * sk * sizeof(float);
+    if (needR > Rw.bytes || needP > Pw.bytes) HIP_TRY(hipDeviceSynchronize());   // growing frees: nothing may still read it
+    HIP_TRY(Rw.reserve(needR));
+    HIP_TRY(Pw.reserve(needP));
     {
     Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
     HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), Rw.as<float>(), stream));
     }
     {
     Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-    HIP_TRY(launch_project(n_chunks, h->d, h->dm, h->L, op.view(), pp, Rw.as<float>(), Pw.as<float>(), stream));
+    HIP_TRY(launch_project(n_chunks, h->d, h->dm, h->L, op.view(), pp, Rw.as<float>(), Pw.as<float>(), stream, gemm_pad));
     }
     *splitk = sk;
     *split_stride = M * n_cols;
@@ -404,8 +410,8 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const ProjPtrs pp = make_proj(proj, h->L);
     int sk = 1; long ss = 0;
-    if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, &sk, &ss, stream)) return rc;
-    return chain_step(h, *plan, h->R_ws[h->wb].as<float>(), h->P_ws[h->wb].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
+    if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, 0, &sk, &ss, stream)) return rc;
+    return chain_step(h, *plan, h->R_ws[0].as<float>(), h->P_ws[0].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
 }
 
 int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
@@ -540,17 +546,30 @@ struct FastPipe {
     }
 };
 
-// batched new-row scores of `n_chunks` projected chunks (current P workspace) into Snew_ws
+// batched new-row scores of `n_chunks` projected chunks of workspace set `set`
 int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const float* q, int Q,
-                 const ProjPtrs& pp, int sk, long ss, bool want_cq, hipStream_t stream) {
+                 const ProjPtrs& pp, int set, int sk, long ss, bool want_cq, hipStream_t stream) {
     const long n_cols = (long)h->L * 2 * h->dm;
     const size_t need = (size_t)n_chunks * h->L * h->H * Q * (op.rows ? op.rows : 1) * sizeof(float);
-    if (need > h->Snew_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(h->Snew_ws.reserve(need));
+    if (need > h->Snew_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(h->Snew_ws[set].reserve(need));
     Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
-    HIP_TRY(launch_new_scores(q, Q, h->H, h->L, n_chunks, op.rows, h->P_ws[h->wb].as<float>(), (long)op.rows * n_cols, n_cols,
-                              2L * h->dm, sk, ss, pp, h->Snew_ws.as<float>(), want_cq ? h->cqbuf.as<float>() : nullptr,
+    HIP_TRY(launch_new_scores(q, Q, h->H, h->L, n_chunks, op.rows, h->P_ws[set].as<float>(), (long)op.rows * n_cols, n_cols,
+                              2L * h->dm, sk, ss, pp, h->Snew_ws[set].as<float>(), want_cq ? h->cqbuf.as<float>() : nullptr,
                               stream));
+    return INFV_OK;
+}
+
+int ensure_side_stream(infv_ltm_handle h) {
+    if (h->side) return INFV_OK;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
+    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));   // the chain must win arbitration
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_c[i], hipEventDisableTiming));
+    }
     return INFV_OK;
 }
 
@@ -582,18 +601,22 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         return INFV_OK;
     }
     FastPipe pipe{h, *plan, Q, pp, stream};
+    if (int rc = ensure_side_stream(h)) return rc;
+    // The side-stream kernels cap their own occupancy (amdgpu_waves_per_eu) so a chain workgroup always
+    // finds wave slots and LDS; extra LDS padding is an experiment knob only.
+    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 0; }();
+    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
+    hipStream_t side = h->side;
     int c = 0;
-    bool have_cq = false;
-    if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator
-        if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
+    if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
+        if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
         if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, &sk, &ss, stream)) return rc;
-        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, sk, ss, true, stream)) return rc;
-        have_cq = true;
-        const StepS st{&plan->first, false, h->Snew_ws.as<float>(), nullptr, h->R_ws[h->wb].as<float>(),
-                       h->P_ws[h->wb].as<float>(), sk, ss, ctx};
+        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, 1, &sk, &ss, stream)) return rc;
+        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, 1, sk, ss, true, stream)) return rc;
+        const StepS st{&plan->first, false, h->Snew_ws[1].as<float>(), nullptr, h->R_ws[1].as<float>(),
+                       h->P_ws[1].as<float>(), sk, ss, ctx};
         if (int rc = pipe.launch(&st)) return rc;
         c = 1;
     } else {
@@ -602,30 +625,54 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         HIP_TRY(launch_new_scores(q, Q, h->H, h->L, 1, h->N, h->KV[h->cur].as<float>(), 0, 2L * h->dm,
                                   (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
                                   stream));
-        have_cq = true;
     }
-    while (c < n_chunks) {
-        const int nb = (n_chunks - c < h->maxC) ? n_chunks - c : h->maxC;
-        if ((size_t)nb * T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(h->kbar_ws.reserve((size_t)nb * T * h->d * sizeof(float)));
+    // ---- sub-batches: the chunk-parallel stage of batch b+1 (side stream) overlaps the chain of batch b ----
+    const int first_c = c;
+    const int n_batches = (n_chunks - first_c + h->maxC - 1) / h->maxC;
+    const size_t rows = plan->inf.rows;
+    std::vector<int> sks(n_batches > 0 ? n_batches : 1, 1);
+    std::vector<long> sss(n_batches > 0 ? n_batches : 1, 0);
+    auto batch_range = [&](int b, int* c0, int* nb) {
+        *c0 = first_c + b * h->maxC;
+        *nb = (n_chunks - *c0 < h->maxC) ? n_chunks - *c0 : h->maxC;
+    };
+    auto stage_parallel = [&](int b) -> int {                  // pool -> rows -> project -> scores of batch b, on `side`
+        int c0, nb; batch_range(b, &c0, &nb);
+        const int set = b & 1;
+        if ((size_t)nb * T * h->d * sizeof(float) > h->kbar_side.bytes) HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(h->kbar_side.reserve((size_t)nb * T * h->d * sizeof(float)));
         {
-            Timed t_(h->prof, INFV_KERNEL_POOL, stream);
-            HIP_TRY(launch_pool(k + c * chunk_k, h->kbar_ws.as<float>(), (int64_t)nb * T, h->P, h->d, stream));
+            Timed t_(h->prof, INFV_KERNEL_POOL, side);
+            HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side.as<float>(), (int64_t)nb * T, h->P, h->d, side, kPoolPad));
         }
-        int sk = 1; long ss = 0;
-        if (int rc = project_chunks(h, *plan, true, h->kbar_ws.as<float>(), nb, T, pp, &sk, &ss, stream)) return rc;
-        if (int rc = batch_scores(h, plan->inf, nb, q, Q, pp, sk, ss, !have_cq, stream)) return rc;
-        have_cq = true;
-        const size_t rows = plan->inf.rows;
+        if (int rc = project_chunks(h, *plan, true, h->kbar_side.as<float>(), nb, T, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
+        if (int rc = batch_scores(h, plan->inf, nb, q, Q, pp, set, sks[b], sss[b], false, side)) return rc;
+        HIP_TRY(hipEventRecord(h->ev_p[set], side));
+        return INFV_OK;
+    };
+    if (n_batches > 0) {
+        HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and (first chunk) set 1 are ordered before
+        HIP_TRY(hipStreamWaitEvent(side, h->ev_in, 0));
+        if (int rc = stage_parallel(0)) return rc;
+    }
+    for (int b = 0; b < n_batches; ++b) {
+        int c0, nb; batch_range(b, &c0, &nb);
+        const int set = b & 1;
+        HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
         for (int i = 0; i < nb; ++i) {
-            const StepS st{&plan->inf, true, h->Snew_ws.as<float>() + (size_t)i * h->L * h->H * Q * rows,
-                           u ? u + (size_t)(c + i) * chunk_u : nullptr,
-                           h->R_ws[h->wb].as<float>() + (size_t)i * rows * h->d,
-                           h->P_ws[h->wb].as<float>() + (size_t)i * rows * h->L * 2 * h->dm, sk, ss,
-                           ctx + (size_t)(c + i) * chunk_ctx};
+            const StepS st{&plan->inf, true, h->Snew_ws[set].as<float>() + (size_t)i * h->L * h->H * Q * rows,
+                           u ? u + (size_t)(c0 + i) * chunk_u : nullptr,
+                           h->R_ws[set].as<float>() + (size_t)i * rows * h->d,
+                           h->P_ws[set].as<float>() + (size_t)i * rows * h->L * 2 * h->dm, sks[b], sss[b],
+                           ctx + (size_t)(c0 + i) * chunk_ctx};
             if (int rc = pipe.launch(&st)) return rc;
+            if (i == 0 && b + 1 < n_batches) {
+                // the launch above ran role U of the previous batch's last chunk: set^1 is free again
+                HIP_TRY(hipEventRecord(h->ev_c[set ^ 1], stream));
+                HIP_TRY(hipStreamWaitEvent(side, h->ev_c[set ^ 1], 0));
+                if (int rc = stage_parallel(b + 1)) return rc;
+            }
         }
-        c += nb;
     }
     // drain: U(last) + C(last-1), then C(last); then bring the K' half of the projected memory up to date
     if (int rc = pipe.launch(nullptr)) return rc;

@@ -387,14 +387,14 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         const int h = b % H, qt = (b / H) % QT, l = b / (H * QT);
         const int sstride = N + 2;
         float* Asm = lds;                                              // [16][N+2] alpha
-        float* Vsm = lds + ((kQTile * sstride + 3) & ~3);              // [N][80]
-        float* red = Vsm + kMaxN * kVStride;                           // [8 waves][64 lanes][4]
+        float* Vsm = lds + ((kQTile * sstride + 3) & ~3);              // [kVRows][80]
+        float* red = Vsm + kVRows * kVStride;                          // [8 waves][64 lanes][4]
         const long tile = (((long)l * H + h) * Q + qt * kQTile);
         const int valid = min(kQTile, Q - qt * kQTile);
         const float* Vhead = rc.KV + (long)l * N * 2 * dm + dm + h * kHeadSize;
         const bool stamp_me = (b == 0 && tid == 0);
         STAMP(16);
-        // prologue: alpha tile and the whole V' head slice together
+        // prologue: alpha tile and the first kVRows rows of the V' head slice together
         const int n4 = N / 4;
         floatx4 al[2];
 #pragma unroll
@@ -404,43 +404,51 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
             al[i] = (ar < valid) ? *reinterpret_cast<const floatx4*>(rc.alpha + (tile + ar) * N + ac4 * 4)
                                  : floatx4{0.f, 0.f, 0.f, 0.f};
         }
-        floatx4 vreg[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + i * kNT;
-            const int r = e >> 4, c4 = e & 15;
-            vreg[i] = (r < N) ? *reinterpret_cast<const floatx4*>(Vhead + (long)r * 2 * dm + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * kNT;
-            const int ar = e / n4, ac4 = e - ar * n4;
-            if (ar < kQTile) {
-                float* dst = &Asm[ar * sstride + ac4 * 4];
-                dst[0] = al[i].x; dst[1] = al[i].y; dst[2] = al[i].z; dst[3] = al[i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + i * kNT;
-            const int r = e >> 4, c4 = e & 15;
-            if (r < N) *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = vreg[i];
-        }
-        __syncthreads();
-        STAMP(17);
         const int c = lane & 15, g = lane >> 4;
-        const int ct = wave & 3, ks = wave >> 2;                       // column tile, box half
+        const int ct = wave & 3, ks = wave >> 2;                       // column tile, half of the staged rows
         floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const int per = N / 2;                                         // boxes of this wave's half (multiple of 8)
-        const int kb = ks * per;
+        for (int base = 0; base < N; base += kVRows) {
+            const int rows = min(kVRows, N - base);
+            floatx4 vreg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + i * kNT;
+                const int r = e >> 4, c4 = e & 15;
+                vreg[i] = (r < rows) ? *reinterpret_cast<const floatx4*>(Vhead + (long)(base + r) * 2 * dm + c4 * 4)
+                                     : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (base == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = tid + i * kNT;
+                    const int ar = e / n4, ac4 = e - ar * n4;
+                    if (ar < kQTile) {
+                        float* dst = &Asm[ar * sstride + ac4 * 4];
+                        dst[0] = al[i].x; dst[1] = al[i].y; dst[2] = al[i].z; dst[3] = al[i].w;
+                    }
+                }
+            } else {
+                __syncthreads();                                       // previous pass's reads of Vsm are done
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + i * kNT;
+                const int r = e >> 4, c4 = e & 15;
+                if (r < rows) *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = vreg[i];
+            }
+            __syncthreads();
+            if (base == 0) STAMP(17);
+            const int per = rows / 2;                                  // boxes of this wave's half (multiple of 8)
+            const int kb = ks * per;
 #pragma unroll 4
-        for (int t = 0; t < per / 4; t += 2) {
-            const float a0 = Asm[c * sstride + kb + 4 * t + g];
-            const float b0 = Vsm[(kb + 4 * t + g) * kVStride + 16 * ct + c];
-            const float a1 = Asm[c * sstride + kb + 4 * (t + 1) + g];
-            const float b1 = Vsm[(kb + 4 * (t + 1) + g) * kVStride + 16 * ct + c];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            for (int t = 0; t < per / 4; t += 2) {
+                const float a0 = Asm[c * sstride + base + kb + 4 * t + g];
+                const float b0 = Vsm[(kb + 4 * t + g) * kVStride + 16 * ct + c];
+                const float a1 = Asm[c * sstride + base + kb + 4 * (t + 1) + g];
+                const float b1 = Vsm[(kb + 4 * (t + 1) + g) * kVStride + 16 * ct + c];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            }
         }
         const floatx4 accw = acc0 + acc1;
         *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
 
 size_t chain_lds_bytes(int N, int S, int rows, int tabw) {
     const size_t roleS = (size_t)chain_smem(N, S, rows, tabw).total;
-    const size_t roleC = (size_t)((kQTile * (N + 2) + 3) & ~3) + kMaxN * kVStride + 8 * 64 * 4;
+    const size_t roleC = (size_t)((kQTile * (N + 2) + 3) & ~3) + kVRows * kVStride + 8 * 64 * 4;
     return (roleS > roleC ? roleS : roleC) * sizeof(float);
 }
 

@@ -38,7 +38,7 @@ struct ProjPtrs {
 };
 
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------
-hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream);
+hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad = 0);
 
 // R[c][r][:] = val * sum of the frames of row r of chunk c;  Pnew[sk][c][r][l][kv][dm] = split-K
 // partials of R . W[l][kv]^T  (sk = project_splitk(n_chunks*rows, d) slabs of n_chunks*rows*L*2*dm floats).
@@ -46,7 +46,7 @@ int project_splitk(int M, int K);
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream);
 hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
-                          const float* R, float* Pnew, hipStream_t stream);
+                          const float* R, float* Pnew, hipStream_t stream, int lds_pad = 0);
 
 // KV[l][n][0][:] = B[l][n] . Wk[l]^T, KV[l][n][1][:] = B[l][n] . Wv[l]^T (no bias).
 hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,

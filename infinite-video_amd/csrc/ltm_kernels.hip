@@ -24,8 +24,10 @@ namespace infv {
 //    1 KiB contiguous; P loads per lane are independent, so the whole 32 KiB of a unit is in
 //    flight at once.  This is the only HBM-heavy stage of the path (25.2 MB per chunk).
 // ======================================================================================
+// waves_per_eu(1,4): at most half of a SIMD's 8 wave slots, so that the latency-critical chain kernel
+// of the other stream always finds room next to it (16 waves x 32 KiB in flight per CU still saturate HBM).
 template <int UNROLL>
-__global__ __launch_bounds__(256) void pool_frames_kernel(const float* __restrict__ k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void pool_frames_kernel(const float* __restrict__ k,
                                                           float* __restrict__ kbar,
                                                           long n_units, int P, int d4, int slices) {
     const int lane = threadIdx.x & 63;
@@ -50,13 +52,15 @@ __global__ __launch_bounds__(256) void pool_frames_kernel(const float* __restric
     reinterpret_cast<floatx4*>(kbar)[frame * d4 + c4] = acc;
 }
 
-hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream) {
+// `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
+// latency-critical kernel on another stream always finds wave slots and LDS (see consolidate()).
+hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad) {
     const int d4 = d / 4;
     const int slices = (d4 + 63) / 64;
     const long n_units = (long)n_frames * slices;
     const long blocks = (n_units + 3) / 4;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(pool_frames_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, k, kbar,
+    hipLaunchKernelGGL(pool_frames_kernel<16>, dim3((unsigned)blocks), dim3(256), lds_pad, stream, k, kbar,
                        n_units, P, d4, slices);
     return hipGetLastError();
 }
@@ -90,8 +94,9 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 constexpr int kBK = 32;
 constexpr int kLdsStride = kBK + 4;   // +1 access width (16 B) against ds_read_b128 conflicts
 
+// waves_per_eu(1,2): two workgroups (72 KB of LDS) per CU at most -- see pool_frames_kernel.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
                                                       ProjPtrs proj, int layer_base, int dm,
                                                       float* __restrict__ C, int ldc, long split_stride,
                                                       int k_per_split) {
@@ -197,16 +202,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 
 static hipError_t launch_gemm(const float* A, int M, int K, const ProjPtrs& proj, int layer_base, int dm,
                               int n_cols, float* C, int ldc, int splitk, long split_stride,
-                              hipStream_t stream) {
+                              hipStream_t stream, int lds_pad = 0) {
     if (M <= 0) return hipSuccess;
     const int k_per_split = K / splitk;
     if (M >= 1024) {
         dim3 grid((M + 127) / 128, n_cols / 128, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, proj,
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, proj,
                            layer_base, dm, C, ldc, split_stride, k_per_split);
     } else {
         dim3 grid((M + 63) / 64, n_cols / 64, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, proj, layer_base,
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), lds_pad, stream, A, M, K, proj, layer_base,
                            dm, C, ldc, split_stride, k_per_split);
     }
     return hipGetLastError();
@@ -228,12 +233,12 @@ hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const Oper
 }
 
 hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
-                          const float* R, float* Pnew, hipStream_t stream) {
+                          const float* R, float* Pnew, hipStream_t stream, int lds_pad) {
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
     const int M = n_chunks * op.rows;
     const int n_cols = n_layers * 2 * dm;
     const int sk = project_splitk(M, d);
-    return launch_gemm(R, M, d, proj, 0, dm, n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream);
+    return launch_gemm(R, M, d, proj, 0, dm, n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream, lds_pad);
 }
 
 // ======================================================================================
