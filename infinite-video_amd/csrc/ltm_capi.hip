@@ -135,6 +135,7 @@ struct infv_ltm_s {
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
     DeviceBuf Sp[2], alpha[3], asum[3], tabring[2], cqbuf;
+    DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][128] u64, ring of 3 (read / accumulate / being cleared)
     int sc = 0;
     int n_bins = 128;
     Profiler prof;
@@ -320,7 +321,9 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         if (e == hipSuccess) e = h->tabring[i].reserve((size_t)h->L * h->N * 16 * sizeof(int32_t));
     }
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        e = h->alpha[i].reserve(nsq * sizeof(float));
+        e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
+        if (e == hipSuccess) e = h->alpha[i].reserve(nsq * sizeof(float));
         if (e == hipSuccess) e = h->asum[i].reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     }
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
@@ -466,12 +469,16 @@ struct FastPipe {
             s.draw_mode = st->inf ? (h->cfg.sticky ? 1 : 2) : 0;
             if (s.draw_mode == 1) {
                 if (!st->u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
-                if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
+                if (counter == 0 && h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
             }
             alpha_slot = (int)(counter % 3);
             tab_slot = (int)(counter % 2);
-            s.part_prev = h->bin_part[h->pc].as<float>(); s.part_next = h->bin_part[h->pc ^ 1].as<float>();
-            s.parts = h->parts;
+            // sticky histogram: the first step of a call may inherit float partials from the per-call path;
+            // afterwards the totals live in the fixed-point ring (read slot k-1, accumulate k, clear k+1)
+            s.part_prev = h->bin_part[h->pc].as<float>(); s.parts = h->parts;
+            s.acc_prev = (counter > 0) ? h->mass_acc[(counter + 2) % 3].as<unsigned long long>() : nullptr;
+            s.acc_next = h->mass_acc[counter % 3].as<unsigned long long>();
+            s.acc_clear = h->mass_acc[(counter + 1) % 3].as<unsigned long long>();
             s.probs_override = h->probs_override.as<float>(); s.override_mask = h->override_mask;
             s.u = st->u; s.uniform_idx = plan.uniform_idx.as<int32_t>();
             s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
@@ -515,6 +522,7 @@ struct FastPipe {
                 (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[stamps x10ns] S:");
                 for (int i = 1; i <= 5; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
+                fprintf(stderr, " [draw: sync %lld probs %lld scan %lld search %lld tab %lld]", hb[12] - hb[1], hb[13] - hb[12], hb[14] - hb[13], hb[15] - hb[14], hb[2] - hb[15]);
                 fprintf(stderr, " | U: %lld %lld | C:", hb[9] - hb[8], hb[11] - hb[9]);
                 for (int i = 17; i <= 19; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
                 fprintf(stderr, " | clk %.0f MHz | ends rel S0: S %lld U %lld C %lld\n",
@@ -532,9 +540,8 @@ struct FastPipe {
         }
         if (st) {
             if (a.s.draw_mode == 1) h->override_mask = 0;
-            h->pc ^= 1; h->sc ^= 1;
+            h->sc ^= 1;
             h->has_memory = true;
-            h->parts = h->H * QS;
             h->lastQ = Q;
             h->last_fast = true;
             pu.valid = true; pu.op = st->op; pu.gather = st->inf;
@@ -602,10 +609,11 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     }
     FastPipe pipe{h, *plan, Q, pp, stream};
     if (int rc = ensure_side_stream(h)) return rc;
-    // The side-stream kernels cap their own occupancy (amdgpu_waves_per_eu) so a chain workgroup always
-    // finds wave slots and LDS; extra LDS padding is an experiment knob only.
-    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 0; }();
-    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
+    HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
+    // Padding LDS caps the side-stream kernels' occupancy: ONE 512-thread pool workgroup (88 KB) or ONE GEMM
+    // workgroup (36 + 90 KB) per CU, so a chain workgroup (<= 52 KB) always finds LDS and wave slots.
+    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
+    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 90 * 1024; }();   // 36 KB static + 90 KB: one per CU
     hipStream_t side = h->side;
     int c = 0;
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
@@ -677,6 +685,11 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     // drain: U(last) + C(last-1), then C(last); then bring the K' half of the projected memory up to date
     if (int rc = pipe.launch(nullptr)) return rc;
     if (int rc = pipe.launch(nullptr)) return rc;
+    if (pipe.counter > 0) {                                   // hand the sticky histogram back as one float partial row
+        HIP_TRY(launch_acc_to_part(h->mass_acc[(pipe.counter + 2) % 3].as<unsigned long long>(), h->L, 1,
+                                   h->bin_part[h->pc].as<float>(), stream));
+        h->parts = 1;
+    }
     return infv_ltm_reproject(h, proj, stream_);
 }
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void new_scores_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qrow = qt * kQTile + 4 * g + r;
-            if (qrow < Q && krow < rows) out[(long)qrow * rows + krow] = acc[r];
+            if (qrow < Q && krow < rows) __builtin_nontemporal_store(acc[r], &out[(long)qrow * rows + krow]);
         }
         if (cq != nullptr && ch == 0 && rt == 0) {
             const float* bk = proj.bk[l] + h * kHeadSize;
@@ -111,6 +111,7 @@ constexpr int kBoxesPerU = 4;
 constexpr int kMaxN = 256;               // boxes the fast path holds in LDS
 constexpr int kMaxTabw = 16;             // slots per box the dense table holds
 constexpr int kNIter = kMaxN / 64;       // boxes per lane in a wave-per-row sweep
+constexpr int kCRows = 64;               // V' rows staged per read-out pass of role C (keeps the launch's LDS small)
 
 struct ChainSmem {            // role S: offsets (in floats) into dynamic LDS, identical on host and device
     int cdf, sidx, gsum, misc, tab, box_val, box_row, w, bin_box, edge_box, edge_dx, Sprev, Ssm, Snew, Dsm, Msm, total;
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
     const int dm = H * kHeadSize;
     int b = blockIdx.x;
     if (a.debug_noop) return;                                          // dispatch-floor timing experiment
+    // latency-critical: win issue arbitration against the throughput kernels of the side stream that share the CU
+    __builtin_amdgcn_s_setprio(3);
 
     if (b < a.s.n_blocks) {
         // ================================================================== role S: wave w <-> query row w
@@ -196,8 +199,10 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         }
         DrawRegs<1> dr;
         if (rs.draw_mode == 1)
-            dr = draw_load<kNT, 1>(rs.part_prev + (long)l * rs.parts * kBins, rs.parts, rs.probs_override + l * kBins,
+            dr = draw_load<kNT, 1>(rs.part_prev + (long)l * rs.parts * kBins, rs.parts,
+                                   rs.acc_prev ? rs.acc_prev + l * kBins : nullptr, rs.probs_override + l * kBins,
                                    (rs.override_mask >> l) & 1u, rs.u + (long)l * a.S, a.S);
+        if (writer && tid < kBins) rs.acc_clear[l * kBins + tid] = 0ull;   // ring slot of the NEXT launch: idle now
         int uni = -1;
         if (rs.draw_mode == 2 && tid < a.S) uni = rs.uniform_idx[tid];
         // ---- park the prologue in LDS ----
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
                                 a.S, lds + m.cdf, sidx, reinterpret_cast<double*>(lds + m.gsum),
                                 writer ? rs.probs_out + l * kBins : nullptr,
                                 writer ? rs.bins_out + (long)l * a.S : nullptr,
-                                writer ? rs.idx_out + (long)l * a.S : nullptr);
+                                writer ? rs.idx_out + (long)l * a.S : nullptr, (b == 0) ? a.dbg : nullptr);
         if (rs.draw_mode != 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -284,8 +289,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         __syncthreads();
         STAMP(3);
         row_phase_wave(Ssm, sstride, N, valid, lds + m.w, rs.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
-                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum,
-                       rs.part_next + (((long)l * H + h) * QS + qs) * kBins, kRowsS);
+                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, rs.acc_next + l * kBins, kRowsS);
         STAMP(4);
         // alpha_k and its row sums for role C two launches later
         if (wave < valid) {
@@ -387,8 +391,8 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         const int h = b % H, qt = (b / H) % QT, l = b / (H * QT);
         const int sstride = N + 2;
         float* Asm = lds;                                              // [16][N+2] alpha
-        float* Vsm = lds + ((kQTile * sstride + 3) & ~3);              // [kVRows][80]
-        float* red = Vsm + kVRows * kVStride;                          // [8 waves][64 lanes][4]
+        float* Vsm = lds + ((kQTile * sstride + 3) & ~3);              // [kCRows][80]
+        float* red = Vsm + kCRows * kVStride;                          // [8 waves][64 lanes][4]
         const long tile = (((long)l * H + h) * Q + qt * kQTile);
         const int valid = min(kQTile, Q - qt * kQTile);
         const float* Vhead = rc.KV + (long)l * N * 2 * dm + dm + h * kHeadSize;
@@ -407,11 +411,11 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         const int c = lane & 15, g = lane >> 4;
         const int ct = wave & 3, ks = wave >> 2;                       // column tile, half of the staged rows
         floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int base = 0; base < N; base += kVRows) {
-            const int rows = min(kVRows, N - base);
-            floatx4 vreg[4];
+        for (int base = 0; base < N; base += kCRows) {
+            const int rows = min(kCRows, N - base);
+            floatx4 vreg[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 const int e = tid + i * kNT;
                 const int r = e >> 4, c4 = e & 15;
                 vreg[i] = (r < rows) ? *reinterpret_cast<const floatx4*>(Vhead + (long)(base + r) * 2 * dm + c4 * 4)
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
                 __syncthreads();                                       // previous pass's reads of Vsm are done
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 const int e = tid + i * kNT;
                 const int r = e >> 4, c4 = e & 15;
                 if (r < rows) *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = vreg[i];
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
 
 size_t chain_lds_bytes(int N, int S, int rows, int tabw) {
     const size_t roleS = (size_t)chain_smem(N, S, rows, tabw).total;
-    const size_t roleC = (size_t)((kQTile * (N + 2) + 3) & ~3) + kVRows * kVStride + 8 * 64 * 4;
+    const size_t roleC = (size_t)((kQTile * (N + 2) + 3) & ~3) + kCRows * kVStride + 8 * 64 * 4;
     return (roleS > roleC ? roleS : roleC) * sizeof(float);
 }
 
@@ -506,4 +510,15 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+}  // namespace infv
+
+namespace infv {
+__global__ void acc_to_part_kernel(const unsigned long long* __restrict__ acc, int parts_pitch, float* __restrict__ part) {
+    const int l = blockIdx.x, j = threadIdx.x;
+    if (j < kBins) part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)((double)acc[l * kBins + j] * (1.0 / kMassScale)) : 0.f;
+}
+hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream) {
+    hipLaunchKernelGGL(acc_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, acc, parts_pitch, part);
+    return hipGetLastError();
+}
 }  // namespace infv

@@ -13,6 +13,7 @@ constexpr int kVRows = 128;              // V' rows staged per read-out pass
 constexpr int kVStride = 80;             // LDS row pitch of the V' stage: == 16 mod 32 -> conflict-free b32 column reads
 constexpr int kDPitch = 132;             // LDS row pitch of the edge densities (129 used)
 constexpr int kMPitch = 128;             // LDS row pitch of the per-row bin masses
+constexpr double kMassScale = 1099511627776.0;   // 2^40: fixed-point scale of the sticky bin masses (integer atomics)
 
 // Sum over the NT threads of the workgroup (NT/64 waves); every thread gets the result.
 template <int NT>
@@ -95,8 +96,11 @@ struct DrawRegs {
 };
 
 // Phase 1: issue every global read of the draw (uniforms, partial masses) -- no LDS, no barrier.
+// `mass_acc` (fixed-point totals accumulated with integer atomics, exact and order-independent) replaces
+// the per-workgroup float partials when non-null.
 template <int NT, int SPT>
 __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int parts,
+                                          const unsigned long long* __restrict__ mass_acc,
                                           const float* __restrict__ probs_override, bool use_override,
                                           const double* __restrict__ u, int S) {
     constexpr int nb = kBins - 1;
@@ -111,6 +115,8 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
             r.ovr[0] = probs_override[tid];
             if (tid + 64 < nb) r.ovr[1] = probs_override[tid + 64];
         }
+    } else if (mass_acc != nullptr) {
+        if (tid < kBins - 1) r.acc = (double)mass_acc[tid] * (1.0 / kMassScale);           // group 0 holds the totals
     } else {
         constexpr int G = NT / kBins;                   // thread groups that split the partial rows
         const int j = tid & (kBins - 1), grp = tid / kBins;
@@ -125,7 +131,8 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
 template <int NT, int SPT>
 __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, const int32_t* bin_box, int S,
                                    float* cdf, int32_t* sidx, double* gsum /*LDS[(NT/128)*128]*/, float* probs_out,
-                                   int32_t* bins_out, int32_t* idx_out) {
+                                   int32_t* bins_out, int32_t* idx_out, long long* dbg = nullptr) {
+#define DSTAMP(i) do { if (dbg != nullptr && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     constexpr int nb = kBins - 1;
     constexpr int G = NT / kBins;
     const int tid = threadIdx.x;
@@ -133,6 +140,7 @@ __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, co
         gsum[tid] = r.acc;                               // [grp][bin]
         __syncthreads();
     }
+    DSTAMP(12);
     if (tid < 64) {
         const int j0 = tid, j1 = tid + 64;
         float p0, p1;
@@ -151,18 +159,24 @@ __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, co
         }
         if (j1 >= nb) p1 = 0.f;
         if (probs_out != nullptr) { probs_out[j0] = p0; if (j1 < nb) probs_out[j1] = p1; }
-        // sequential fp32 running sum in bin order (torch.multinomial, CPU): every lane follows the same
-        // dependent chain (bin i's probability is broadcast from its owner lane with v_readlane) and
-        // drops each partial sum into LDS; nothing else sits on the chain.
-        float run = 0.f;
+        DSTAMP(13);
+        // Sequential fp32 running sum in bin order (torch.multinomial, CPU), as a systolic scan over the
+        // lanes: c <- wave_shr:1(c) + p.  After t steps lane i holds the left-to-right sum of its last
+        // min(t,i)+1 terms, so after 63 steps every lane holds ((p_0 + p_1) + ...) + p_i with exactly the
+        // CPU's association and rounding -- one dependent VALU instruction per bin, no LDS.
+        float c0 = p0;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) { run = run + readlane_f32(p0, i); cdf[i] = run; }
+        for (int t = 0; t < 63; ++t) c0 = dpp_f32<0x138>(c0) + p0;          // bins 0..63
+        const float carry = readlane_f32(c0, 63);
+        const float q1 = (j0 == 0) ? carry + p1 : p1;                       // bin 64 continues the chain
+        float c1 = q1;
 #pragma unroll
-        for (int i = 0; i < 63; ++i) { run = run + readlane_f32(p1, i); cdf[64 + i] = run; }
-        const float c0 = cdf[j0], c1 = (j1 < nb) ? cdf[j1] : 0.f;   // same wave: LDS ops complete in order
+        for (int t = 0; t < 62; ++t) c1 = dpp_f32<0x138>(c1) + q1;          // bins 64..126 (lane 63: padding)
+        const float run = readlane_f32(c1, 62);
         cdf[j0] = c0 / run;
         if (j1 < nb) cdf[j1] = (j1 == nb - 1) ? 1.f : c1 / run;
         if (tid == 0) cdf[nb] = 2.f;                                 // pad: never below a uniform
+        DSTAMP(14);
     }
     __syncthreads();
     // lower bound of u in the non-decreasing cdf == number of entries below u (torch's binary search
@@ -189,6 +203,8 @@ __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, co
         }
     }
     __syncthreads();
+    DSTAMP(15);
+#undef DSTAMP
 }
 
 // --------------------------------------------------------------------------------------
@@ -250,44 +266,69 @@ __device__ inline void row_phase(float* Ssm, int sstride, int N, int valid_rows,
 // --------------------------------------------------------------------------------------
 __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_rows, const float* w,
                                       float w_out, const int32_t* edge_box, const float* edge_dx, float* Dsm,
-                                      float* Msm, float* asum, float* __restrict__ part_out, int rows_in_tile) {
+                                      float* Msm, float* asum, float* __restrict__ part_out,
+                                      unsigned long long* __restrict__ mass_acc, int rows_in_tile) {
+    constexpr int NI = 4;                              // N <= 256: at most 4 boxes per lane
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
     float* Srow = Ssm + row * sstride;
     float* Drow = Dsm + row * kDPitch;
+    float sv[NI];
     float m = -INFINITY;
-    for (int n = lane; n < N; n += 64) m = fmaxf(m, Srow[n]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        sv[i] = (n < N) ? Srow[n] : -INFINITY;
+        m = fmaxf(m, sv[i]);
+    }
     m = wave_max(m);
     const float md = fmaxf(m, 0.f);                    // edges outside every box score 0
-    // edge densities feed the Gibbs draw: accurate expf
-    for (int j = lane; j <= kBins; j += 64) {
-        const int eb = edge_box[j];
-        const float sc = (eb >= 0) ? Srow[eb] : 0.f;
-        Drow[j] = expf(sc - md);
+    // edge densities feed the Gibbs draw: accurate expf.  129 edges: lanes take j, j+64 and lane 0 edge 128.
+    {
+        const int eb0 = edge_box[lane], eb1 = edge_box[lane + 64];
+        const int eb2 = edge_box[kBins];
+        const float s0 = (eb0 >= 0) ? Srow[eb0] : 0.f, s1 = (eb1 >= 0) ? Srow[eb1] : 0.f;
+        const float s2 = (eb2 >= 0) ? Srow[eb2] : 0.f;
+        Drow[lane] = expf(s0 - md);
+        Drow[lane + 64] = expf(s1 - md);
+        const float d2 = expf(s2 - md);                // same value in every lane
+        if (lane == 0) Drow[kBins] = d2;
     }
     __syncthreads();                                   // raw-score reads done before alpha overwrites
     // softmax weights feed only the read-out (1e-3 budget): hardware exp2
+    float e[NI];
     float esum = 0.f;
-    for (int n = lane; n < N; n += 64) {
-        const float e = w[n] * __expf(Srow[n] - m);
-        Srow[n] = e;
-        esum += e;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        e[i] = (n < N) ? w[n] * __expf(sv[i] - m) : 0.f;
+        esum += e[i];
     }
     esum = wave_sum(esum);
     const float inv = 1.0f / (esum + w_out * __expf(-m));
-    for (int n = lane; n < N; n += 64) Srow[n] *= inv;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) Srow[n] = e[i] * inv;
+    }
     if (lane == 0) asum[row] = esum * inv;
-    float z = 0.f;
-    for (int j = lane; j < kBins; j += 64) z += (Drow[j] + Drow[j + 1]) * edge_dx[j];
-    const float inv_z = 1.0f / (wave_sum(z) * 0.5f);
-    for (int j = lane; j < kBins - 1; j += 64) {
-        const float dl = Drow[j + 1] * inv_z, dr = Drow[j + 2] * inv_z;
-        Msm[row * kMPitch + j] = (row < valid_rows) ? ((dl + dr) * edge_dx[j + 1]) * 0.5f : 0.f;
+    const float d0 = Drow[lane], d1 = Drow[lane + 1], d64 = Drow[lane + 64], d65 = Drow[lane + 65];
+    const float dx0 = edge_dx[lane], dx1 = edge_dx[lane + 64];
+    const float z = wave_sum((d0 + d1) * dx0 + (d64 + d65) * dx1) * 0.5f;
+    const float inv_z = 1.0f / z;
+    // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
+    {
+        const float d2 = Drow[lane + 2], d66 = (lane + 66 <= kBins) ? Drow[lane + 66] : 0.f;
+        const float dxa = edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? edge_dx[lane + 65] : 0.f;
+        const bool ok = row < valid_rows;
+        Msm[row * kMPitch + lane] = ok ? ((d1 * inv_z + d2 * inv_z) * dxa) * 0.5f : 0.f;
+        if (lane + 64 < kBins - 1) Msm[row * kMPitch + lane + 64] = ok ? ((d65 * inv_z + d66 * inv_z) * dxb) * 0.5f : 0.f;
     }
     __syncthreads();
     if (tid < kBins - 1) {
         float t = 0.f;
         for (int r = 0; r < rows_in_tile; ++r) t += Msm[r * kMPitch + tid];
-        part_out[tid] = t;
+        if (part_out != nullptr) part_out[tid] = t;
+        if (mass_acc != nullptr) atomicAdd(&mass_acc[tid], (unsigned long long)((double)t * kMassScale + 0.5));
     }
 }
 

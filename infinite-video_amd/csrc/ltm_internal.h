@@ -77,7 +77,9 @@ struct ChainRoleS {
     int n_blocks;                   // H * QS * L, or 0
     OperatorView op;
     int draw_mode;                  // 0: none (first chunk of a document), 1: sticky Gibbs draw, 2: uniform resample
-    const float* part_prev; float* part_next; int parts;
+    const float* part_prev; int parts;            // float partials of the previous step (per-call path hand-over) ...
+    const unsigned long long* acc_prev;           // ... or its fixed-point totals [L][128] (fast path steady state)
+    unsigned long long* acc_next; unsigned long long* acc_clear;   // this step's totals; the ring slot to zero for the next
     const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;     // [L][128], [L][S], [L][S]  (diagnostics)
     int32_t* tab_out;               // [L][N*tabw] resolved source box of every (box, slot) for role U
@@ -115,6 +117,8 @@ hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_c
                              long chunk_stride, long row_stride, long layer_stride, int splitk, long split_stride,
                              const ProjPtrs& proj, float* Snew, float* cq, hipStream_t stream);
 
+// part[l][0][j] = acc[l][j] / 2^40 (fast path -> per-call path hand-over of the sticky histogram)
+hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream);
 // bin_mass[j] = sum over parts of bin_part[layer][p][j]
 hipError_t launch_sum_parts(const float* bin_part_layer, int parts, int pitch, float* bin_mass, hipStream_t stream);
 

@@ -24,14 +24,12 @@ namespace infv {
 //    1 KiB contiguous; P loads per lane are independent, so the whole 32 KiB of a unit is in
 //    flight at once.  This is the only HBM-heavy stage of the path (25.2 MB per chunk).
 // ======================================================================================
-// waves_per_eu(1,4): at most half of a SIMD's 8 wave slots, so that the latency-critical chain kernel
-// of the other stream always finds room next to it (16 waves x 32 KiB in flight per CU still saturate HBM).
-template <int UNROLL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void pool_frames_kernel(const float* __restrict__ k,
+template <int UNROLL, int NT>
+__global__ __launch_bounds__(NT) void pool_frames_kernel(const float* __restrict__ k,
                                                           float* __restrict__ kbar,
                                                           long n_units, int P, int d4, int slices) {
     const int lane = threadIdx.x & 63;
-    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (unit >= n_units) return;
     const long frame = unit / slices;
     const int c4 = (int)(unit - frame * slices) * 64 + lane;
@@ -49,7 +47,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     for (; p < P; ++p) acc += __builtin_nontemporal_load(src + (long)p * d4);
     const float fp = (float)P;
     acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does
-    reinterpret_cast<floatx4*>(kbar)[frame * d4 + c4] = acc;
+    // streaming store: leave no dirty lines in L2 (every kernel boundary of the concurrent chain writes L2 back)
+    __builtin_nontemporal_store(acc, reinterpret_cast<floatx4*>(kbar) + frame * d4 + c4);
 }
 
 // `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
@@ -58,10 +57,23 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
     const int d4 = d / 4;
     const int slices = (d4 + 63) / 64;
     const long n_units = (long)n_frames * slices;
-    const long blocks = (n_units + 3) / 4;
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(pool_frames_kernel<16>, dim3((unsigned)blocks), dim3(256), lds_pad, stream, k, kbar,
-                       n_units, P, d4, slices);
+    if (n_units == 0) return hipSuccess;
+    if (lds_pad > 0) {
+        // overlapped mode: 512-thread workgroups whose padding LDS lets only ONE of them live on a CU
+        // (8 waves x 32 KiB in flight still cover the HBM latency), so the chain kernel always finds room
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 512>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3((unsigned)((n_units + 7) / 8)), dim3(512), lds_pad, stream,
+                           k, kbar, n_units, P, d4, slices);
+    } else {
+        hipLaunchKernelGGL((pool_frames_kernel<16, 256>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
+                           n_units, P, d4, slices);
+    }
     return hipGetLastError();
 }
 
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
             acc.x = fmaf(val, v.x, acc.x); acc.y = fmaf(val, v.y, acc.y);
             acc.z = fmaf(val, v.z, acc.z); acc.w = fmaf(val, v.w, acc.w);
         }
-        dst[c4] = acc;
+        __builtin_nontemporal_store(acc, dst + c4);
     }
 }
 
@@ -94,12 +106,11 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 constexpr int kBK = 32;
 constexpr int kLdsStride = kBK + 4;   // +1 access width (16 B) against ds_read_b128 conflicts
 
-// waves_per_eu(1,2): two workgroups (72 KB of LDS) per CU at most -- see pool_frames_kernel.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
                                                       ProjPtrs proj, int layer_base, int dm,
                                                       float* __restrict__ C, int ldc, long split_stride,
-                                                      int k_per_split) {
+                                                      int k_per_split, int y_off) {
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave in each dim
     constexpr int AR = BM / 32, BR = BN / 32;          // rows staged per thread
     __shared__ float As[BM * kLdsStride];
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM, n0 = (blockIdx.y + y_off) * BN;
     const int kbeg = blockIdx.z * k_per_split;
     const int ntiles = k_per_split / kBK;
     C += (long)blockIdx.z * split_stride;
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 const int o = n0 + wn * (BN / 2) + j * 32 + li;
-                if (m < M) C[(long)m * ldc + o] = acc[i][j][r];
+                if (m < M) __builtin_nontemporal_store(acc[i][j][r], &C[(long)m * ldc + o]);
             }
 }
 
@@ -205,14 +216,37 @@ static hipError_t launch_gemm(const float* A, int M, int K, const ProjPtrs& proj
                               hipStream_t stream, int lds_pad = 0) {
     if (M <= 0) return hipSuccess;
     const int k_per_split = K / splitk;
+    static bool attr_set = false;
+    if (lds_pad > 0 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<128, 128>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<64, 64>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     if (M >= 1024) {
-        dim3 grid((M + 127) / 128, n_cols / 128, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, proj,
-                           layer_base, dm, C, ldc, split_stride, k_per_split);
+        const int gx = (M + 127) / 128, gy = n_cols / 128;
+        if (lds_pad > 0) {
+            // overlapped mode: one workgroup per CU (padding LDS) and never more workgroups than CUs in a
+            // launch, so no workgroup of this kernel ever waits for a slot: a kernel with pending workgroups
+            // was measured to stall the dispatch of the concurrent chain kernel for tens of microseconds.
+            int ny = 256 / gx;                                   // column tiles per launch
+            if (ny < 1) ny = 1;
+            for (int y0 = 0; y0 < gy; y0 += ny) {
+                dim3 grid(gx, (gy - y0 < ny) ? gy - y0 : ny, splitk);
+                hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, proj,
+                                   layer_base, dm, C, ldc, split_stride, k_per_split, y0);
+            }
+        } else {
+            dim3 grid(gx, gy, splitk);
+            hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, proj,
+                               layer_base, dm, C, ldc, split_stride, k_per_split, 0);
+        }
     } else {
         dim3 grid((M + 63) / 64, n_cols / 64, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), lds_pad, stream, A, M, K, proj, layer_base,
-                           dm, C, ldc, split_stride, k_per_split);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, proj, layer_base,
+                           dm, C, ldc, split_stride, k_per_split, 0);
     }
     return hipGetLastError();
 }
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin
     __shared__ int32_t sidx[1024];
     const int l = blockIdx.x;
     const bool ovr = (override_mask >> l) & 1u;
-    const DrawRegs<4> r = draw_load<256, 4>(bin_part + (long)l * parts * kBins, parts, probs_override + l * kBins,
+    const DrawRegs<4> r = draw_load<256, 4>(bin_part + (long)l * parts * kBins, parts, nullptr, probs_override + l * kBins,
                                             ovr, u + (long)l * S, S);
     draw_finish<256, 4>(r, ovr, sticky.bin_box, S, cdf, sidx, gsum, probs_out + l * kBins, bins_out + (long)l * S,
                         idx_out + (long)l * S);
