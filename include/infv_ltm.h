@@ -173,8 +173,9 @@ typedef enum {
     INFV_KERNEL_UPDATE = 4,   /* memory update                            */
     INFV_KERNEL_ATTEND = 5,   /* scores / softmax / read-out              */
     INFV_KERNEL_SCORES = 6,   /* batched new-row scores (fast path)       */
-    INFV_KERNEL_CHAIN = 7,    /* fused per-chunk chain step (fast path)   */
-    INFV_KERNEL_COUNT = 8
+    INFV_KERNEL_CHAIN = 7,    /* per-chunk chain step: draw, score recurrence, softmax weights (fast path) */
+    INFV_KERNEL_UC = 8,       /* state update + read-out of a sub-batch (fast path) */
+    INFV_KERNEL_COUNT = 9
 } infv_kernel;
 int infv_ltm_profile_enable(infv_ltm_handle h, int32_t on);
 int infv_ltm_profile_read(infv_ltm_handle h, int32_t kernel, int64_t* launches, double* total_ms);

@@ -80,7 +80,7 @@ _SIGNATURES = {
     "infv_ltm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
-KERNELS = ("pool", "rows", "project", "draw", "update", "attend", "scores", "chain")
+KERNELS = ("pool", "rows", "project", "draw", "update", "attend", "scores", "chain", "uc")
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None

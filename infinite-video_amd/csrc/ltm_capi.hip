@@ -129,12 +129,18 @@ struct infv_ltm_s {
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
-    DeviceBuf kbar_ws, kbar_side, R_ws[2], P_ws[2], Snew_ws[2];
+    DeviceBuf kbar_ws, kbar_side, R_ws[3], P_ws[3], Snew_ws[3];
     hipStream_t side = nullptr;
-    hipEvent_t ev_in = nullptr, ev_p[2] = {nullptr, nullptr}, ev_c[2] = {nullptr, nullptr};
+    hipStream_t chain = nullptr;        // CU-masked stream of the chain kernels (only with a CU split)
+    hipEvent_t ev_caller = nullptr, ev_done = nullptr;
+    hipEvent_t ev_in = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
-    DeviceBuf Sp[2], alpha[3], asum[3], tabring[2], cqbuf;
+    DeviceBuf Sp[2], cqbuf;
+    DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
+    int ring = 0;
+    hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
+    hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
     DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][128] u64, ring of 3 (read / accumulate / being cleared)
     int sc = 0;
     int n_bins = 128;
@@ -142,8 +148,13 @@ struct infv_ltm_s {
     ~infv_ltm_s() {
         for (auto& kv : plans) delete kv.second;
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (chain) { (void)hipStreamSynchronize(chain); (void)hipStreamDestroy(chain); }
+        if (ucs) { (void)hipStreamSynchronize(ucs); (void)hipStreamDestroy(ucs); }
+        for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
+        if (ev_caller) (void)hipEventDestroy(ev_caller);
+        if (ev_done) (void)hipEventDestroy(ev_done);
         if (ev_in) (void)hipEventDestroy(ev_in);
-        for (int i = 0; i < 2; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); if (ev_c[i]) (void)hipEventDestroy(ev_c[i]); }
+        for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
     }
 };
 
@@ -318,14 +329,12 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->bin_part[i].reserve((size_t)h->L * max_parts * h->n_bins * sizeof(float));
         if (e == hipSuccess) e = hipMemset(h->bin_part[i].p, 0, h->bin_part[i].bytes);
         if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
-        if (e == hipSuccess) e = h->tabring[i].reserve((size_t)h->L * h->N * 16 * sizeof(int32_t));
     }
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
-        if (e == hipSuccess) e = h->alpha[i].reserve(nsq * sizeof(float));
-        if (e == hipSuccess) e = h->asum[i].reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     }
+    h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
     if (e == hipSuccess) e = h->probs_override.reserve((size_t)h->L * h->n_bins * sizeof(float));
@@ -429,89 +438,57 @@ int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* 
 
 }  // extern "C"
 
-// ---- whole-video fast path: 3-stage pipeline over launches (S(k), U(k-1), C(k-2)) --------------
+// ---- whole-video fast path -----------------------------------------------------------------------
+// Per chunk ONE small launch of chain_kernel's role S (draw -> score recurrence -> alpha, sticky
+// histogram, gather table); per sub-batch ONE launch of uc_kernel (memory update + read-out of all its
+// chunks) on its own stream, overlapping role S of the next sub-batch.
 namespace {
 
-struct PendingU {                    // state update waiting for the next launch
-    bool valid = false;
-    const Operator* op = nullptr;
-    bool gather = false;
-    const float* R = nullptr; const float* Pn = nullptr; int sk = 1; long ss = 0;
-    int tab_slot = 0, alpha_slot = 0;
-    float* ctx = nullptr;
-};
-struct PendingC {                    // read-out waiting for the launch after its state update
-    bool valid = false;
-    int alpha_slot = 0;
-    float* ctx = nullptr;
-};
-struct StepS {                       // critical work of the chunk entering the pipeline
+struct StepS {                       // critical work of the chunk entering the chain
     const Operator* op; bool inf; const float* Snew; const double* u;
-    const float* R; const float* Pn; int sk; long ss; float* ctx;
 };
 
 struct FastPipe {
     infv_ltm_handle h; const Plan& plan; int Q; const ProjPtrs& pp; hipStream_t stream;
-    PendingU pu; PendingC pc;
-    long counter = 0;                // chunks that entered the pipeline in this call
+    long counter = 0;                // chunks that entered the chain in this call
 
-    int launch(const StepS* st) {
+    size_t alpha_slot() const { return (size_t)h->L * h->H * Q * h->N; }
+    size_t asum_slot() const { return (size_t)h->L * h->H * Q; }
+    size_t tab_slot() const { return (size_t)h->L * h->N * 16; }
+
+    int launch_s(const StepS& st) {
         ChainArgs a;
         memset(&a, 0, sizeof(a));
         const int QT = (Q + kQTile - 1) / kQTile, QS = chain_s_tiles(Q);
         a.N = h->N; a.H = h->H; a.Q = Q; a.QT = QT; a.QS = QS; a.L = h->L; a.S = h->S; a.d4 = h->d / 4; a.dm4 = h->dm / 4;
         a.st = plan.sticky();
-        int alpha_slot = 0, tab_slot = 0;
-        if (st) {
-            ChainRoleS& s = a.s;
-            s.n_blocks = h->H * QS * h->L;
-            s.op = st->op->view();
-            s.draw_mode = st->inf ? (h->cfg.sticky ? 1 : 2) : 0;
-            if (s.draw_mode == 1) {
-                if (!st->u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
-                if (counter == 0 && h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
-            }
-            alpha_slot = (int)(counter % 3);
-            tab_slot = (int)(counter % 2);
-            // sticky histogram: the first step of a call may inherit float partials from the per-call path;
-            // afterwards the totals live in the fixed-point ring (read slot k-1, accumulate k, clear k+1)
-            s.part_prev = h->bin_part[h->pc].as<float>(); s.parts = h->parts;
-            s.acc_prev = (counter > 0) ? h->mass_acc[(counter + 2) % 3].as<unsigned long long>() : nullptr;
-            s.acc_next = h->mass_acc[counter % 3].as<unsigned long long>();
-            s.acc_clear = h->mass_acc[(counter + 1) % 3].as<unsigned long long>();
-            s.probs_override = h->probs_override.as<float>(); s.override_mask = h->override_mask;
-            s.u = st->u; s.uniform_idx = plan.uniform_idx.as<int32_t>();
-            s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
-            s.tab_out = h->tabring[tab_slot].as<int32_t>();
-            s.Sp_prev = h->Sp[h->sc].as<float>(); s.Sp_next = h->Sp[h->sc ^ 1].as<float>();
-            s.Snew = st->Snew; s.cq = h->cqbuf.as<float>();
-            s.w = plan.w.as<float>(); s.w_out = plan.w_out;
-            s.alpha_out = h->alpha[alpha_slot].as<float>(); s.asum_out = h->asum[alpha_slot].as<float>();
+        ChainRoleS& s = a.s;
+        s.n_blocks = h->H * QS * h->L;
+        s.op = st.op->view();
+        s.draw_mode = st.inf ? (h->cfg.sticky ? 1 : 2) : 0;
+        if (s.draw_mode == 1) {
+            if (!st.u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
+            if (counter == 0 && h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
         }
-        if (pu.valid) {
-            ChainRoleU& u = a.u;
-            u.n_blocks = chain_u_blocks(h->N, h->L);
-            u.op = pu.op->view();
-            u.gather = pu.gather ? 1 : 0;
-            u.tab = h->tabring[pu.tab_slot].as<int32_t>();
-            u.R = pu.R; u.Pnew = pu.Pn; u.splitk = pu.sk; u.split_stride4 = pu.ss / 4;
-            u.B_prev = h->B[h->cur].as<float>(); u.KV_prev = h->KV[h->cur].as<float>();
-            u.B_next = h->B[h->cur ^ 1].as<float>(); u.KV_next = h->KV[h->cur ^ 1].as<float>();
-        }
-        if (pc.valid) {
-            ChainRoleC& c = a.c;
-            c.n_blocks = h->H * QT * h->L;
-            c.alpha = h->alpha[pc.alpha_slot].as<float>(); c.asum = h->asum[pc.alpha_slot].as<float>();
-            c.KV = h->KV[h->cur].as<float>();                 // V' of the chunk whose update ran last launch
-            for (int l = 0; l < h->L; ++l) c.bv[l] = pp.bv[l];
-            c.ctx_out = pc.ctx;
-        }
+        const long slot = counter % h->ring;
+        // sticky histogram: the first step of a call may inherit float partials from the per-call path;
+        // afterwards the totals live in the fixed-point ring (read slot k-1, accumulate k, clear k+1)
+        s.part_prev = h->bin_part[h->pc].as<float>(); s.parts = h->parts;
+        s.acc_prev = (counter > 0) ? h->mass_acc[(counter + 2) % 3].as<unsigned long long>() : nullptr;
+        s.acc_next = h->mass_acc[counter % 3].as<unsigned long long>();
+        s.acc_clear = h->mass_acc[(counter + 1) % 3].as<unsigned long long>();
+        s.probs_override = h->probs_override.as<float>(); s.override_mask = h->override_mask;
+        s.u = st.u; s.uniform_idx = plan.uniform_idx.as<int32_t>();
+        s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
+        s.tab_out = h->tab_ring.as<int32_t>() + slot * tab_slot();
+        s.Sp_prev = h->Sp[h->sc].as<float>(); s.Sp_next = h->Sp[h->sc ^ 1].as<float>();
+        s.Snew = st.Snew; s.cq = h->cqbuf.as<float>();
+        s.w = plan.w.as<float>(); s.w_out = plan.w_out;
+        s.alpha_out = h->alpha_ring.as<float>() + slot * alpha_slot();
+        s.asum_out = h->asum_ring.as<float>() + slot * asum_slot();
         {
-            // timing experiments only (results are wrong when a role is masked out): INFV_CHAIN_ROLES=bitmask S=1 U=2 C=4 noop=8
+            // timing experiments only: INFV_CHAIN_ROLES & 8 -> every workgroup returns at once
             static const int role_mask = [] { const char* e = getenv("INFV_CHAIN_ROLES"); return e ? atoi(e) : 7; }();
-            if (!(role_mask & 1)) a.s.n_blocks = 0;
-            if (!(role_mask & 2)) a.u.n_blocks = 0;
-            if (!(role_mask & 4)) a.c.n_blocks = 0;
             a.debug_noop = (role_mask & 8) ? 1 : 0;
             static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
             a.dbg = dbg;
@@ -522,33 +499,44 @@ struct FastPipe {
                 (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[stamps x10ns] S:");
                 for (int i = 1; i <= 5; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
-                fprintf(stderr, " [draw: sync %lld probs %lld scan %lld search %lld tab %lld]", hb[12] - hb[1], hb[13] - hb[12], hb[14] - hb[13], hb[15] - hb[14], hb[2] - hb[15]);
-                fprintf(stderr, " | U: %lld %lld | C:", hb[9] - hb[8], hb[11] - hb[9]);
-                for (int i = 17; i <= 19; ++i) fprintf(stderr, " %lld", hb[i] - hb[i - 1]);
-                fprintf(stderr, " | clk %.0f MHz | ends rel S0: S %lld U %lld C %lld\n",
-                        100.0 * (double)(hb[29] - hb[24]) / (double)(hb[5] - hb[0]), hb[5] - hb[0], hb[11] - hb[0], hb[19] - hb[0]);
+                fprintf(stderr, " [draw: sync %lld probs %lld scan %lld search %lld tab %lld] | clk %.0f MHz | S total %lld\n",
+                        hb[12] - hb[1], hb[13] - hb[12], hb[14] - hb[13], hb[15] - hb[14], hb[2] - hb[15],
+                        100.0 * (double)(hb[29] - hb[24]) / (double)(hb[5] - hb[0]), hb[5] - hb[0]);
             }
             Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
             HIP_TRY(launch_chain(a, stream));
         }
-        // ---- advance the pipeline ----
-        pc.valid = false;
-        if (pu.valid) {
-            h->cur ^= 1;                                      // B / V' now describe pu's chunk
-            pc.valid = true; pc.alpha_slot = pu.alpha_slot; pc.ctx = pu.ctx;
-            pu.valid = false;
+        if (s.draw_mode == 1) h->override_mask = 0;
+        h->sc ^= 1;
+        h->lastQ = Q;
+        h->last_fast = true;
+        ++counter;
+        return INFV_OK;
+    }
+
+    // memory update + read-out of `n` chunks whose role S used ring slots slot0.. ; flips the B / KV ping-pong
+    int launch_uc(const Operator& op, bool inf, int n, long slot0, const float* R, const float* Pn, int sk, long ss,
+                  float* ctx, hipStream_t ucs) {
+        UcArgs u;
+        memset(&u, 0, sizeof(u));
+        u.N = h->N; u.H = h->H; u.Q = Q; u.L = h->L; u.d = h->d; u.dm = h->dm; u.tabw = op.tabw;
+        u.op = op.view();
+        u.gather = inf ? 1 : 0;
+        u.have_state = h->has_memory ? 1 : 0;
+        u.n_chunks = n; u.slot0 = slot0 % h->ring; u.ring = h->ring;
+        u.tab = h->tab_ring.as<int32_t>(); u.tab_slot = (long)tab_slot();
+        u.alpha = h->alpha_ring.as<float>(); u.asum = h->asum_ring.as<float>();
+        u.R = R; u.Pnew = Pn; u.splitk = sk; u.split_stride = ss;
+        u.B_prev = h->B[h->cur].as<float>(); u.KV_prev = h->KV[h->cur].as<float>();
+        u.B_next = h->B[h->cur ^ 1].as<float>(); u.KV_next = h->KV[h->cur ^ 1].as<float>();
+        for (int l = 0; l < h->L; ++l) u.bv[l] = pp.bv[l];
+        u.ctx = ctx;
+        {
+            Timed t_(h->prof, INFV_KERNEL_UC, ucs);
+            HIP_TRY(::infv::launch_uc(u, ucs));
         }
-        if (st) {
-            if (a.s.draw_mode == 1) h->override_mask = 0;
-            h->sc ^= 1;
-            h->has_memory = true;
-            h->lastQ = Q;
-            h->last_fast = true;
-            pu.valid = true; pu.op = st->op; pu.gather = st->inf;
-            pu.R = st->R; pu.Pn = st->Pn; pu.sk = st->sk; pu.ss = st->ss;
-            pu.tab_slot = tab_slot; pu.alpha_slot = alpha_slot; pu.ctx = st->ctx;
-            ++counter;
-        }
+        h->cur ^= 1;
+        h->has_memory = true;
         return INFV_OK;
     }
 };
@@ -569,14 +557,32 @@ int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const floa
 
 int ensure_side_stream(infv_ltm_handle h) {
     if (h->side) return INFV_OK;
-    int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
-    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));   // the chain must win arbitration
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->ucs, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_s[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_c[i], hipEventDisableTiming));
     }
+    // INFV_CU_SPLIT=n (experiment): the chain kernels run on their own stream restricted to n CUs
+    // (n/8 per XCD), the chunk-parallel stage on the other 256-n, so the two never share a CU.
+    static const int split = [] { const char* e = getenv("INFV_CU_SPLIT"); return e ? atoi(e) : 0; }();
+    if (split >= 8 && split <= 248) {
+        uint32_t mask_chain[8], mask_side[8];
+        const int per = split / 8;
+        for (int x = 0; x < 8; ++x) {
+            mask_chain[x] = (per >= 32) ? 0xffffffffu : ((1u << per) - 1u);
+            mask_side[x] = ~mask_chain[x];
+        }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&h->chain, 8, mask_chain));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&h->side, 8, mask_side));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_caller, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    } else {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
+        HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     return INFV_OK;
 }
 
@@ -607,25 +613,46 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                                           ctx + c * chunk_ctx, stream_)) return rc;
         return INFV_OK;
     }
-    FastPipe pipe{h, *plan, Q, pp, stream};
     if (int rc = ensure_side_stream(h)) return rc;
-    HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
+    hipStream_t caller = stream;
+    if (h->chain) {                                          // CU split: everything below runs on the masked chain stream
+        HIP_TRY(hipEventRecord(h->ev_caller, caller));
+        HIP_TRY(hipStreamWaitEvent(h->chain, h->ev_caller, 0));
+        stream = h->chain;
+        stream_ = h->chain;
+    }
     // Padding LDS caps the side-stream kernels' occupancy: ONE 512-thread pool workgroup (88 KB) or ONE GEMM
-    // workgroup (36 + 90 KB) per CU, so a chain workgroup (<= 52 KB) always finds LDS and wave slots.
+    // workgroup (36 + 90 KB) per CU, so a role-S workgroup always finds LDS and wave slots.
     static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
-    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 90 * 1024; }();   // 36 KB static + 90 KB: one per CU
-    hipStream_t side = h->side;
+    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 90 * 1024; }();
+    FastPipe pipe{h, *plan, Q, pp, stream};
+    HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
+    {   // rings of role S's per-chunk outputs (sized for this call's Q)
+        const size_t need_a = (size_t)h->ring * pipe.alpha_slot() * sizeof(float);
+        if (need_a > h->alpha_ring.bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->alpha_ring.reserve(need_a));
+            HIP_TRY(h->asum_ring.reserve((size_t)h->ring * pipe.asum_slot() * sizeof(float)));
+            HIP_TRY(h->tab_ring.reserve((size_t)h->ring * pipe.tab_slot() * sizeof(int32_t)));
+        }
+    }
+    hipStream_t side = h->side, ucs = h->ucs;
     int c = 0;
+    bool uc_pending[3] = {false, false, false};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
         if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
         if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, 1, &sk, &ss, stream)) return rc;
-        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, 1, sk, ss, true, stream)) return rc;
-        const StepS st{&plan->first, false, h->Snew_ws[1].as<float>(), nullptr, h->R_ws[1].as<float>(),
-                       h->P_ws[1].as<float>(), sk, ss, ctx};
-        if (int rc = pipe.launch(&st)) return rc;
+        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, 2, &sk, &ss, stream)) return rc;
+        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, 2, sk, ss, true, stream)) return rc;
+        const StepS st{&plan->first, false, h->Snew_ws[2].as<float>(), nullptr};
+        if (int rc = pipe.launch_s(st)) return rc;
+        HIP_TRY(hipEventRecord(h->ev_s[2], stream));
+        HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[2], 0));
+        if (int rc = pipe.launch_uc(plan->first, false, 1, 0, h->R_ws[2].as<float>(), h->P_ws[2].as<float>(), sk, ss, ctx, ucs)) return rc;
+        HIP_TRY(hipEventRecord(h->ev_uc[2], ucs));
+        uc_pending[2] = true;
         c = 1;
     } else {
         // continue an existing memory: bias-free scores of the current K' rows under this query
@@ -634,7 +661,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                                   (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
                                   stream));
     }
-    // ---- sub-batches: the chunk-parallel stage of batch b+1 (side stream) overlaps the chain of batch b ----
+    // ---- sub-batches.  Streams: `side` = chunk-parallel stage of batch b+1, caller's stream = role S of
+    //      batch b (one launch per chunk), `ucs` = memory update + read-out of batch b-1 ----
     const int first_c = c;
     const int n_batches = (n_chunks - first_c + h->maxC - 1) / h->maxC;
     const size_t rows = plan->inf.rows;
@@ -646,7 +674,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     };
     auto stage_parallel = [&](int b) -> int {                  // pool -> rows -> project -> scores of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b & 1;
+        const int set = b % 3;
+        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if ((size_t)nb * T * h->d * sizeof(float) > h->kbar_side.bytes) HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(h->kbar_side.reserve((size_t)nb * T * h->d * sizeof(float)));
         {
@@ -659,38 +688,46 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         return INFV_OK;
     };
     if (n_batches > 0) {
-        HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and (first chunk) set 1 are ordered before
+        HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
         HIP_TRY(hipStreamWaitEvent(side, h->ev_in, 0));
         if (int rc = stage_parallel(0)) return rc;
     }
     for (int b = 0; b < n_batches; ++b) {
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b & 1;
+        const int set = b % 3;
         HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
+        // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
+        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
+        const long slot0 = pipe.counter;
         for (int i = 0; i < nb; ++i) {
             const StepS st{&plan->inf, true, h->Snew_ws[set].as<float>() + (size_t)i * h->L * h->H * Q * rows,
-                           u ? u + (size_t)(c0 + i) * chunk_u : nullptr,
-                           h->R_ws[set].as<float>() + (size_t)i * rows * h->d,
-                           h->P_ws[set].as<float>() + (size_t)i * rows * h->L * 2 * h->dm, sks[b], sss[b],
-                           ctx + (size_t)(c0 + i) * chunk_ctx};
-            if (int rc = pipe.launch(&st)) return rc;
-            if (i == 0 && b + 1 < n_batches) {
-                // the launch above ran role U of the previous batch's last chunk: set^1 is free again
-                HIP_TRY(hipEventRecord(h->ev_c[set ^ 1], stream));
-                HIP_TRY(hipStreamWaitEvent(side, h->ev_c[set ^ 1], 0));
+                           u ? u + (size_t)(c0 + i) * chunk_u : nullptr};
+            if (int rc = pipe.launch_s(st)) return rc;
+            if (i == 0 && b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
-            }
         }
+        HIP_TRY(hipEventRecord(h->ev_s[set], stream));
+        HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
+        if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[set].as<float>(), h->P_ws[set].as<float>(),
+                                    sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
+        HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
+        uc_pending[set] = true;
     }
-    // drain: U(last) + C(last-1), then C(last); then bring the K' half of the projected memory up to date
-    if (int rc = pipe.launch(nullptr)) return rc;
-    if (int rc = pipe.launch(nullptr)) return rc;
-    if (pipe.counter > 0) {                                   // hand the sticky histogram back as one float partial row
+    // join: the memory and every ctx are complete once the last UC kernel is; then hand the sticky histogram
+    // back as one float partial row and bring the K' half of the projected memory up to date
+    for (int i = 0; i < 3; ++i)
+        if (uc_pending[i]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[i], 0));
+    if (pipe.counter > 0) {
         HIP_TRY(launch_acc_to_part(h->mass_acc[(pipe.counter + 2) % 3].as<unsigned long long>(), h->L, 1,
                                    h->bin_part[h->pc].as<float>(), stream));
         h->parts = 1;
     }
-    return infv_ltm_reproject(h, proj, stream_);
+    if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
+    if (h->chain) {
+        HIP_TRY(hipEventRecord(h->ev_done, h->chain));
+        HIP_TRY(hipStreamWaitEvent(caller, h->ev_done, 0));
+    }
+    return INFV_OK;
 }
 
 }  // extern "C"

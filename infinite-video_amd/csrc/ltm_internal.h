@@ -112,6 +112,25 @@ bool chain_supported(int N, int S, int rows_max, int tabw);
 int chain_u_blocks(int N, int n_layers);
 int chain_s_tiles(int Q);            // 8-row query tiles of role S (= sticky partial rows per head)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
+// ---- state update + read-out of a sub-batch in one launch (ltm_uc.hip) ----
+struct UcArgs {
+    int N, H, Q, L, d, dm, tabw;
+    OperatorView op;
+    int gather;                     // 0: new rows only (first chunk of a document)
+    int have_state;                 // 0: start from an empty memory (first chunk)
+    int n_chunks;
+    long slot0; int ring;           // chunk i of the launch uses ring slot (slot0 + i) % ring
+    const int32_t* tab; long tab_slot;   // [ring] slots of tab_slot ints, each [L][N*tabw]: gather tables written by role S
+    const float* alpha;             // [ring][L][H][Q][N]  softmax weights written by role S
+    const float* asum;              // [ring][L][H][Q]
+    const float* R; const float* Pnew; int splitk; long split_stride;   // new rows of the launch's first chunk onwards
+    const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
+    const float* bv[kMaxLayers];
+    float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks
+};
+bool uc_supported(int N, int d, int dm, int tabw, int rows_max);
+hipError_t launch_uc(const UcArgs& a, hipStream_t stream);
+
 // S'new[c][l][h][q][r] = (q_h[q]/sqrt(dh)) . Kmat(c,r,l)_h ; optionally cq[l][h][q] = q_h[q].bk_h/sqrt(dh)
 hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_chunks, int rows, const float* Kmat,
                              long chunk_stride, long row_stride, long layer_stride, int splitk, long split_stride,

@@ -1,0 +1,254 @@
+// State update + read-out of a whole sub-batch of chunks in ONE launch ("UC kernel").
+//
+// Role S of the chain publishes, per chunk c, the resolved gather table tab_c[n][k] (source box of the
+// k-th resampled slot of box n) and the softmax weights alpha_c.  Given those, the memory update
+//     X_c[n][:] = val_n * sum_k X_{c-1}[tab_c[n][k]][:] + Xnew_c[row(n)][:]        X in {B, V'}
+// acts on every COLUMN of B / V' independently (reference long_term_attention_gibbs.py:210-216:
+// B_past^T . samples^T and x @ G are column-wise linear maps).  So a workgroup that owns a 32-column
+// slice of one matrix keeps that slice in LDS and walks through all chunks of the sub-batch with no
+// inter-workgroup dependency at all; V' slices also produce their 32 columns of the read-out
+//     ctx_c[q][cols] = sum_n alpha_c[h][q][n] * V'_c[n][cols] + (sum_n alpha) * bv[cols]        (:284)
+// on the MFMA pipe.  The sequential dimension (chunks) costs only LDS latency here, not kernel launches.
+#include "ltm_device.h"
+
+namespace infv {
+
+constexpr int kUcNT = 512;
+constexpr int kUcCols = 32;               // columns per slice
+constexpr int kUcPitch = kUcCols + 1;     // LDS row pitch of a slice (conflict-free row gathers)
+constexpr int kUcMaxN = 256;
+constexpr int kUcQ = 32;                  // query rows per read-out pass
+
+struct UcSmem { int cur, nxt, tab, val, brow, newr, alpha, asum, red, total; };
+
+__host__ __device__ inline UcSmem uc_smem(int N, int tabw, int rows_max) {
+    UcSmem m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.cur = take(N * kUcPitch);
+    m.nxt = take(N * kUcPitch);
+    m.tab = take(N * tabw);
+    m.val = take(N);
+    m.brow = take(N);
+    m.newr = take(rows_max * kUcCols);
+    m.alpha = take(kUcQ * (N + 2));
+    m.asum = take(kUcQ);
+    m.red = take(8 * 64 * 4);
+    m.total = o;
+    return m;
+}
+
+__global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, tabw = a.tabw, rows = a.op.rows;
+    const UcSmem m = uc_smem(N, tabw, rows);
+    float* cur = lds + m.cur;
+    float* nxt = lds + m.nxt;
+    int32_t* tab = reinterpret_cast<int32_t*>(lds + m.tab);
+    float* val = lds + m.val;
+    int32_t* brow = reinterpret_cast<int32_t*>(lds + m.brow);
+    float* newr = lds + m.newr;
+    float* Asm = lds + m.alpha;
+    float* asum = lds + m.asum;
+    float* red = lds + m.red;
+    const int sstride = N + 2;
+
+    // which slice: per layer first the B slices (d / 32), then the V' slices (dm / 32)
+    const int sb = a.d / kUcCols, sv = a.dm / kUcCols;
+    const int per_layer = sb + sv;
+    const int l = blockIdx.x / per_layer;
+    const int sl = blockIdx.x - l * per_layer;
+    const bool isV = sl >= sb;
+    const int col0 = (isV ? sl - sb : sl) * kUcCols;
+    const int dm = a.dm, H = a.H, Q = a.Q;
+    const int h = col0 / kHeadSize;                      // head of a V' slice
+    // global views of this slice
+    const int pitch = isV ? 2 * dm : a.d;
+    const float* src = isV ? a.KV_prev + (long)l * N * 2 * dm + dm + col0 : a.B_prev + (long)l * N * a.d + col0;
+    float* dst = isV ? a.KV_next + (long)l * N * 2 * dm + dm + col0 : a.B_next + (long)l * N * a.d + col0;
+
+    // ---- load the slice and the static operator tables ----
+    for (int e = tid; e < N * kUcCols; e += kUcNT) {
+        const int n = e / kUcCols, j = e - n * kUcCols;
+        cur[n * kUcPitch + j] = a.have_state ? src[(long)n * pitch + j] : 0.f;
+    }
+    for (int n = tid; n < N; n += kUcNT) { val[n] = a.op.box_val[n]; brow[n] = a.op.box_row[n]; }
+    __syncthreads();
+
+    // Per-chunk inputs are prefetched one chunk ahead into registers (all are written by earlier launches,
+    // none depends on this kernel), so the sequential loop never waits for a global round trip:
+    //   gather table  N*tabw ints  -> int4 per thread (N*tabw <= 2048)
+    //   new rows      rows*32      -> up to 16 floats per thread (rows <= 256)
+    //   alpha tile    32*N         -> 4 float4 per thread (V' slices; N <= 256, Q-tile of 32 rows)
+    const int n4 = N / 4;
+    const bool one_qtile = Q <= kUcQ;                    // alpha of the next chunk can be prefetched whole
+    int4 t_reg = make_int4(-1, -1, -1, -1);
+    float nr_reg[16];
+    floatx4 al_reg[4];
+    float as_reg = 0.f;
+    auto prefetch = [&](int i) {
+        const long slot = (a.slot0 + i) % a.ring;
+        const int32_t* tabg = a.tab + slot * a.tab_slot + (long)l * N * tabw;
+        if (a.gather && tid * 4 < N * tabw) t_reg = *reinterpret_cast<const int4*>(tabg + tid * 4);
+        const long crow = (long)i * rows;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * kUcNT;
+            nr_reg[u] = 0.f;
+            if (e < rows * kUcCols) {
+                const int r = e / kUcCols, j = e - r * kUcCols;
+                if (isV) {
+                    const long off = ((crow + r) * a.L + l) * 2L * dm + dm + col0 + j;
+                    float v = 0.f;
+                    for (int k = 0; k < a.splitk; ++k) v += a.Pnew[off + k * a.split_stride];
+                    nr_reg[u] = v;
+                } else {
+                    nr_reg[u] = a.R[(crow + r) * a.d + col0 + j];
+                }
+            }
+        }
+        if (isV && one_qtile) {
+            const float* alg = a.alpha + ((slot * a.L + l) * H + h) * (long)Q * N;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + u * kUcNT;
+                const int r = e / n4, c4 = e - r * n4;
+                al_reg[u] = (r < Q) ? *reinterpret_cast<const floatx4*>(alg + (long)r * N + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (tid < kUcQ) as_reg = (tid < Q) ? a.asum[((slot * a.L + l) * H + h) * (long)Q + tid] : 0.f;
+        }
+    };
+    prefetch(0);
+    for (int i = 0; i < a.n_chunks; ++i) {
+        const long slot = (a.slot0 + i) % a.ring;        // ring slot of this chunk's alpha / tab
+        // ---- park this chunk's prefetched inputs in LDS, start fetching the next chunk's ----
+        if (tid * 4 < N * tabw) *reinterpret_cast<int4*>(&tab[tid * 4]) = a.gather ? t_reg : make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * kUcNT;
+            if (e < rows * kUcCols) newr[e] = nr_reg[u];
+        }
+        if (isV && one_qtile) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + u * kUcNT;
+                const int r = e / n4, c4 = e - r * n4;
+                if (r < kUcQ) {
+                    float* d4 = &Asm[r * sstride + c4 * 4];
+                    d4[0] = al_reg[u].x; d4[1] = al_reg[u].y; d4[2] = al_reg[u].z; d4[3] = al_reg[u].w;
+                }
+            }
+            if (tid < kUcQ) asum[tid] = as_reg;
+        }
+        if (i + 1 < a.n_chunks) prefetch(i + 1);
+        __syncthreads();
+        // ---- memory update of the slice: column j = tid & 31, boxes (tid >> 5) + 16 u; gathers from LDS ----
+        {
+            const int j = tid & (kUcCols - 1), nb0 = tid >> 5;
+#pragma unroll 4
+            for (int u = 0; u < kUcMaxN / 16; ++u) {
+                const int n = nb0 + 16 * u;
+                if (n < N) {
+                    float acc = 0.f;
+                    const float vn = val[n];
+                    for (int k0 = 0; k0 < tabw; k0 += 4) {
+                        const int4 s4 = *reinterpret_cast<const int4*>(&tab[n * tabw + k0]);
+                        const float v0 = cur[max(s4.x, 0) * kUcPitch + j], v1 = cur[max(s4.y, 0) * kUcPitch + j];
+                        const float v2 = cur[max(s4.z, 0) * kUcPitch + j], v3 = cur[max(s4.w, 0) * kUcPitch + j];
+                        if (s4.x >= 0) acc = fmaf(vn, v0, acc);
+                        if (s4.y >= 0) acc = fmaf(vn, v1, acc);
+                        if (s4.z >= 0) acc = fmaf(vn, v2, acc);
+                        if (s4.w >= 0) acc = fmaf(vn, v3, acc);
+                    }
+                    const int r = brow[n];
+                    if (r >= 0) acc += newr[r * kUcCols + j];
+                    nxt[n * kUcPitch + j] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        { float* t = cur; cur = nxt; nxt = t; }
+        // ---- read-out of the V' slice: passes of 32 query rows ----
+        if (isV) {
+            const float* alg = a.alpha + ((slot * a.L + l) * H + h) * (long)Q * N;
+            const float* asg = a.asum + ((slot * a.L + l) * H + h) * (long)Q;
+            float* ctx = a.ctx + (long)i * a.L * Q * dm + (long)l * Q * dm + col0;
+            for (int q0 = 0; q0 < Q; q0 += kUcQ) {
+                const int qn = min(kUcQ, Q - q0);
+                if (!one_qtile) {
+                    for (int e = tid; e < kUcQ * N; e += kUcNT) {
+                        const int r = e / N, n = e - r * N;
+                        Asm[r * sstride + n] = (r < qn) ? alg[(long)(q0 + r) * N + n] : 0.f;
+                    }
+                    if (tid < kUcQ) asum[tid] = (tid < qn) ? asg[q0 + tid] : 0.f;
+                    __syncthreads();
+                }
+                // 8 waves = 2 query tiles x 2 column tiles x 2 halves of the box dimension
+                const int c = lane & 15, g = lane >> 4;
+                const int qt = wave & 1, ct = (wave >> 1) & 1, ks = wave >> 2;
+                const int per = N / 2, kb = ks * per;
+                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int t = 0; t < per / 4; t += 2) {
+                    const float a0 = Asm[(16 * qt + c) * sstride + kb + 4 * t + g];
+                    const float b0 = cur[(kb + 4 * t + g) * kUcPitch + 16 * ct + c];
+                    const float a1 = Asm[(16 * qt + c) * sstride + kb + 4 * (t + 1) + g];
+                    const float b1 = cur[(kb + 4 * (t + 1) + g) * kUcPitch + 16 * ct + c];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+                }
+                const floatx4 accw = acc0 + acc1;
+                *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
+                __syncthreads();
+                if (ks == 0) {
+                    floatx4 tot = accw;
+                    tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
+                    const float* bv = a.bv[l] + col0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * qt + 4 * g + r;
+                        if (rr < qn) {
+                            const int col = 16 * ct + c;
+                            ctx[(long)(q0 + rr) * dm + col] = tot[r] + asum[rr] * bv[col];
+                        }
+                    }
+                }
+                if (!one_qtile) __syncthreads();
+            }
+        }
+        // (the next iteration's LDS stores touch tab / newr / Asm / asum / nxt: all of their readers above
+        //  sit before the last barrier of this iteration, except the read-out, which only reads Asm, asum,
+        //  cur and red -- so one barrier is needed before Asm / asum are overwritten)
+        if (isV && one_qtile) __syncthreads();
+    }
+    // ---- write the slice back ----
+    for (int e = tid; e < N * kUcCols; e += kUcNT) {
+        const int n = e / kUcCols, j = e - n * kUcCols;
+        dst[(long)n * pitch + j] = cur[n * kUcPitch + j];
+    }
+}
+
+size_t uc_lds_bytes(int N, int tabw, int rows_max) { return (size_t)uc_smem(N, tabw, rows_max).total * sizeof(float); }
+
+bool uc_supported(int N, int d, int dm, int tabw, int rows_max) {
+    return N <= kUcMaxN && N % 16 == 0 && N * tabw <= 4 * kUcNT && rows_max * kUcCols <= 16 * kUcNT && d % kUcCols == 0 && dm % kHeadSize == 0 && (tabw & 3) == 0 &&
+           uc_lds_bytes(N, tabw, rows_max) <= 160 * 1024;
+}
+
+hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (a.n_chunks <= 0) return hipSuccess;
+    if (!uc_supported(a.N, a.d, a.dm, a.tabw, a.op.rows)) return hipErrorInvalidValue;
+    const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
+    hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace infv
