@@ -532,6 +532,16 @@ struct FastPipe {
         for (int l = 0; l < h->L; ++l) u.bv[l] = pp.bv[l];
         u.ctx = ctx;
         {
+            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_UC_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
+            u.dbg = dbg;
+            static int calls = 0;
+            if (dbg && (++calls % 8) == 0) {
+                long long hb[16];
+                (void)hipStreamSynchronize(ucs);
+                (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[uc stamps x10ns] park %lld prefetch-issue %lld barrier %lld gather %lld mfma %lld red-barrier %lld epilogue %lld | chunk total %lld\n",
+                        hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
+            }
             Timed t_(h->prof, INFV_KERNEL_UC, ucs);
             HIP_TRY(::infv::launch_uc(u, ucs));
         }

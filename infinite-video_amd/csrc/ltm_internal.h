@@ -127,6 +127,7 @@ struct UcArgs {
     const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
     const float* bv[kMaxLayers];
     float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks
+    long long* dbg;                 // timing experiments: phase stamps of one V' workgroup, or nullptr
 };
 bool uc_supported(int N, int d, int dm, int tabw, int rows_max);
 hipError_t launch_uc(const UcArgs& a, hipStream_t stream);

@@ -19,6 +19,10 @@ constexpr int kUcPitch = kUcCols + 1;     // LDS row pitch of a slice (conflict-
 constexpr int kUcMaxN = 256;
 constexpr int kUcQ = 32;                  // query rows per read-out pass
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter,
+// which would expose the latency of the next chunk's prefetch loads at every barrier.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct UcSmem { int cur, nxt, tab, val, brow, newr, alpha, asum, red, total; };
 
 __host__ __device__ inline UcSmem uc_smem(int N, int tabw, int rows_max) {
@@ -87,40 +91,57 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
     float nr_reg[16];
     floatx4 al_reg[4];
     float as_reg = 0.f;
+    // offsets of this thread's prefetch elements relative to the chunk's base (computed once)
+    int nr_off[16];                                      // -1: not mine
+    const long nr_chunk = isV ? (long)rows * a.L * 2 * dm : (long)rows * a.d;
+    const float* nr_base = isV ? a.Pnew + (long)l * 2 * dm + dm + col0 : a.R + col0;
+    const int nsplit = isV ? a.splitk : 1;               // only the projected rows come as split-K partial slabs
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + u * kUcNT;
+        nr_off[u] = -1;
+        if (e < rows * kUcCols) {
+            const int r = e / kUcCols, j = e - r * kUcCols;
+            nr_off[u] = isV ? r * a.L * 2 * dm + j : r * a.d + j;
+        }
+    }
+    int al_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * kUcNT;
+        const int r = e / n4, c4 = e - r * n4;
+        al_off[u] = (r < Q && r < kUcQ) ? r * N + c4 * 4 : -1;
+    }
+    const long al_slot = (long)a.L * H * Q * N, as_slot = (long)a.L * H * Q;
+    const float* al_base = a.alpha + ((long)l * H + h) * (long)Q * N;
+    const float* as_base = a.asum + ((long)l * H + h) * (long)Q;
     auto prefetch = [&](int i) {
         const long slot = (a.slot0 + i) % a.ring;
-        const int32_t* tabg = a.tab + slot * a.tab_slot + (long)l * N * tabw;
-        if (a.gather && tid * 4 < N * tabw) t_reg = *reinterpret_cast<const int4*>(tabg + tid * 4);
-        const long crow = (long)i * rows;
+        if (a.gather && tid * 4 < N * tabw)
+            t_reg = *reinterpret_cast<const int4*>(a.tab + slot * a.tab_slot + (long)l * N * tabw + tid * 4);
+        const float* nb = nr_base + (long)i * nr_chunk;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int e = tid + u * kUcNT;
-            nr_reg[u] = 0.f;
-            if (e < rows * kUcCols) {
-                const int r = e / kUcCols, j = e - r * kUcCols;
-                if (isV) {
-                    const long off = ((crow + r) * a.L + l) * 2L * dm + dm + col0 + j;
-                    float v = 0.f;
-                    for (int k = 0; k < a.splitk; ++k) v += a.Pnew[off + k * a.split_stride];
-                    nr_reg[u] = v;
-                } else {
-                    nr_reg[u] = a.R[(crow + r) * a.d + col0 + j];
-                }
+            float v = 0.f;
+            if (nr_off[u] >= 0) {
+                v = nb[nr_off[u]];
+                for (int k = 1; k < nsplit; ++k) v += nb[nr_off[u] + k * a.split_stride];
             }
+            nr_reg[u] = v;
         }
         if (isV && one_qtile) {
-            const float* alg = a.alpha + ((slot * a.L + l) * H + h) * (long)Q * N;
+            const float* ab = al_base + slot * al_slot;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = tid + u * kUcNT;
-                const int r = e / n4, c4 = e - r * n4;
-                al_reg[u] = (r < Q) ? *reinterpret_cast<const floatx4*>(alg + (long)r * N + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (tid < kUcQ) as_reg = (tid < Q) ? a.asum[((slot * a.L + l) * H + h) * (long)Q + tid] : 0.f;
+            for (int u = 0; u < 4; ++u)
+                al_reg[u] = (al_off[u] >= 0) ? *reinterpret_cast<const floatx4*>(ab + al_off[u]) : floatx4{0.f, 0.f, 0.f, 0.f};
+            if (tid < kUcQ) as_reg = (tid < Q) ? as_base[slot * as_slot + tid] : 0.f;
         }
     };
+    const bool stamp_me = a.dbg != nullptr && tid == 0 && blockIdx.x == sb && a.n_chunks > 4;   // first V' slice of layer 0
+#define USTAMP(k) do { if (stamp_me && i == 3) a.dbg[k] = wall_clock64(); } while (0)
     prefetch(0);
     for (int i = 0; i < a.n_chunks; ++i) {
+        USTAMP(0);
         const long slot = (a.slot0 + i) % a.ring;        // ring slot of this chunk's alpha / tab
         // ---- park this chunk's prefetched inputs in LDS, start fetching the next chunk's ----
         if (tid * 4 < N * tabw) *reinterpret_cast<int4*>(&tab[tid * 4]) = a.gather ? t_reg : make_int4(-1, -1, -1, -1);
@@ -141,33 +162,68 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
             }
             if (tid < kUcQ) asum[tid] = as_reg;
         }
+        USTAMP(1);
         if (i + 1 < a.n_chunks) prefetch(i + 1);
-        __syncthreads();
+        USTAMP(2);
+        lds_barrier();
+        USTAMP(3);
         // ---- memory update of the slice: column j = tid & 31, boxes (tid >> 5) + 16 u; gathers from LDS ----
         {
             const int j = tid & (kUcCols - 1), nb0 = tid >> 5;
-#pragma unroll 4
-            for (int u = 0; u < kUcMaxN / 16; ++u) {
-                const int n = nb0 + 16 * u;
-                if (n < N) {
-                    float acc = 0.f;
-                    const float vn = val[n];
-                    for (int k0 = 0; k0 < tabw; k0 += 4) {
-                        const int4 s4 = *reinterpret_cast<const int4*>(&tab[n * tabw + k0]);
-                        const float v0 = cur[max(s4.x, 0) * kUcPitch + j], v1 = cur[max(s4.y, 0) * kUcPitch + j];
-                        const float v2 = cur[max(s4.z, 0) * kUcPitch + j], v3 = cur[max(s4.w, 0) * kUcPitch + j];
-                        if (s4.x >= 0) acc = fmaf(vn, v0, acc);
-                        if (s4.y >= 0) acc = fmaf(vn, v1, acc);
-                        if (s4.z >= 0) acc = fmaf(vn, v2, acc);
-                        if (s4.w >= 0) acc = fmaf(vn, v3, acc);
+            if (tabw == 4) {
+                // all table entries first, then all gathered values, then the arithmetic: the LDS latencies overlap
+#pragma unroll 1
+                for (int u0 = 0; u0 < kUcMaxN / 16; u0 += 4) {
+                    int4 s4[4]; float vn[4]; int br[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int n = min(nb0 + 16 * (u0 + u), N - 1);
+                        s4[u] = *reinterpret_cast<const int4*>(&tab[n * 4]);
+                        vn[u] = val[n]; br[u] = brow[n];
                     }
-                    const int r = brow[n];
-                    if (r >= 0) acc += newr[r * kUcCols + j];
-                    nxt[n * kUcPitch + j] = acc;
+                    float g[4][4], nw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        g[u][0] = cur[max(s4[u].x, 0) * kUcPitch + j]; g[u][1] = cur[max(s4[u].y, 0) * kUcPitch + j];
+                        g[u][2] = cur[max(s4[u].z, 0) * kUcPitch + j]; g[u][3] = cur[max(s4[u].w, 0) * kUcPitch + j];
+                        nw[u] = newr[max(br[u], 0) * kUcCols + j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int n = nb0 + 16 * (u0 + u);
+                        float acc = 0.f;
+                        if (s4[u].x >= 0) acc = fmaf(vn[u], g[u][0], acc);
+                        if (s4[u].y >= 0) acc = fmaf(vn[u], g[u][1], acc);
+                        if (s4[u].z >= 0) acc = fmaf(vn[u], g[u][2], acc);
+                        if (s4[u].w >= 0) acc = fmaf(vn[u], g[u][3], acc);
+                        if (br[u] >= 0) acc += nw[u];
+                        if (n < N) nxt[n * kUcPitch + j] = acc;
+                    }
+                }
+            } else {
+                for (int u = 0; u < kUcMaxN / 16; ++u) {
+                    const int n = nb0 + 16 * u;
+                    if (n < N) {
+                        float acc = 0.f;
+                        const float vn = val[n];
+                        for (int k0 = 0; k0 < tabw; k0 += 4) {
+                            const int4 s4 = *reinterpret_cast<const int4*>(&tab[n * tabw + k0]);
+                            const float v0 = cur[max(s4.x, 0) * kUcPitch + j], v1 = cur[max(s4.y, 0) * kUcPitch + j];
+                            const float v2 = cur[max(s4.z, 0) * kUcPitch + j], v3 = cur[max(s4.w, 0) * kUcPitch + j];
+                            if (s4.x >= 0) acc = fmaf(vn, v0, acc);
+                            if (s4.y >= 0) acc = fmaf(vn, v1, acc);
+                            if (s4.z >= 0) acc = fmaf(vn, v2, acc);
+                            if (s4.w >= 0) acc = fmaf(vn, v3, acc);
+                        }
+                        const int r = brow[n];
+                        if (r >= 0) acc += newr[r * kUcCols + j];
+                        nxt[n * kUcPitch + j] = acc;
+                    }
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        USTAMP(4);
         { float* t = cur; cur = nxt; nxt = t; }
         // ---- read-out of the V' slice: passes of 32 query rows ----
         if (isV) {
@@ -182,7 +238,7 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
                         Asm[r * sstride + n] = (r < qn) ? alg[(long)(q0 + r) * N + n] : 0.f;
                     }
                     if (tid < kUcQ) asum[tid] = (tid < qn) ? asg[q0 + tid] : 0.f;
-                    __syncthreads();
+                    lds_barrier();
                 }
                 // 8 waves = 2 query tiles x 2 column tiles x 2 halves of the box dimension
                 const int c = lane & 15, g = lane >> 4;
@@ -198,9 +254,11 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
                 }
+                USTAMP(5);
                 const floatx4 accw = acc0 + acc1;
                 *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
-                __syncthreads();
+                lds_barrier();
+                USTAMP(6);
                 if (ks == 0) {
                     floatx4 tot = accw;
                     tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
@@ -214,13 +272,14 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
                         }
                     }
                 }
-                if (!one_qtile) __syncthreads();
+                if (!one_qtile) lds_barrier();
             }
         }
         // (the next iteration's LDS stores touch tab / newr / Asm / asum / nxt: all of their readers above
         //  sit before the last barrier of this iteration, except the read-out, which only reads Asm, asum,
         //  cur and red -- so one barrier is needed before Asm / asum are overwritten)
-        if (isV && one_qtile) __syncthreads();
+        if (isV && one_qtile) lds_barrier();
+        USTAMP(7);
     }
     // ---- write the slice back ----
     for (int e = tid; e < N * kUcCols; e += kUcNT) {
