@@ -141,6 +141,7 @@ struct infv_ltm_s {
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
+    DeviceBuf sync_words;              // [0..7] arrival counters per layer, [8] error flag of the persistent chain kernel
     DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][128] u64, ring of 3 (read / accumulate / being cleared)
     int sc = 0;
     int n_bins = 128;
@@ -334,6 +335,8 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
+    if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(h->sync_words.p, 0, 16 * sizeof(unsigned int));
     h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
@@ -514,6 +517,45 @@ struct FastPipe {
         return INFV_OK;
     }
 
+    // role S of `n` consecutive infinite-memory chunks in one persistent launch
+    int launch_s_batch(int n, const float* Snew, const double* u) {
+        ChainBatchArgs b;
+        memset(&b, 0, sizeof(b));
+        const int QS = chain_s_tiles(Q);
+        b.N = h->N; b.H = h->H; b.Q = Q; b.QS = QS; b.L = h->L; b.S = h->S;
+        b.st = plan.sticky();
+        b.op = plan.inf.view();
+        b.draw_mode = h->cfg.sticky ? 1 : 2;
+        if (b.draw_mode == 1) {
+            if (!u) return fail(INFV_ERR_INVALID, "sticky consolidation needs the Gibbs uniforms u");
+            if (counter == 0 && h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available");
+        }
+        b.n_steps = n; b.step0 = counter; b.ring = h->ring;
+        b.first_from_parts = (counter == 0) ? 1 : 0;
+        b.part_prev = h->bin_part[h->pc].as<float>(); b.parts = h->parts;
+        for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
+        b.arrive = h->sync_words.as<unsigned int>(); b.error = h->sync_words.as<unsigned int>() + 8;
+        b.probs_override = h->probs_override.as<float>(); b.override_mask = h->override_mask;
+        b.u = u; b.uniform_idx = plan.uniform_idx.as<int32_t>();
+        b.probs_out = h->probs.as<float>(); b.bins_out = h->bins.as<int32_t>(); b.idx_out = h->idx.as<int32_t>();
+        b.tab_ring = h->tab_ring.as<int32_t>(); b.tab_slot = (long)tab_slot();
+        b.alpha_ring = h->alpha_ring.as<float>(); b.alpha_slot = (long)alpha_slot();
+        b.asum_ring = h->asum_ring.as<float>(); b.asum_slot = (long)asum_slot();
+        b.Sp_in = h->Sp[h->sc].as<float>(); b.Sp_out = h->Sp[h->sc ^ 1].as<float>();
+        b.Snew = Snew; b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
+        HIP_TRY(hipMemsetAsync(h->sync_words.p, 0, 8 * sizeof(unsigned int), stream));     // arrival counters
+        {
+            Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
+            HIP_TRY(launch_chain_batch(b, stream));
+        }
+        if (b.draw_mode == 1) h->override_mask = 0;
+        h->sc ^= 1;
+        h->lastQ = Q;
+        h->last_fast = true;
+        counter += n;
+        return INFV_OK;
+    }
+
     // memory update + read-out of `n` chunks whose role S used ring slots slot0.. ; flips the B / KV ping-pong
     int launch_uc(const Operator& op, bool inf, int n, long slot0, const float* R, const float* Pn, int sk, long ss,
                   float* ctx, hipStream_t ucs) {
@@ -673,6 +715,10 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     }
     // ---- sub-batches.  Streams: `side` = chunk-parallel stage of batch b+1, caller's stream = role S of
     //      batch b (one launch per chunk), `ucs` = memory update + read-out of batch b-1 ----
+    // INFV_PERSISTENT=0 falls back to one role-S launch per chunk
+    static const bool want_persistent = [] { const char* e = getenv("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
+    const bool persistent = want_persistent &&
+        chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
     const int first_c = c;
     const int n_batches = (n_chunks - first_c + h->maxC - 1) / h->maxC;
     const size_t rows = plan->inf.rows;
@@ -709,12 +755,19 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
         const long slot0 = pipe.counter;
-        for (int i = 0; i < nb; ++i) {
-            const StepS st{&plan->inf, true, h->Snew_ws[set].as<float>() + (size_t)i * h->L * h->H * Q * rows,
-                           u ? u + (size_t)(c0 + i) * chunk_u : nullptr};
-            if (int rc = pipe.launch_s(st)) return rc;
-            if (i == 0 && b + 1 < n_batches)
+        if (persistent) {
+            // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
+            if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
+            if (int rc = pipe.launch_s_batch(nb, h->Snew_ws[set].as<float>(), u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
+        } else {
+            for (int i = 0; i < nb; ++i) {
+                const StepS st{&plan->inf, true, h->Snew_ws[set].as<float>() + (size_t)i * h->L * h->H * Q * rows,
+                               u ? u + (size_t)(c0 + i) * chunk_u : nullptr};
+                if (int rc = pipe.launch_s(st)) return rc;
+                if (i == 0 && b + 1 < n_batches)
+                    if (int rc = stage_parallel(b + 1)) return rc;
+            }
         }
         HIP_TRY(hipEventRecord(h->ev_s[set], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
@@ -797,6 +850,11 @@ int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* 
     if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipStreamSynchronize(stream));
+    {
+        unsigned int err = 0;
+        HIP_TRY(hipMemcpy(&err, h->sync_words.as<unsigned int>() + 8, sizeof(err), hipMemcpyDeviceToHost));
+        if (err) return fail(INFV_ERR_STATE, "a workgroup of the persistent chain kernel timed out waiting for its layer");
+    }
     if (bins) HIP_TRY(hipMemcpy(bins, h->bins.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (idx) HIP_TRY(hipMemcpy(idx, h->idx.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (probs) HIP_TRY(hipMemcpy(probs, h->probs.as<float>() + (size_t)layer * h->n_bins, (h->n_bins - 1) * sizeof(float), hipMemcpyDeviceToHost));

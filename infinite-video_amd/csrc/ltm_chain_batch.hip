@@ -1,0 +1,262 @@
+// Role S of a whole sub-batch of chunks in ONE launch (persistent over the sub-batch).
+//
+// The per-chunk launch of chain_kernel pays, per step, a kernel boundary (~3.5 us of dispatch + cache
+// write-back) and a cold reload of its state.  Here the H*QS*L workgroups of role S stay resident for all
+// chunks of a sub-batch and keep their score tile, tables and gather machinery in LDS; the only
+// inter-workgroup dependency of a step -- the 127 sticky bin masses summed over the (head, query) rows of a
+// layer -- is exchanged in place:
+//   * every workgroup adds its masses into a fixed-point accumulator with integer atomics (performed at
+//     the memory side: exact, order-independent, no L2 coherence involved),
+//   * then bumps the layer's arrival counter; a workgroup starts step i's draw once the counter shows
+//     that all workgroups of its layer finished step i-1, and reads the totals back with returning atomics.
+// No fence / L2 write-back is needed: the exchanged words are only ever touched by device-scope atomics.
+// All workgroups of the launch must be co-resident (96 at the headline shape, one per CU of 256); waits are
+// bounded and raise an error flag instead of hanging.
+#include "ltm_device.h"
+
+namespace infv {
+
+constexpr int kBNT = 512;
+constexpr int kBRows = 8;
+constexpr int kBMaxN = 256;
+constexpr int kBNIter = kBMaxN / 64;
+
+struct BatchSmem { int cdf, sidx, gsum, misc, tab0, tab, box_val, box_row, w, bin_box, edge_box, edge_dx, Sp0, Sp1, Ssm, Snew, Dsm, Msm, total; };
+
+__host__ __device__ inline BatchSmem batch_smem(int N, int S, int rows, int tabw) {
+    BatchSmem m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.cdf = take(kBins);
+    m.sidx = take(S);
+    m.gsum = take(2 * kBNT);
+    m.misc = take(64);                                 // [0,16) cq | [16,32) asum | [32] wait flag
+    m.tab0 = take(N * tabw);                           // static slot ids
+    m.tab = take(N * tabw);                            // resolved source boxes of the current step
+    m.box_val = take(N);
+    m.box_row = take(N);
+    m.w = take(N);
+    m.bin_box = take(kBins);
+    m.edge_box = take(kBins + 4);
+    m.edge_dx = take(kBins);
+    m.Sp0 = take(kBRows * (N + 4));
+    m.Sp1 = take(kBRows * (N + 4));
+    m.Ssm = take(kBRows * (N + 2));
+    m.Snew = take(kBRows * (rows + 1));
+    m.Dsm = take(kBRows * kDPitch);
+    m.Msm = take(kBRows * kMPitch);
+    m.total = o;
+    return m;
+}
+
+__device__ inline unsigned long long coherent_read(unsigned long long* p) { return atomicAdd(p, 0ull); }
+
+__global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
+    const int rows = a.op.rows, tabw = a.op.tabw;
+    const BatchSmem m = batch_smem(N, a.S, rows, tabw);
+    const int b = blockIdx.x;
+    const int h = b % H, qs = (b / H) % QS, l = b / (H * QS);
+    const int blocks_per_layer = H * QS;
+    const int sp = N + 4, sstride = N + 2, sn = rows + 1;
+    float* Spc = lds + m.Sp0;                           // current bias-free scores of this tile
+    float* Spn = lds + m.Sp1;
+    float* Ssm = lds + m.Ssm;
+    float* Snew = lds + m.Snew;
+    float* cqs = lds + m.misc;
+    float* asum = lds + m.misc + 16;
+    int32_t* sidx = reinterpret_cast<int32_t*>(lds + m.sidx);
+    int32_t* tab0 = reinterpret_cast<int32_t*>(lds + m.tab0);
+    int32_t* tab = reinterpret_cast<int32_t*>(lds + m.tab);
+    const long tile = (((long)l * H + h) * Q + qs * kBRows);
+    const int valid = min(kBRows, Q - qs * kBRows);
+    const bool writer = (h == 0 && qs == 0);
+    const long tile_snew = (long)a.L * H * Q * rows;     // floats of one step's S'new
+
+    // ---- one-time set-up: tables, slot table, score tile ----
+    {
+        const int n4 = N / 4;
+        const int sr = tid / n4, sc4 = tid - sr * n4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (sr < valid) v = *reinterpret_cast<const floatx4*>(a.Sp_in + (tile + sr) * N + sc4 * 4);
+        if (sr < kBRows) *reinterpret_cast<floatx4*>(&Spc[sr * sp + sc4 * 4]) = v;
+        if (tid < kBRows) cqs[tid] = (tid < valid) ? a.cq[tile + tid] : 0.f;
+        if (tid < N) {
+            (lds + m.box_val)[tid] = a.op.box_val[tid];
+            reinterpret_cast<int32_t*>(lds + m.box_row)[tid] = a.op.box_row[tid];
+            (lds + m.w)[tid] = a.w[tid];
+        }
+        if (tid < kBins) {
+            reinterpret_cast<int32_t*>(lds + m.bin_box)[tid] = a.st.bin_box[tid];
+            (lds + m.edge_dx)[tid] = a.st.edge_dx[tid];
+        }
+        if (tid <= kBins) reinterpret_cast<int32_t*>(lds + m.edge_box)[tid] = a.st.edge_box[tid];
+        for (int e = tid; e < N * tabw; e += kBNT) tab0[e] = a.op.slot_tab[e];
+        if (a.draw_mode == 2)
+            for (int s = tid; s < a.S; s += kBNT) sidx[s] = a.uniform_idx[s];
+    }
+    // prefetch of step 0: S'new tile elements and this thread's uniform
+    float sn_reg[4];
+    double u_reg = 2.0;
+    auto prefetch = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * kBNT;
+            const int r = e / rows, cc = e - r * rows;
+            sn_reg[k] = (e < kBRows * rows && r < valid) ? a.Snew[i * tile_snew + (tile + r) * rows + cc] : 0.f;
+        }
+        if (a.draw_mode == 1 && tid < a.S) u_reg = a.u[((long)i * a.L + l) * a.S + tid];
+    };
+    prefetch(0);
+    __syncthreads();
+
+    for (int i = 0; i < a.n_steps; ++i) {
+        const long g = a.step0 + i;                      // global step index of this call
+        unsigned long long* acc_prev = a.acc[(g + 2) % 3] + l * kBins;
+        unsigned long long* acc_cur = a.acc[g % 3] + l * kBins;
+        unsigned long long* acc_clr = a.acc[(g + 1) % 3] + l * kBins;
+        const long slot = g % a.ring;
+        // park the prefetched S'new tile
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * kBNT;
+            if (e < kBRows * rows) { const int r = e / rows; Snew[r * sn + (e - r * rows)] = sn_reg[k]; }
+        }
+        const double my_u = u_reg;
+        // ---- wait until every workgroup of this layer has finished the previous step of this launch ----
+        if (i > 0 && a.draw_mode == 1) {
+            if (tid == 0) {
+                const unsigned target = (unsigned)(blocks_per_layer * i);
+                int spins = 0;
+                while (__hip_atomic_load(a.arrive + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 22)) { atomicExch(a.error, 1u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        if (writer && tid < kBins) atomicExch(acc_clr + tid, 0ull);      // slot of the NEXT step: idle until then
+        // ---- draw ----
+        if (a.draw_mode == 1) {
+            const bool ovr = (i == 0) && ((a.override_mask >> l) & 1u);
+            DrawRegs<1> dr;
+            dr.us[0] = my_u; dr.acc = 0.0; dr.ovr[0] = dr.ovr[1] = 0.f;
+            if (ovr) {
+                if (tid < 64) {
+                    dr.ovr[0] = a.probs_override[l * kBins + tid];
+                    if (tid + 64 < kBins - 1) dr.ovr[1] = a.probs_override[l * kBins + tid + 64];
+                }
+            } else if (i == 0 && a.first_from_parts) {
+                const int j = tid & (kBins - 1), grp = tid / kBins;
+                if (j < kBins - 1)
+                    for (int p = grp; p < a.parts; p += kBNT / kBins) dr.acc += (double)a.part_prev[((long)l * a.parts + p) * kBins + j];
+            } else if (tid < kBins - 1) {
+                dr.acc = (double)coherent_read(acc_prev + tid) * (1.0 / kMassScale);
+            }
+            const bool last = (i == a.n_steps - 1);
+            draw_finish<kBNT, 1>(dr, ovr, reinterpret_cast<const int32_t*>(lds + m.bin_box), a.S, lds + m.cdf, sidx,
+                                 reinterpret_cast<double*>(lds + m.gsum),
+                                 (writer && last) ? a.probs_out + l * kBins : nullptr,
+                                 (writer && last) ? a.bins_out + (long)l * a.S : nullptr,
+                                 (writer && last) ? a.idx_out + (long)l * a.S : nullptr);
+        } else {
+            __syncthreads();
+        }
+        // resolved gather table of this step (published for the UC kernel by the layer's writer)
+        {
+            int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;
+            for (int e = tid; e < N * tabw; e += kBNT) {
+                const int sl = tab0[e];
+                const int src = (sl >= 0) ? sidx[sl] : -1;
+                tab[e] = src;
+                if (writer) tab_out[e] = src;
+            }
+        }
+        if (i + 1 < a.n_steps) prefetch(i + 1);
+        __syncthreads();
+        // ---- score recurrence ----
+        {
+            const float* box_val = lds + m.box_val;
+            const int32_t* box_row = reinterpret_cast<const int32_t*>(lds + m.box_row);
+            const int row = wave;
+            const float cqr = cqs[row];
+            const float* Sp = Spc + row * sp;
+#pragma unroll
+            for (int k = 0; k < kBNIter; ++k) {
+                const int n = lane + 64 * k;
+                if (n < N) {
+                    float acc = 0.f;
+                    const float val = box_val[n];
+                    for (int k0 = 0; k0 < tabw; k0 += 4) {
+                        const int4 src = *reinterpret_cast<const int4*>(&tab[n * tabw + k0]);
+                        const float v0 = Sp[max(src.x, 0)], v1 = Sp[max(src.y, 0)];
+                        const float v2 = Sp[max(src.z, 0)], v3 = Sp[max(src.w, 0)];
+                        if (src.x >= 0) acc = fmaf(val, v0, acc);
+                        if (src.y >= 0) acc = fmaf(val, v1, acc);
+                        if (src.z >= 0) acc = fmaf(val, v2, acc);
+                        if (src.w >= 0) acc = fmaf(val, v3, acc);
+                    }
+                    const int r = box_row[n];
+                    if (r >= 0) acc += Snew[row * sn + r];
+                    Spn[row * sp + n] = acc;
+                    Ssm[row * sstride + n] = acc + cqr;
+                }
+            }
+        }
+        __syncthreads();
+        row_phase_wave(Ssm, sstride, N, valid, lds + m.w, a.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
+                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows);
+        // the masses are at the memory side once the atomics are acknowledged; then announce the arrival
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) atomicAdd(a.arrive + l, 1u);
+        // alpha_i and its row sums for the UC kernel
+        if (wave < valid) {
+            float* al = a.alpha_ring + slot * a.alpha_slot + (tile + wave) * N;
+#pragma unroll
+            for (int k = 0; k < kBNIter; ++k) {
+                const int n = lane + 64 * k;
+                if (n < N) al[n] = Ssm[wave * sstride + n];
+            }
+            if (lane == 0) a.asum_ring[slot * a.asum_slot + tile + wave] = asum[wave];
+        }
+        { float* t = Spc; Spc = Spn; Spn = t; }
+        // (next iteration's first LDS writes go to Snew, whose last readers sit before the barrier above)
+    }
+    // ---- hand the score tile to the next launch ----
+    __syncthreads();
+    {
+        const int n4 = N / 4;
+        const int sr = tid / n4, sc4 = tid - sr * n4;
+        if (sr < valid) *reinterpret_cast<floatx4*>(a.Sp_out + (tile + sr) * N + sc4 * 4) =
+                            *reinterpret_cast<const floatx4*>(&Spc[sr * sp + sc4 * 4]);
+    }
+}
+
+size_t chain_batch_lds_bytes(int N, int S, int rows, int tabw) { return (size_t)batch_smem(N, S, rows, tabw).total * sizeof(float); }
+
+bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
+    return N <= kBMaxN && N % 16 == 0 && S <= kBNT && rows <= kBMaxN && tabw <= 16 && (tabw & 3) == 0 &&
+           n_blocks <= 128 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
+}
+
+hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (a.n_steps <= 0) return hipSuccess;
+    const int blocks = a.H * a.QS * a.L;
+    if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, blocks)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_batch_kernel, dim3(blocks), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
+                       stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace infv

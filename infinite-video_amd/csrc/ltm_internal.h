@@ -112,6 +112,32 @@ bool chain_supported(int N, int S, int rows_max, int tabw);
 int chain_u_blocks(int N, int n_layers);
 int chain_s_tiles(int Q);            // 8-row query tiles of role S (= sticky partial rows per head)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
+// ---- role S of a whole sub-batch in one persistent launch (ltm_chain_batch.hip) ----
+struct ChainBatchArgs {
+    int N, H, Q, QS, L, S;
+    StickyView st;
+    OperatorView op;                // infinite-memory operator
+    int draw_mode;                  // 1: sticky Gibbs draw, 2: uniform resample
+    int n_steps;
+    long step0; int ring;           // step i has global index step0+i: histogram slot (step0+i)%3, output slot (step0+i)%ring
+    int first_from_parts;           // step 0 reads the float partials of the per-call path instead of the ring
+    const float* part_prev; int parts;
+    unsigned long long* acc[3];     // fixed-point sticky histograms [L][128], ring of 3
+    unsigned int* arrive;           // [L] arrival counters, zero at launch
+    unsigned int* error;            // set to 1 if a wait timed out
+    const float* probs_override; unsigned override_mask;     // teacher forcing of step 0
+    const double* u;                // [n_steps][L][S]
+    const int32_t* uniform_idx;
+    float* probs_out; int32_t* bins_out; int32_t* idx_out;    // diagnostics of the last step
+    int32_t* tab_ring; long tab_slot;
+    float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
+    const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
+    const float* Snew;              // [n_steps][L][H][Q][rows]
+    const float* cq; const float* w; float w_out;
+};
+bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
+hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
+
 // ---- state update + read-out of a sub-batch in one launch (ltm_uc.hip) ----
 struct UcArgs {
     int N, H, Q, L, d, dm, tabw;
