@@ -131,8 +131,6 @@ struct infv_ltm_s {
     // stream while the chain of sub-batch b-1 runs on the caller's stream
     DeviceBuf kbar_ws, kbar_side, R_ws[3], P_ws[3], Snew_ws[3];
     hipStream_t side = nullptr;
-    hipStream_t chain = nullptr;        // CU-masked stream of the chain kernels (only with a CU split)
-    hipEvent_t ev_caller = nullptr, ev_done = nullptr;
     hipEvent_t ev_in = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
@@ -149,11 +147,8 @@ struct infv_ltm_s {
     ~infv_ltm_s() {
         for (auto& kv : plans) delete kv.second;
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-        if (chain) { (void)hipStreamSynchronize(chain); (void)hipStreamDestroy(chain); }
         if (ucs) { (void)hipStreamSynchronize(ucs); (void)hipStreamDestroy(ucs); }
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
-        if (ev_caller) (void)hipEventDestroy(ev_caller);
-        if (ev_done) (void)hipEventDestroy(ev_done);
         if (ev_in) (void)hipEventDestroy(ev_in);
         for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
     }
@@ -490,9 +485,6 @@ struct FastPipe {
         s.alpha_out = h->alpha_ring.as<float>() + slot * alpha_slot();
         s.asum_out = h->asum_ring.as<float>() + slot * asum_slot();
         {
-            // timing experiments only: INFV_CHAIN_ROLES & 8 -> every workgroup returns at once
-            static const int role_mask = [] { const char* e = getenv("INFV_CHAIN_ROLES"); return e ? atoi(e) : 7; }();
-            a.debug_noop = (role_mask & 8) ? 1 : 0;
             static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
             a.dbg = dbg;
             static int stamp_calls = 0;
@@ -544,6 +536,18 @@ struct FastPipe {
         b.Sp_in = h->Sp[h->sc].as<float>(); b.Sp_out = h->Sp[h->sc ^ 1].as<float>();
         b.Snew = Snew; b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
         HIP_TRY(hipMemsetAsync(h->sync_words.p, 0, 8 * sizeof(unsigned int), stream));     // arrival counters
+        {
+            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
+            b.dbg = dbg;
+            static int calls = 0;
+            if (dbg && (++calls % 8) == 0) {
+                long long hb[16];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[batch-S stamps x10ns] wait %lld draw %lld tab %lld recurrence %lld row-phase %lld atomics+arrive %lld alpha-out %lld | step %lld\n",
+                        hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
+            }
+        }
         {
             Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
             HIP_TRY(launch_chain_batch(b, stream));
@@ -615,25 +619,9 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
     }
-    // INFV_CU_SPLIT=n (experiment): the chain kernels run on their own stream restricted to n CUs
-    // (n/8 per XCD), the chunk-parallel stage on the other 256-n, so the two never share a CU.
-    static const int split = [] { const char* e = getenv("INFV_CU_SPLIT"); return e ? atoi(e) : 0; }();
-    if (split >= 8 && split <= 248) {
-        uint32_t mask_chain[8], mask_side[8];
-        const int per = split / 8;
-        for (int x = 0; x < 8; ++x) {
-            mask_chain[x] = (per >= 32) ? 0xffffffffu : ((1u << per) - 1u);
-            mask_side[x] = ~mask_chain[x];
-        }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&h->chain, 8, mask_chain));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&h->side, 8, mask_side));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_caller, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-    } else {
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
-        HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
-    }
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
+    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     return INFV_OK;
 }
@@ -666,13 +654,6 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         return INFV_OK;
     }
     if (int rc = ensure_side_stream(h)) return rc;
-    hipStream_t caller = stream;
-    if (h->chain) {                                          // CU split: everything below runs on the masked chain stream
-        HIP_TRY(hipEventRecord(h->ev_caller, caller));
-        HIP_TRY(hipStreamWaitEvent(h->chain, h->ev_caller, 0));
-        stream = h->chain;
-        stream_ = h->chain;
-    }
     // Padding LDS caps the side-stream kernels' occupancy: ONE 512-thread pool workgroup (88 KB) or ONE GEMM
     // workgroup (36 + 90 KB) per CU, so a role-S workgroup always finds LDS and wave slots.
     static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
@@ -785,12 +766,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                                    h->bin_part[h->pc].as<float>(), stream));
         h->parts = 1;
     }
-    if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
-    if (h->chain) {
-        HIP_TRY(hipEventRecord(h->ev_done, h->chain));
-        HIP_TRY(hipStreamWaitEvent(caller, h->ev_done, 0));
-    }
-    return INFV_OK;
+    return infv_ltm_reproject(h, proj, stream_);
 }
 
 }  // extern "C"

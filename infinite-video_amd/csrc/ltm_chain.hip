@@ -1,27 +1,22 @@
-// Whole-video fast path of the LTM memory chain (used by infv_ltm_consolidate, where the query
-// of every layer is the same for all chunks).
+// Whole-video fast path of the LTM memory chain, part 1: the sequential "role S" of one chunk per launch
+// (used for the first chunk of a document, and as the fallback when the persistent sub-batch kernel of
+// ltm_chain_batch.hip does not apply), plus the batched new-row scores.
 //
 // The chain  B_c = f(B_{c-1}, S_{c-1}, kbar_c, u_c)  is sequential across chunks, so its cost is
-// latency, not bandwidth.  Two restatements take the matrix products off the critical path:
+// latency, not bandwidth.  Three restatements take everything but a gather off the critical path
+// (DESIGN.md section 2):
 //
 //  (1) score recurrence.  K'_c[n] = val_n * sum_{s in slots(n)} K'_{c-1}[idx_s] + P_c[row(n)]
 //      (projection is linear), hence with a fixed query
 //          S'_c[q][n] = val_n * sum_s S'_{c-1}[q][idx_s] + S'new_c[q][row(n)],
 //      S'new_c = (q/sqrt(dh)) . P_c^T  is batched over chunks ahead of time (new_scores_kernel).
-//      The chain step then needs no GEMM for the scores (reference :224-230), only a gather.
-//  (2) deferred read-out.  ctx_{c} = alpha_c . (V'_c + bv) is not an input of step c+1, so launch
-//      c+1 computes it ("role C") beside step c+1's critical work.
+//  (2) deferred state update and read-out.  B_c, V'_c and ctx_c are not inputs of step c+1's draw;
+//      role S only publishes the resolved gather table and the softmax weights, and the UC kernel
+//      (ltm_uc.hip) applies them to a whole sub-batch later, slice-parallel.
 //
-//  (3) deferred state update.  B_c / V'_c are not inputs of step c+1's scores either, so they are
-//      gathered one launch later from the indices step c published ("role U"), and the read-out
-//      follows one launch after that.
-//
-// One launch per chunk, three kinds of workgroups that never talk to each other inside a launch,
-// each working on a different chunk of a 3-stage software pipeline (launch k):
-//   role S  (head, 8-row q-tile, layer): draw_k -> score recurrence -> alpha_k, sticky partials_k  [critical]
-//   role U  (4 boxes, layer)           : B_{k-1}, V'_{k-1} rows from idx_{k-1} (gather + new rows)
-//   role C  (head, 16-row q-tile, layer): ctx_{k-2} from alpha_{k-2}, V'_{k-2}
-// Every S workgroup repeats the (tiny) Gibbs draw so that no in-launch hand-off is needed.
+// Role S of chunk k (one workgroup per (head, 8-row query tile, layer)):
+//   draw_k -> score recurrence -> alpha_k, sticky bin masses_k (fixed-point atomics), gather table_k.
+// Every workgroup repeats the (tiny) Gibbs draw so that no in-launch hand-off is needed.
 #include "ltm_device.h"
 
 namespace infv {
@@ -107,11 +102,9 @@ hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_c
 // ======================================================================================
 constexpr int kNT = 512;                 // 8 waves = 2 per SIMD
 constexpr int kRowsS = 8;                // query rows per role-S workgroup: wave w <-> row w
-constexpr int kBoxesPerU = 4;
 constexpr int kMaxN = 256;               // boxes the fast path holds in LDS
 constexpr int kMaxTabw = 16;             // slots per box the dense table holds
 constexpr int kNIter = kMaxN / 64;       // boxes per lane in a wave-per-row sweep
-constexpr int kCRows = 64;               // V' rows staged per read-out pass of role C (keeps the launch's LDS small)
 
 struct ChainSmem {            // role S: offsets (in floats) into dynamic LDS, identical on host and device
     int cdf, sidx, gsum, misc, tab, box_val, box_row, w, bin_box, edge_box, edge_dx, Sprev, Ssm, Snew, Dsm, Msm, total;
@@ -149,7 +142,6 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
     const int N = a.N, H = a.H, Q = a.Q, QT = a.QT, QS = a.QS;
     const int dm = H * kHeadSize;
     int b = blockIdx.x;
-    if (a.debug_noop) return;                                          // dispatch-floor timing experiment
     // latency-critical: win issue arbitration against the throughput kernels of the side stream that share the CU
     __builtin_amdgcn_s_setprio(3);
 
@@ -303,183 +295,10 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         STAMP(5);
         return;
     }
-    b -= a.s.n_blocks;
-    if (b < a.u.n_blocks) {
-        // ================================================================== role U: B and V' rows of 4 boxes
-        const ChainRoleU& ru = a.u;
-        const int tabw = ru.op.tabw;
-        const int per_layer = (N + kBoxesPerU - 1) / kBoxesPerU;
-        const int l = b / per_layer, n0 = (b - l * per_layer) * kBoxesPerU;
-        const int d4 = a.d4, dm4 = a.dm4, kv4 = 2 * dm4;
-        const int total4 = d4 + dm4;
-        const int nbox = min(kBoxesPerU, N - n0);
-        const floatx4* R4 = reinterpret_cast<const floatx4*>(ru.R);
-        const floatx4* P4 = reinterpret_cast<const floatx4*>(ru.Pnew);
-        int32_t* src_lds = reinterpret_cast<int32_t*>(lds);             // [kBoxesPerU][tabw] resolved source boxes
-        float* val_lds = lds + kBoxesPerU * kMaxTabw;                   // [kBoxesPerU]
-        const bool stamp_me = (b == 0 && tid == 0);
-        STAMP(8);
-        // round trip 1: resolved source boxes of this workgroup's boxes, plus the new-row contributions
-        if (tid < nbox * tabw)
-            src_lds[tid] = ru.gather ? ru.tab[((long)l * N + n0) * tabw + tid] : -1;
-        if (tid < nbox) val_lds[tid] = ru.op.box_val[n0 + tid];
-        floatx4 newv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            newv[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const int o = tid + i * kNT;
-            if (o < nbox * total4) {
-                const int bi = o / total4, c = o - bi * total4;
-                const int r = ru.op.box_row[n0 + bi];
-                if (r >= 0) {
-                    if (c < d4) {
-                        newv[i] = R4[(long)r * d4 + c];
-                    } else {
-                        const long off = ((long)r * a.L + l) * kv4 + dm4 + (c - d4);
-                        for (int k = 0; k < ru.splitk; ++k) newv[i] += P4[off + k * ru.split_stride4];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        STAMP(9);
-        // round trip 2: the gathered rows
-        const floatx4* Bp = reinterpret_cast<const floatx4*>(ru.B_prev) + (long)l * N * d4;
-        const floatx4* Vp = reinterpret_cast<const floatx4*>(ru.KV_prev) + (long)l * N * kv4 + dm4;
-        floatx4* Bn = reinterpret_cast<floatx4*>(ru.B_next) + (long)l * N * d4;
-        floatx4* Vn = reinterpret_cast<floatx4*>(ru.KV_next) + (long)l * N * kv4 + dm4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = tid + i * kNT;
-            if (o < nbox * total4) {
-                const int bi = o / total4, c = o - bi * total4;
-                const int n = n0 + bi;
-                const bool isB = c < d4;
-                const int cc = isB ? c : c - d4;
-                const floatx4* prev = isB ? Bp : Vp;
-                const int pitch = isB ? d4 : kv4;
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (ru.gather) {
-                    const float val = val_lds[bi];
-                    for (int k0 = 0; k0 < tabw; k0 += 4) {             // 4 gathered rows in flight at a time
-                        const int4 src = *reinterpret_cast<const int4*>(&src_lds[bi * tabw + k0]);
-                        const int sv[4] = {src.x, src.y, src.z, src.w};
-                        floatx4 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = prev[(long)max(sv[k], 0) * pitch + cc];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (sv[k] >= 0) {
-                                acc.x = fmaf(val, v[k].x, acc.x); acc.y = fmaf(val, v[k].y, acc.y);
-                                acc.z = fmaf(val, v[k].z, acc.z); acc.w = fmaf(val, v[k].w, acc.w);
-                            }
-                    }
-                }
-                acc += newv[i];
-                if (isB) Bn[(long)n * d4 + cc] = acc; else Vn[(long)n * kv4 + cc] = acc;
-            }
-        }
-        STAMP(11);
-        return;
-    }
-    b -= a.u.n_blocks;
-    {
-        // ================================================================== role C: read-out of one (head, 16-row tile)
-        // 8 waves = 4 column tiles (16 of the head's 64 columns) x 2 halves of the box dimension;
-        // the 2 partial accumulators of a column tile are summed through LDS in a fixed order.
-        const ChainRoleC& rc = a.c;
-        const int h = b % H, qt = (b / H) % QT, l = b / (H * QT);
-        const int sstride = N + 2;
-        float* Asm = lds;                                              // [16][N+2] alpha
-        float* Vsm = lds + ((kQTile * sstride + 3) & ~3);              // [kCRows][80]
-        float* red = Vsm + kCRows * kVStride;                          // [8 waves][64 lanes][4]
-        const long tile = (((long)l * H + h) * Q + qt * kQTile);
-        const int valid = min(kQTile, Q - qt * kQTile);
-        const float* Vhead = rc.KV + (long)l * N * 2 * dm + dm + h * kHeadSize;
-        const bool stamp_me = (b == 0 && tid == 0);
-        STAMP(16);
-        // prologue: alpha tile and the first kVRows rows of the V' head slice together
-        const int n4 = N / 4;
-        floatx4 al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * kNT;
-            const int ar = e / n4, ac4 = e - ar * n4;
-            al[i] = (ar < valid) ? *reinterpret_cast<const floatx4*>(rc.alpha + (tile + ar) * N + ac4 * 4)
-                                 : floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-        const int c = lane & 15, g = lane >> 4;
-        const int ct = wave & 3, ks = wave >> 2;                       // column tile, half of the staged rows
-        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int base = 0; base < N; base += kCRows) {
-            const int rows = min(kCRows, N - base);
-            floatx4 vreg[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = tid + i * kNT;
-                const int r = e >> 4, c4 = e & 15;
-                vreg[i] = (r < rows) ? *reinterpret_cast<const floatx4*>(Vhead + (long)(base + r) * 2 * dm + c4 * 4)
-                                     : floatx4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (base == 0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int e = tid + i * kNT;
-                    const int ar = e / n4, ac4 = e - ar * n4;
-                    if (ar < kQTile) {
-                        float* dst = &Asm[ar * sstride + ac4 * 4];
-                        dst[0] = al[i].x; dst[1] = al[i].y; dst[2] = al[i].z; dst[3] = al[i].w;
-                    }
-                }
-            } else {
-                __syncthreads();                                       // previous pass's reads of Vsm are done
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = tid + i * kNT;
-                const int r = e >> 4, c4 = e & 15;
-                if (r < rows) *reinterpret_cast<floatx4*>(&Vsm[r * kVStride + c4 * 4]) = vreg[i];
-            }
-            __syncthreads();
-            if (base == 0) STAMP(17);
-            const int per = rows / 2;                                  // boxes of this wave's half (multiple of 8)
-            const int kb = ks * per;
-#pragma unroll 4
-            for (int t = 0; t < per / 4; t += 2) {
-                const float a0 = Asm[c * sstride + base + kb + 4 * t + g];
-                const float b0 = Vsm[(kb + 4 * t + g) * kVStride + 16 * ct + c];
-                const float a1 = Asm[c * sstride + base + kb + 4 * (t + 1) + g];
-                const float b1 = Vsm[(kb + 4 * (t + 1) + g) * kVStride + 16 * ct + c];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-            }
-        }
-        const floatx4 accw = acc0 + acc1;
-        *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
-        __syncthreads();
-        STAMP(18);
-        if (ks == 0) {
-            floatx4 tot = accw;
-            tot += *reinterpret_cast<const floatx4*>(&red[((4 + ct) * 64 + lane) * 4]);
-            const float* bv = rc.bv[l] + h * kHeadSize;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 4 * g + r;
-                if (rr < valid) {
-                    const int col = 16 * ct + c;
-                    rc.ctx_out[((long)l * Q + qt * kQTile + rr) * dm + h * kHeadSize + col] =
-                        tot[r] + rc.asum[tile + rr] * bv[col];
-                }
-            }
-        }
-        STAMP(19);
-    }
 }
 
 size_t chain_lds_bytes(int N, int S, int rows, int tabw) {
-    const size_t roleS = (size_t)chain_smem(N, S, rows, tabw).total;
-    const size_t roleC = (size_t)((kQTile * (N + 2) + 3) & ~3) + kCRows * kVStride + 8 * 64 * 4;
-    return (roleS > roleC ? roleS : roleC) * sizeof(float);
+    return (size_t)chain_smem(N, S, rows, tabw).total * sizeof(float);
 }
 
 bool chain_supported(int N, int S, int rows_max, int tabw) {
@@ -489,8 +308,6 @@ bool chain_supported(int N, int S, int rows_max, int tabw) {
 
 int chain_s_tiles(int Q) { return (Q + kRowsS - 1) / kRowsS; }
 
-int chain_u_blocks(int N, int n_layers) { return n_layers * ((N + kBoxesPerU - 1) / kBoxesPerU); }
-
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -499,11 +316,9 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int blocks = a.s.n_blocks + a.u.n_blocks + a.c.n_blocks;
+    const int blocks = a.s.n_blocks;
     if (blocks == 0) return hipSuccess;
-    int rows = 1, tabw = 4;
-    if (a.s.n_blocks) { rows = a.s.op.rows; tabw = a.s.op.tabw; }
-    if (a.u.n_blocks && a.u.op.tabw > kMaxTabw) return hipErrorInvalidValue;
+    const int rows = a.s.op.rows, tabw = a.s.op.tabw;
     if (!chain_supported(a.N, a.S, rows, tabw)) return hipErrorInvalidValue;
     const size_t lds = chain_lds_bytes(a.N, a.S, rows, tabw);
     hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kNT), lds, stream, a);

@@ -101,19 +101,29 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     // prefetch of step 0: S'new tile elements and this thread's uniform
     float sn_reg[4];
     double u_reg = 2.0;
-    auto prefetch = [&](int i) {
+    int sn_off[4], sn_lds[4];                            // per-thread element offsets, computed once
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = tid + k * kBNT;
-            const int r = e / rows, cc = e - r * rows;
-            sn_reg[k] = (e < kBRows * rows && r < valid) ? a.Snew[i * tile_snew + (tile + r) * rows + cc] : 0.f;
-        }
-        if (a.draw_mode == 1 && tid < a.S) u_reg = a.u[((long)i * a.L + l) * a.S + tid];
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + k * kBNT;
+        const int r = e / rows, cc = e - r * rows;
+        sn_off[k] = (e < kBRows * rows && r < valid) ? (int)((tile + r) * rows + cc) : -1;
+        sn_lds[k] = (e < kBRows * rows) ? r * sn + cc : -1;
+    }
+    const double* u_base = a.u + (long)l * a.S + tid;
+    const long u_step = (long)a.L * a.S;
+    const bool has_u = a.draw_mode == 1 && tid < a.S;
+    auto prefetch = [&](int i) {
+        const float* sb = a.Snew + i * tile_snew;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sn_reg[k] = (sn_off[k] >= 0) ? sb[sn_off[k]] : 0.f;
+        if (has_u) u_reg = u_base[i * u_step];
     };
     prefetch(0);
     __syncthreads();
 
+#define BSTAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) a.dbg[k] = wall_clock64(); } while (0)
     for (int i = 0; i < a.n_steps; ++i) {
+        BSTAMP(0);
         const long g = a.step0 + i;                      // global step index of this call
         unsigned long long* acc_prev = a.acc[(g + 2) % 3] + l * kBins;
         unsigned long long* acc_cur = a.acc[g % 3] + l * kBins;
@@ -121,10 +131,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         const long slot = g % a.ring;
         // park the prefetched S'new tile
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = tid + k * kBNT;
-            if (e < kBRows * rows) { const int r = e / rows; Snew[r * sn + (e - r * rows)] = sn_reg[k]; }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (sn_lds[k] >= 0) Snew[sn_lds[k]] = sn_reg[k];
         const double my_u = u_reg;
         // ---- wait until every workgroup of this layer has finished the previous step of this launch ----
         if (i > 0 && a.draw_mode == 1) {
@@ -132,12 +140,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
                 const unsigned target = (unsigned)(blocks_per_layer * i);
                 int spins = 0;
                 while (__hip_atomic_load(a.arrive + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 22)) { atomicExch(a.error, 1u); break; }
                 }
             }
             __syncthreads();
         }
+        BSTAMP(1);
         if (writer && tid < kBins) atomicExch(acc_clr + tid, 0ull);      // slot of the NEXT step: idle until then
         // ---- draw ----
         if (a.draw_mode == 1) {
@@ -165,18 +174,15 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         } else {
             __syncthreads();
         }
+        BSTAMP(2);
         // resolved gather table of this step (published for the UC kernel by the layer's writer)
-        {
-            int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;
-            for (int e = tid; e < N * tabw; e += kBNT) {
-                const int sl = tab0[e];
-                const int src = (sl >= 0) ? sidx[sl] : -1;
-                tab[e] = src;
-                if (writer) tab_out[e] = src;
-            }
+        for (int e = tid; e < N * tabw; e += kBNT) {
+            const int sl = tab0[e];
+            tab[e] = (sl >= 0) ? sidx[sl] : -1;
         }
         if (i + 1 < a.n_steps) prefetch(i + 1);
         __syncthreads();
+        BSTAMP(3);
         // ---- score recurrence ----
         {
             const float* box_val = lds + m.box_val;
@@ -207,13 +213,21 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
             }
         }
         __syncthreads();
+        BSTAMP(4);
         row_phase_wave(Ssm, sstride, N, valid, lds + m.w, a.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
                        lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows);
+        BSTAMP(5);
         // the masses are at the memory side once the atomics are acknowledged; then announce the arrival
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) atomicAdd(a.arrive + l, 1u);
-        // alpha_i and its row sums for the UC kernel
+        BSTAMP(6);
+        // outputs for the UC kernel go out after the arrival, off the other workgroups' critical path:
+        // the resolved gather table (layer's writer) and alpha_i with its row sums
+        if (writer) {
+            int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;
+            for (int e = tid; e < N * tabw; e += kBNT) tab_out[e] = tab[e];
+        }
         if (wave < valid) {
             float* al = a.alpha_ring + slot * a.alpha_slot + (tile + wave) * N;
 #pragma unroll
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
             if (lane == 0) a.asum_ring[slot * a.asum_slot + tile + wave] = asum[wave];
         }
         { float* t = Spc; Spc = Spn; Spn = t; }
+        BSTAMP(7);
         // (next iteration's first LDS writes go to Snew, whose last readers sit before the barrier above)
     }
     // ---- hand the score tile to the next launch ----

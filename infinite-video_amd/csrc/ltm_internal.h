@@ -68,11 +68,7 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
                          const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
                          float* bin_part, float* scores, hipStream_t stream);
 
-// ---- whole-video fast path (ltm_chain.hip) ----------------------------------------------------
-// One launch runs up to three independent roles, each on its own chunk of a 3-stage pipeline:
-//   S(k)   draw k -> score recurrence -> alpha_k, sticky partials_k, publishes idx_k
-//   U(k-1) B and V' rows of chunk k-1 from idx_{k-1}            (no draw: reads what S published)
-//   C(k-2) read-out ctx_{k-2} = alpha_{k-2} . (V'_{k-2} + bv)
+// ---- whole-video fast path, role S of one chunk per launch (ltm_chain.hip) ----------------------
 struct ChainRoleS {
     int n_blocks;                   // H * QS * L, or 0
     OperatorView op;
@@ -86,30 +82,14 @@ struct ChainRoleS {
     const float* Sp_prev; float* Sp_next; const float* Snew; const float* cq; const float* w; float w_out;
     float* alpha_out; float* asum_out;
 };
-struct ChainRoleU {
-    int n_blocks;                   // L * ceil(N / boxes per block), or 0
-    OperatorView op;
-    int gather;                     // 0: new rows only (first chunk of a document)
-    const int32_t* tab;             // [L][N*tabw] written by role S one launch earlier
-    const float* R; const float* Pnew; int splitk; long split_stride4;
-    const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
-};
-struct ChainRoleC {
-    int n_blocks;                   // H * QT * L, or 0
-    const float* alpha; const float* asum; const float* KV; const float* bv[kMaxLayers]; float* ctx_out;
-};
 struct ChainArgs {
-    int N, H, Q, QT, QS, L, S, d4, dm4;   // QT: 16-row tiles (role C), QS: 8-row tiles (role S)
+    int N, H, Q, QT, QS, L, S, d4, dm4;   // QS: 8-row query tiles of role S
     StickyView st;
     ChainRoleS s;
-    ChainRoleU u;
-    ChainRoleC c;
-    int debug_noop;                 // timing experiments: every workgroup returns at once
     long long* dbg;                 // timing experiments: phase stamps (100 MHz) of one workgroup per role, or nullptr
 };
 size_t chain_lds_bytes(int N, int S, int rows, int tabw);
 bool chain_supported(int N, int S, int rows_max, int tabw);
-int chain_u_blocks(int N, int n_layers);
 int chain_s_tiles(int Q);            // 8-row query tiles of role S (= sticky partial rows per head)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
 // ---- role S of a whole sub-batch in one persistent launch (ltm_chain_batch.hip) ----
@@ -134,6 +114,7 @@ struct ChainBatchArgs {
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
     const float* Snew;              // [n_steps][L][H][Q][rows]
     const float* cq; const float* w; float w_out;
+    long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
 };
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
