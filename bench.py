@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=2048, help="chunks of the synthetic video (whole job)")
-    ap.add_argument("--batch-chunks", type=int, default=32, help="chunks pooled/projected per sub-batch")
+    ap.add_argument("--batch-chunks", type=int, default=28,
+                    help="chunks per sub-batch (28 x 64 new rows = 14 row tiles x 18 column tiles = 252 GEMM workgroups)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

@@ -135,6 +135,7 @@ struct infv_ltm_s {
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
     DeviceBuf Sp[2], cqbuf;
+    DeviceBuf qt_buf;                  // fast path: pre-multiplied queries qt[(l*H+h)*Q+q][d] of the current call
     DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
@@ -334,6 +335,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (e == hipSuccess) e = hipMemset(h->sync_words.p, 0, 16 * sizeof(unsigned int));
     h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
+    if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
     if (e == hipSuccess) e = h->probs_override.reserve((size_t)h->L * h->n_bins * sizeof(float));
     if (e == hipSuccess) e = h->bins.reserve((size_t)h->L * h->S * sizeof(int32_t));
@@ -443,7 +445,7 @@ int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* 
 namespace {
 
 struct StepS {                       // critical work of the chunk entering the chain
-    const Operator* op; bool inf; const float* Snew; const double* u;
+    const Operator* op; bool inf; const float* Snew; const double* u; int sk; long ss;   // Snew: scores part of the chunk's first output row
 };
 
 struct FastPipe {
@@ -480,7 +482,8 @@ struct FastPipe {
         s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
         s.tab_out = h->tab_ring.as<int32_t>() + slot * tab_slot();
         s.Sp_prev = h->Sp[h->sc].as<float>(); s.Sp_next = h->Sp[h->sc ^ 1].as<float>();
-        s.Snew = st.Snew; s.cq = h->cqbuf.as<float>();
+        s.Snew = st.Snew; s.snew_ld = h->L * h->dm + h->L * h->H * Q; s.snew_splitk = st.sk; s.snew_split_stride = st.ss;
+        s.cq = h->cqbuf.as<float>();
         s.w = plan.w.as<float>(); s.w_out = plan.w_out;
         s.alpha_out = h->alpha_ring.as<float>() + slot * alpha_slot();
         s.asum_out = h->asum_ring.as<float>() + slot * asum_slot();
@@ -510,7 +513,7 @@ struct FastPipe {
     }
 
     // role S of `n` consecutive infinite-memory chunks in one persistent launch
-    int launch_s_batch(int n, const float* Snew, const double* u) {
+    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u) {
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
         const int QS = chain_s_tiles(Q);
@@ -534,7 +537,8 @@ struct FastPipe {
         b.alpha_ring = h->alpha_ring.as<float>(); b.alpha_slot = (long)alpha_slot();
         b.asum_ring = h->asum_ring.as<float>(); b.asum_slot = (long)asum_slot();
         b.Sp_in = h->Sp[h->sc].as<float>(); b.Sp_out = h->Sp[h->sc ^ 1].as<float>();
-        b.Snew = Snew; b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
+        b.Snew = Snew; b.snew_ld = h->L * h->dm + h->L * h->H * Q; b.snew_splitk = sk; b.snew_split_stride = ss;
+        b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
         HIP_TRY(hipMemsetAsync(h->sync_words.p, 0, 8 * sizeof(unsigned int), stream));     // arrival counters
         {
             static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
@@ -572,7 +576,7 @@ struct FastPipe {
         u.n_chunks = n; u.slot0 = slot0 % h->ring; u.ring = h->ring;
         u.tab = h->tab_ring.as<int32_t>(); u.tab_slot = (long)tab_slot();
         u.alpha = h->alpha_ring.as<float>(); u.asum = h->asum_ring.as<float>();
-        u.R = R; u.Pnew = Pn; u.splitk = sk; u.split_stride = ss;
+        u.R = R; u.Pnew = Pn; u.p_ld = h->L * h->dm + h->L * h->H * Q; u.splitk = sk; u.split_stride = ss;
         u.B_prev = h->B[h->cur].as<float>(); u.KV_prev = h->KV[h->cur].as<float>();
         u.B_next = h->B[h->cur ^ 1].as<float>(); u.KV_next = h->KV[h->cur ^ 1].as<float>();
         for (int l = 0; l < h->L; ++l) u.bv[l] = pp.bv[l];
@@ -596,6 +600,32 @@ struct FastPipe {
         return INFV_OK;
     }
 };
+
+// fast-path chunk-parallel stage after the pool: new rows R, then ONE GEMM whose output rows are
+// [ V' projection of the row (L*dm) | its scores under the call's pre-multiplied queries (L*H*Q) ]
+int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T, int Q,
+                        const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad) {
+    const Operator& op = inf ? plan.inf : plan.first;
+    const long M = (long)n_chunks * op.rows;
+    const int n_out = h->L * h->H * Q;
+    const long ld = (long)h->L * h->dm + n_out;
+    const int sk_max = 8;
+    const size_t needR = (size_t)(M ? M : 1) * h->d * sizeof(float), needP = (size_t)(M ? M : 1) * ld * sk_max * sizeof(float);
+    if (needR > h->R_ws[set].bytes || (M < 1024 ? needP : needP / sk_max) > h->P_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(h->R_ws[set].reserve(needR));
+    HIP_TRY(h->P_ws[set].reserve(M < 1024 ? needP : needP / sk_max));
+    {
+        Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
+        HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[set].as<float>(), stream));
+    }
+    {
+        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
+        HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+                                    h->P_ws[set].as<float>(), splitk, stream, gemm_pad));
+    }
+    *split_stride = M * ld;
+    return INFV_OK;
+}
 
 // batched new-row scores of `n_chunks` projected chunks of workspace set `set`
 int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const float* q, int Q,
@@ -646,7 +676,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     if (new_doc) infv_ltm_reset(h);
     if (n_chunks == 0) return INFV_OK;
     const int rows_max = plan->first.rows > plan->inf.rows ? plan->first.rows : plan->inf.rows;
-    if (!chain_supported(h->N, h->S, rows_max, plan->inf.tabw)) {
+    if (!chain_supported(h->N, h->S, rows_max, plan->inf.tabw) || (h->L * h->H * Q) % 128 != 0 || (h->L * h->dm) % 128 != 0 ||
+        !uc_supported(h->N, h->d, h->dm, plan->inf.tabw, rows_max)) {
         // shapes the fused chain kernel cannot hold in LDS: per-chunk stage kernels
         for (int c = 0; c < n_chunks; ++c)
             if (int rc = infv_ltm_forward(h, k + c * chunk_k, T, q, Q, proj, u ? u + c * chunk_u : nullptr, 0,
@@ -670,6 +701,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         }
     }
     hipStream_t side = h->side, ucs = h->ucs;
+    // pre-multiplied queries qt = (q/sqrt(dh)) . Wk_h and the bias term cq = q_h . bk_h / sqrt(dh), once per call
+    HIP_TRY(launch_qtilde(q, Q, h->H, h->d, h->L, pp, h->qt_buf.as<float>(), h->cqbuf.as<float>(), stream));
     int c = 0;
     bool uc_pending[3] = {false, false, false};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
@@ -677,9 +710,9 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
         if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks(h, *plan, false, h->kbar_ws.as<float>(), 1, T, pp, 2, &sk, &ss, stream)) return rc;
-        if (int rc = batch_scores(h, plan->first, 1, q, Q, pp, 2, sk, ss, true, stream)) return rc;
-        const StepS st{&plan->first, false, h->Snew_ws[2].as<float>(), nullptr};
+        if (int rc = project_chunks_fast(h, *plan, false, h->kbar_ws.as<float>(), 1, T, Q, pp, 2, &sk, &ss, stream, 0)) return rc;
+        const long v_cols = (long)h->L * h->dm;             // a GEMM output row is [ V' (L*dm) | scores (L*H*Q) ]
+        const StepS st{&plan->first, false, h->P_ws[2].as<float>() + v_cols, nullptr, sk, ss};
         if (int rc = pipe.launch_s(st)) return rc;
         HIP_TRY(hipEventRecord(h->ev_s[2], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[2], 0));
@@ -719,8 +752,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
             Timed t_(h->prof, INFV_KERNEL_POOL, side);
             HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side.as<float>(), (int64_t)nb * T, h->P, h->d, side, kPoolPad));
         }
-        if (int rc = project_chunks(h, *plan, true, h->kbar_side.as<float>(), nb, T, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
-        if (int rc = batch_scores(h, plan->inf, nb, q, Q, pp, set, sks[b], sss[b], false, side)) return rc;
+        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side.as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         return INFV_OK;
     };
@@ -740,11 +772,13 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
-            if (int rc = pipe.launch_s_batch(nb, h->Snew_ws[set].as<float>(), u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
+            if (int rc = pipe.launch_s_batch(nb, h->P_ws[set].as<float>() + (size_t)h->L * h->dm, sks[b], sss[b],
+                                             u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
         } else {
             for (int i = 0; i < nb; ++i) {
-                const StepS st{&plan->inf, true, h->Snew_ws[set].as<float>() + (size_t)i * h->L * h->H * Q * rows,
-                               u ? u + (size_t)(c0 + i) * chunk_u : nullptr};
+                const size_t ld = (size_t)h->L * h->dm + (size_t)h->L * h->H * Q;
+                const StepS st{&plan->inf, true, h->P_ws[set].as<float>() + (size_t)i * rows * ld + (size_t)h->L * h->dm,
+                               u ? u + (size_t)(c0 + i) * chunk_u : nullptr, sks[b], sss[b]};
                 if (int rc = pipe.launch_s(st)) return rc;
                 if (i == 0 && b + 1 < n_batches)
                     if (int rc = stage_parallel(b + 1)) return rc;

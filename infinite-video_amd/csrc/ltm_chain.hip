@@ -173,8 +173,11 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + i * kNT;
-            const int r = e / rows, cc = e - r * rows;
-            sn_reg[i] = (e < kRowsS * rows && r < valid) ? rs.Snew[(tile + r) * rows + cc] : 0.f;
+            const int qr = e & (kRowsS - 1), nr = e >> 3;               // kRowsS == 8
+            float v = 0.f;
+            if (e < kRowsS * rows && qr < valid)
+                for (int k = 0; k < rs.snew_splitk; ++k) v += rs.Snew[(long)nr * rs.snew_ld + tile + qr + k * rs.snew_split_stride];
+            sn_reg[i] = v;
         }
         const float cq_reg = (tid < valid) ? rs.cq[tile + tid] : 0.f;
         const float t_box_val = (tid < N) ? rs.op.box_val[tid] : 0.f;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + i * kNT;
-            if (e < kRowsS * rows) { const int r = e / rows; Snew[r * sn + (e - r * rows)] = sn_reg[i]; }
+            if (e < kRowsS * rows) Snew[(e & (kRowsS - 1)) * sn + (e >> 3)] = sn_reg[i];
         }
         if (tid < kRowsS) cqs[tid] = cq_reg;
         if (tid < N) {

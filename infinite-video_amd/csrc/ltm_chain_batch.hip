@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     const long tile = (((long)l * H + h) * Q + qs * kBRows);
     const int valid = min(kBRows, Q - qs * kBRows);
     const bool writer = (h == 0 && qs == 0);
-    const long tile_snew = (long)a.L * H * Q * rows;     // floats of one step's S'new
+    const long tile_snew = (long)rows * a.snew_ld;       // floats of one step's rows
 
     // ---- one-time set-up: tables, slot table, score tile ----
     {
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int e = tid + k * kBNT;
-        const int r = e / rows, cc = e - r * rows;
-        sn_off[k] = (e < kBRows * rows && r < valid) ? (int)((tile + r) * rows + cc) : -1;
-        sn_lds[k] = (e < kBRows * rows) ? r * sn + cc : -1;
+        const int qr = e & (kBRows - 1), nr = e >> 3;    // kBRows == 8: 8 consecutive columns of S'new per new row
+        sn_off[k] = (e < kBRows * rows && qr < valid) ? (int)((long)nr * a.snew_ld + tile + qr) : -1;
+        sn_lds[k] = (e < kBRows * rows) ? qr * sn + nr : -1;
     }
     const double* u_base = a.u + (long)l * a.S + tid;
     const long u_step = (long)a.L * a.S;
@@ -115,7 +115,14 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     auto prefetch = [&](int i) {
         const float* sb = a.Snew + i * tile_snew;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sn_reg[k] = (sn_off[k] >= 0) ? sb[sn_off[k]] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            float v = 0.f;
+            if (sn_off[k] >= 0) {
+                v = sb[sn_off[k]];
+                for (int x = 1; x < a.snew_splitk; ++x) v += sb[sn_off[k] + x * a.snew_split_stride];
+            }
+            sn_reg[k] = v;
+        }
         if (has_u) u_reg = u_base[i * u_step];
     };
     prefetch(0);

@@ -37,6 +37,13 @@ struct ProjPtrs {
     const float* bv[kMaxLayers];
 };
 
+// Row segments of a GEMM's B operand: output column o in [start[s], start[s+1]) reads row o - start[s] of base[s].
+constexpr int kMaxSegs = 2 * kMaxLayers + 1;
+struct WSegs {
+    const float* base[kMaxSegs];
+    int start[kMaxSegs + 1];
+};
+
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------
 hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad = 0);
 
@@ -47,6 +54,12 @@ hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const Oper
                        hipStream_t stream);
 hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
                           const float* R, float* Pnew, hipStream_t stream, int lds_pad = 0);
+
+// fast path (consolidate): V half only, scores through the pre-multiplied queries qt
+hipError_t launch_project_fast(int M, int d, int dm, int n_layers, int n_out, const ProjPtrs& proj, const float* qt,
+                               const float* R, float* C, int* splitk, hipStream_t stream, int lds_pad = 0);
+hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, const ProjPtrs& proj, float* qt, float* cq,
+                         hipStream_t stream);
 
 // KV[l][n][0][:] = B[l][n] . Wk[l]^T, KV[l][n][1][:] = B[l][n] . Wv[l]^T (no bias).
 hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
@@ -79,7 +92,8 @@ struct ChainRoleS {
     const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;     // [L][128], [L][S], [L][S]  (diagnostics)
     int32_t* tab_out;               // [L][N*tabw] resolved source box of every (box, slot) for role U
-    const float* Sp_prev; float* Sp_next; const float* Snew; const float* cq; const float* w; float w_out;
+    const float* Sp_prev; float* Sp_next; const float* cq; const float* w; float w_out;
+    const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // this chunk's new-row scores: row pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
     float* alpha_out; float* asum_out;
 };
 struct ChainArgs {
@@ -112,7 +126,7 @@ struct ChainBatchArgs {
     int32_t* tab_ring; long tab_slot;
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
-    const float* Snew;              // [n_steps][L][H][Q][rows]
+    const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // [n_steps][rows] rows of pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
     const float* cq; const float* w; float w_out;
     long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
 };
@@ -130,7 +144,7 @@ struct UcArgs {
     const int32_t* tab; long tab_slot;   // [ring] slots of tab_slot ints, each [L][N*tabw]: gather tables written by role S
     const float* alpha;             // [ring][L][H][Q][N]  softmax weights written by role S
     const float* asum;              // [ring][L][H][Q]
-    const float* R; const float* Pnew; int splitk; long split_stride;   // new rows of the launch's first chunk onwards
+    const float* R; const float* Pnew; int p_ld; int splitk; long split_stride;   // new rows of the launch's first chunk onwards; Pnew rows of pitch p_ld: [L][dm] (V' half), split-K slabs
     const float* B_prev; const float* KV_prev; float* B_next; float* KV_next;
     const float* bv[kMaxLayers];
     float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 
 // ======================================================================================
 // 3. projection GEMM (NT):  C[sk][m][o] = sum_{k in split sk} A[m][k] * Wrow(o)[k]
-//    A [M][K] row-major; Wrow(o) = row (o % dm) of wk/wv of layer layer_base + o/(2dm).
+//    A [M][K] row-major; Wrow(o) = row (o % rows_per_seg) of segment o / rows_per_seg (a list of row-major
+//    [rows_per_seg][K] matrices: the layers' Wk / Wv, or the pre-multiplied queries of the fast path).
 //    fp32 MFMA 32x32x2, block tile BM x BN x 32, 4 waves as 2x2, register-staged prefetch.
 // ======================================================================================
 constexpr int kBK = 32;
@@ -108,7 +109,7 @@ constexpr int kLdsStride = kBK + 4;   // +1 access width (16 B) against ds_read_
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
-                                                      ProjPtrs proj, int layer_base, int dm,
+                                                      WSegs segs,
                                                       float* __restrict__ C, int ldc, long split_stride,
                                                       int k_per_split, int y_off) {
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave in each dim
@@ -135,10 +136,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int o = n0 + row0 + 32 * i;
-        const int l = layer_base + o / (2 * dm);
-        const int kv = (o / dm) & 1;
-        const float* w = kv ? proj.wv[l] : proj.wk[l];
-        b_src[i] = w + (long)(o % dm) * K + kbeg + c4 * 4;
+        int seg = 0;
+        while (o >= segs.start[seg + 1]) ++seg;
+        b_src[i] = segs.base[seg] + (long)(o - segs.start[seg]) * K + kbeg + c4 * 4;
     }
 
     floatx4 a_reg[AR], b_reg[BR];
@@ -211,7 +211,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             }
 }
 
-static hipError_t launch_gemm(const float* A, int M, int K, const ProjPtrs& proj, int layer_base, int dm,
+static void segs_clear(WSegs& s) {
+    for (int i = 0; i < kMaxSegs; ++i) s.base[i] = nullptr;
+    for (int i = 0; i <= kMaxSegs; ++i) s.start[i] = 0x7fffffff;
+    s.start[0] = 0;
+}
+static void segs_push(WSegs& s, int& n, const float* base, int rows) {
+    s.base[n] = base;
+    s.start[n + 1] = s.start[n] + rows;
+    ++n;
+}
+static WSegs kv_segs(const ProjPtrs& proj, int layer_base, int n_layers, int dm) {
+    WSegs s;
+    segs_clear(s);
+    int n = 0;
+    for (int l = 0; l < n_layers; ++l) { segs_push(s, n, proj.wk[layer_base + l], dm); segs_push(s, n, proj.wv[layer_base + l], dm); }
+    return s;
+}
+
+static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
                               int n_cols, float* C, int ldc, int splitk, long split_stride,
                               hipStream_t stream, int lds_pad = 0) {
     if (M <= 0) return hipSuccess;
@@ -235,18 +253,18 @@ static hipError_t launch_gemm(const float* A, int M, int K, const ProjPtrs& proj
             if (ny < 1) ny = 1;
             for (int y0 = 0; y0 < gy; y0 += ny) {
                 dim3 grid(gx, (gy - y0 < ny) ? gy - y0 : ny, splitk);
-                hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, proj,
-                                   layer_base, dm, C, ldc, split_stride, k_per_split, y0);
+                hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
+                                   C, ldc, split_stride, k_per_split, y0);
             }
         } else {
             dim3 grid(gx, gy, splitk);
-            hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, proj,
-                               layer_base, dm, C, ldc, split_stride, k_per_split, 0);
+            hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, segs,
+                               C, ldc, split_stride, k_per_split, 0);
         }
     } else {
         dim3 grid((M + 63) / 64, n_cols / 64, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, proj, layer_base,
-                           dm, C, ldc, split_stride, k_per_split, 0);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, segs,
+                           C, ldc, split_stride, k_per_split, 0);
     }
     return hipGetLastError();
 }
@@ -272,7 +290,68 @@ hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const Opera
     const int M = n_chunks * op.rows;
     const int n_cols = n_layers * 2 * dm;
     const int sk = project_splitk(M, d);
-    return launch_gemm(R, M, d, proj, 0, dm, n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream, lds_pad);
+    return launch_gemm(R, M, d, kv_segs(proj, 0, n_layers, dm), n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream, lds_pad);
+}
+
+// Fast path: ONE GEMM for the V' half of the new rows and their scores under the pre-multiplied queries qt:
+//   C[sk][m][0 : L*dm)           = R[m] . Wv[l]^T                       (projection of the new rows, V' half only)
+//   C[sk][m][L*dm : L*dm + n_out) = R[m] . qt[o],  o = (l*H + h)*Q + q   (new-row scores; the K half is never formed)
+hipError_t launch_project_fast(int M, int d, int dm, int n_layers, int n_out, const ProjPtrs& proj, const float* qt,
+                               const float* R, float* C, int* splitk, hipStream_t stream, int lds_pad) {
+    const int n_cols = n_layers * dm + n_out;
+    *splitk = project_splitk(M, d);
+    if (M == 0) return hipSuccess;
+    WSegs s;
+    segs_clear(s);
+    int n = 0;
+    for (int l = 0; l < n_layers; ++l) segs_push(s, n, proj.wv[l], dm);
+    segs_push(s, n, qt, n_out);
+    return launch_gemm(R, M, d, s, n_cols, C, n_cols, *splitk, (long)M * n_cols, stream, lds_pad);
+}
+
+// qt[(l*H + h)*Q + q][:] = sum_e (q[l][q][h*64+e] / sqrt(dh)) * Wk[l][h*64+e][:]   and   cq[(l*H+h)*Q + q] = q_h . bk_h / sqrt(dh)
+// so that  S'new = (q/sqrt(dh)) . (R Wk^T)_h^T = R . qt^T  without projecting the K half of the new rows.
+__global__ __launch_bounds__(256) void qtilde_kernel(const float* __restrict__ q, int Q, int H, int d, ProjPtrs proj,
+                                                     float* __restrict__ qt, float* __restrict__ cq) {
+    extern __shared__ float qs[];                      // [Q][64] scaled query slice of this head
+    const int h = blockIdx.x, l = blockIdx.y;
+    const int dm = H * kHeadSize;
+    const float scale = 1.0f / sqrtf((float)kHeadSize);
+    for (int e = threadIdx.x; e < Q * kHeadSize; e += 256) {
+        const int r = e / kHeadSize, c = e - r * kHeadSize;
+        qs[e] = q[((long)l * Q + r) * dm + h * kHeadSize + c] * scale;
+    }
+    __syncthreads();
+    const float* wk = proj.wk[l] + (long)h * kHeadSize * d;
+    const float* bk = proj.bk[l] + h * kHeadSize;
+    const long row0 = ((long)l * H + h) * Q;
+    if ((int)threadIdx.x < Q) {
+        float c = 0.f;
+        for (int e = 0; e < kHeadSize; ++e) c = fmaf(qs[threadIdx.x * kHeadSize + e], bk[e], c);
+        cq[row0 + threadIdx.x] = c;
+    }
+    for (int k = threadIdx.x; k < d; k += 256) {
+        for (int r0 = 0; r0 < Q; r0 += 32) {
+            float acc[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) acc[r] = 0.f;
+            for (int e = 0; e < kHeadSize; ++e) {
+                const float w = wk[(long)e * d + k];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) acc[r] = fmaf(qs[min(r0 + r, Q - 1) * kHeadSize + e], w, acc[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r)
+                if (r0 + r < Q) qt[(row0 + r0 + r) * d + k] = acc[r];
+        }
+    }
+}
+
+hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, const ProjPtrs& proj, float* qt, float* cq,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(qtilde_kernel, dim3(H, n_layers), dim3(256), (size_t)Q * kHeadSize * sizeof(float), stream, q, Q, H,
+                       d, proj, qt, cq);
+    return hipGetLastError();
 }
 
 // ======================================================================================
@@ -376,7 +455,7 @@ hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_lay
 hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
                             hipStream_t stream) {
     for (int l = 0; l < n_layers; ++l) {
-        hipError_t e = launch_gemm(B + (long)l * N * d, N, d, proj, l, dm, 2 * dm, KV + (long)l * N * 2 * dm,
+        hipError_t e = launch_gemm(B + (long)l * N * d, N, d, kv_segs(proj, l, 1, dm), 2 * dm, KV + (long)l * N * 2 * dm,
                                    2 * dm, 1, 0, stream);
         if (e != hipSuccess) return e;
     }

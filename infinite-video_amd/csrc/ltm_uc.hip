@@ -93,8 +93,8 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
     float as_reg = 0.f;
     // offsets of this thread's prefetch elements relative to the chunk's base (computed once)
     int nr_off[16];                                      // -1: not mine
-    const long nr_chunk = isV ? (long)rows * a.L * 2 * dm : (long)rows * a.d;
-    const float* nr_base = isV ? a.Pnew + (long)l * 2 * dm + dm + col0 : a.R + col0;
+    const long nr_chunk = isV ? (long)rows * a.p_ld : (long)rows * a.d;
+    const float* nr_base = isV ? a.Pnew + (long)l * dm + col0 : a.R + col0;
     const int nsplit = isV ? a.splitk : 1;               // only the projected rows come as split-K partial slabs
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
         nr_off[u] = -1;
         if (e < rows * kUcCols) {
             const int r = e / kUcCols, j = e - r * kUcCols;
-            nr_off[u] = isV ? r * a.L * 2 * dm + j : r * a.d + j;
+            nr_off[u] = isV ? r * a.p_ld + j : r * a.d + j;
         }
     }
     int al_off[4];
