@@ -129,7 +129,7 @@ def test_draw_kernel_equals_torch_multinomial_on_skewed_probs(dev):
         np.testing.assert_array_equal(bins, expect)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[5]], ids=lambda c: c.name)
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[5], CASES[7]], ids=lambda c: c.name)
 def test_consolidate_equals_per_chunk_forward(dev, case):
     """The batched whole-video entry point must reproduce the per-chunk chain."""
     ks, qs, ws = case_inputs(case)
@@ -189,3 +189,72 @@ def test_ragged_query_length_and_errors(dev):
         eng.forward(torch.from_numpy(ks[2]).to(dev), torch.from_numpy(q20[None]).to(dev), projs, None, new_doc=False)
     with pytest.raises(ValueError):
         eng.forward(torch.from_numpy(ks[2][:, :100].copy()).to(dev), torch.from_numpy(q20[None]).to(dev), projs)
+
+
+def test_long_video_many_subbatches_matches_oracle(dev):
+    """26 chunks in sub-batches of 4: the rings of the persistent chain kernel wrap, the workspaces rotate
+    through all three sets, and the UC kernel runs 7 times.  Compared chunk by chunk with the oracle."""
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    N, H, dh, d, P, T, Q, L, Cn = 64, 12, 64, 768, 32, 8, 32, 2, 26
+    eng = LTMEngine(N, H, dh, d, P, tau=0.75, sticky=True, n_layers=L, max_q=Q, device=dev, max_batch_chunks=4)
+    ws = [synth.layer_projections(l, d, H * dh, seed=777) for l in range(L)]
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    qs = np.stack([synth.layer_query(l, Q, H * dh, seed=778) for l in range(L)])
+    u = synth.gibbs_uniforms(Cn, L, seed=779)
+    ks = np.stack([synth.frame_tokens(c, T, P, d, seed=780) for c in range(Cn)])
+    ctx = eng.consolidate(torch.from_numpy(ks).to(dev), torch.from_numpy(qs).to(dev), projs,
+                          torch.from_numpy(u).to(dev), new_doc=True).cpu().numpy()
+    orc = [O.ClosedFormOracle(N, H, dh, 0.75, True, *ws[l], tokens_per_frame=P) for l in range(L)]
+    for c in range(Cn):
+        for l in range(L):
+            ref = orc[l].step(ks[c], qs[l], new_doc=(c == 0), u=u[c, l])
+            np.testing.assert_allclose(ctx[c, l], ref, rtol=0, atol=CTX_TOL, err_msg=f"chunk {c} layer {l}")
+    for l in range(L):
+        bins, idx, probs = eng.last_draw(l)
+        np.testing.assert_array_equal(bins, orc[l].last_bins)          # the 25th consecutive draw still agrees
+        np.testing.assert_allclose(eng.export_state(l)[0].cpu().numpy(), orc[l].B_past, rtol=0, atol=B_TOL)
+        np.testing.assert_allclose(eng.last_scores(l, Q), orc[l].S_prev, rtol=1e-4, atol=2e-5)
+    # the consolidated memory continues correctly on the per-call path (K' re-projected, histogram handed back)
+    k_next = synth.frame_tokens(Cn, T, P, d, seed=780)
+    u_next = synth.gibbs_uniforms(1, L, seed=781)[0]
+    out = eng.forward(torch.from_numpy(k_next).to(dev), torch.from_numpy(qs).to(dev), projs,
+                      torch.from_numpy(u_next).to(dev), new_doc=False).cpu().numpy()
+    for l in range(L):
+        ref = orc[l].step(k_next, qs[l], new_doc=False, u=u_next[l])
+        assert (eng.last_draw(l)[0] == orc[l].last_bins).all()
+        np.testing.assert_allclose(out[l], ref, rtol=0, atol=CTX_TOL)
+
+
+def test_headline_shape_consolidate_in_pieces(dev):
+    """BASELINE headline shape (T=256, N=256, 2 layers): 13 chunks consolidated in one call, in sub-batches of 5,
+    and as two calls (7 + 6 chunks, second one continuing the memory) give the same video as the per-chunk
+    forward chain; ends are checked against the oracle."""
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    N, H, dh, d, P, T, Q, L, Cn = 256, 12, 64, 768, 32, 256, 32, 2, 13
+    ws = [synth.layer_projections(l, d, H * dh, seed=901) for l in range(L)]
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    q = torch.from_numpy(np.stack([synth.layer_query(l, Q, H * dh, seed=902) for l in range(L)])).to(dev)
+    u = torch.from_numpy(synth.gibbs_uniforms(Cn, L, seed=903)).to(dev)
+    k = torch.from_numpy(np.stack([synth.frame_tokens(c, T, P, d, seed=904) for c in range(Cn)])).to(dev)
+    mk = lambda bc: LTMEngine(N, H, dh, d, P, tau=0.75, sticky=True, n_layers=L, max_q=Q, device=dev, max_batch_chunks=bc)
+    a = mk(32)
+    per_chunk = torch.stack([a.forward(k[c], q, projs, u[c], new_doc=(c == 0)) for c in range(Cn)])
+    b = mk(5)
+    whole = b.consolidate(k, q, projs, u, new_doc=True)
+    c2 = mk(28)
+    first = c2.consolidate(k[:7], q, projs, u[:7], new_doc=True)
+    second = c2.consolidate(k[7:], q, projs, u[7:], new_doc=False)
+    np.testing.assert_allclose(whole.cpu().numpy(), per_chunk.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(torch.cat([first, second]).cpu().numpy(), per_chunk.cpu().numpy(), rtol=0, atol=2e-5)
+    for l in range(L):
+        np.testing.assert_array_equal(b.last_draw(l)[0], a.last_draw(l)[0])
+        np.testing.assert_array_equal(c2.last_draw(l)[0], a.last_draw(l)[0])
+        np.testing.assert_allclose(b.export_state(l)[0].cpu().numpy(), a.export_state(l)[0].cpu().numpy(), rtol=0, atol=1e-5)
+    # oracle on the first two chunks of layer 0 (the full chain at this shape costs ~1 s per chunk on the CPU)
+    orc = O.ClosedFormOracle(N, H, dh, 0.75, True, *ws[0], tokens_per_frame=P)
+    kc, qc, uc = k.cpu().numpy(), q.cpu().numpy(), u.cpu().numpy()
+    for c in range(2):
+        ref = orc.step(kc[c], qc[0], new_doc=(c == 0), u=uc[c, 0])
+        np.testing.assert_allclose(whole[c, 0].cpu().numpy(), ref, rtol=0, atol=CTX_TOL)
