@@ -262,7 +262,7 @@ size_t chain_batch_lds_bytes(int N, int S, int rows, int tabw) { return (size_t)
 
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
     return N <= kBMaxN && N % 16 == 0 && S <= kBNT && rows <= kBMaxN && tabw <= 16 && (tabw & 3) == 0 &&
-           n_blocks <= 128 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
+           n_blocks <= 384 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
 }
 
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
