@@ -122,6 +122,7 @@ struct infv_ltm_s {
     bool has_memory = false;
     int lastQ = 0;                     // query length of the last attend
     bool last_fast = false;            // last step ran in the fused chain kernel (scores = Sp + cq)
+    bool k_stale = false;              // the K' half of KV is out of date (the fast path does not maintain it)
     int parts = 0;                     // row count of bin_part per layer, set by the last attend
     DeviceBuf bin_part[2];             // [L][max_parts][n_bins]  sticky partials (ping-pong in the fast path)
     int pc = 0;                        // which bin_part holds the latest partials
@@ -396,6 +397,7 @@ int infv_ltm_reset(infv_ltm_handle h) {
     if (int rc = check_handle(h)) return rc;
     h->has_memory = false;
     h->parts = 0;
+    h->k_stale = false;
     return INFV_OK;
 }
 
@@ -421,6 +423,8 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     if (int rc = find_plan(h, T, &plan)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const ProjPtrs pp = make_proj(proj, h->L);
+    if (h->k_stale && h->has_memory)
+        if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
     int sk = 1; long ss = 0;
     if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, 0, &sk, &ss, stream)) return rc;
     return chain_step(h, *plan, h->R_ws[0].as<float>(), h->P_ws[0].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
@@ -722,6 +726,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         c = 1;
     } else {
         // continue an existing memory: bias-free scores of the current K' rows under this query
+        if (h->k_stale)
+            if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
         Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
         HIP_TRY(launch_new_scores(q, Q, h->H, h->L, 1, h->N, h->KV[h->cur].as<float>(), 0, 2L * h->dm,
                                   (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
@@ -800,7 +806,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                                    h->bin_part[h->pc].as<float>(), stream));
         h->parts = 1;
     }
-    return infv_ltm_reproject(h, proj, stream_);
+    h->k_stale = true;                                        // K' is re-projected from B on demand (per-call path, continuation)
+    return INFV_OK;
 }
 
 }  // extern "C"
@@ -828,6 +835,7 @@ int infv_ltm_reproject(infv_ltm_handle h, const infv_ltm_proj* proj, void* strea
     const ProjPtrs pp = make_proj(proj, h->L);
     HIP_TRY(launch_reproject(h->B[h->cur].as<float>(), h->N, h->d, h->dm, h->L, pp, h->KV[h->cur].as<float>(),
                              static_cast<hipStream_t>(stream_)));
+    h->k_stale = false;
     return INFV_OK;
 }
 
