@@ -774,12 +774,16 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
         const long slot0 = pipe.counter;
+        static const bool serial = getenv("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
+        if (serial) { HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
         if (persistent) {
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
+            if (serial) HIP_TRY(hipStreamSynchronize(side));
             if (int rc = pipe.launch_s_batch(nb, h->P_ws[set].as<float>() + (size_t)h->L * h->dm, sks[b], sss[b],
                                              u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
+            if (serial) HIP_TRY(hipStreamSynchronize(stream));
         } else {
             for (int i = 0; i < nb; ++i) {
                 const size_t ld = (size_t)h->L * h->dm + (size_t)h->L * h->H * Q;

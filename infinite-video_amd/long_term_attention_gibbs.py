@@ -22,6 +22,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -31,8 +32,9 @@ from .basis_maps import NB_SAMPLES
 from .engine import LTMEngine
 
 # one-entry cache of pooled frames: the Q-former calls every layer's LTM with the same
-# encoder_hidden_states, so the frame tokens (25 MB at the headline shape) are read once per chunk
-_pool_cache = {"key": None, "kbar": None}
+# encoder_hidden_states tensor OBJECT, so the frame tokens (25 MB at the headline shape) are read once per
+# chunk.  Keyed by a weak reference to that object (an address could be recycled by the allocator) + its version.
+_pool_cache = {"ref": None, "version": -1, "kbar": None}
 
 
 class LongTermAttention(nn.Module):
@@ -127,6 +129,32 @@ class LongTermAttention(nn.Module):
         if self._engine is not None:
             self._engine.reset()
 
+    # ------------------------------------------------------------------ persistence of the consolidated memory
+    def memory_state(self) -> Optional[dict]:
+        """Everything needed to continue the document later or elsewhere: the coefficient matrix ``B_past``
+        and the sticky bin masses derived from the last scores (the reference never serialises its LTM state;
+        SURVEY.md section 5).  ``None`` if the memory is empty.  Tensors are on the CPU."""
+        if self._engine is None or not self._engine.has_memory:
+            return None
+        B, mass = self._engine.export_state(0)
+        return {"B_past": B.cpu(), "bin_mass": mass.cpu(), "num_basis": self.attn_num_basis, "tau": self.tau,
+                "sticky": bool(self.sticky_memories), "version": 1}
+
+    def load_memory_state(self, state: Optional[dict], device) -> None:
+        """Inverse of :meth:`memory_state` (``None`` clears the memory).  The projected memory is rebuilt
+        from ``B_past`` with the current key/value weights."""
+        device = torch.device(device)
+        if state is None:
+            if self._engine is not None:
+                self._engine.reset()
+            return
+        if state.get("version") != 1 or state["num_basis"] != self.attn_num_basis:
+            raise ValueError("memory state does not match this LongTermAttention")
+        eng = self._get_engine(device, 32)
+        eng.reset()
+        eng.import_state(0, state["B_past"].to(device=device, dtype=torch.float32).contiguous(),
+                         state["bin_mass"].to(device=device, dtype=torch.float32).contiguous(), self._proj(device))
+
     # ------------------------------------------------------------------ forward
     def forward(self, k, q, new_doc, layer_n):
         """k [1, T*P, d] frame tokens, q [1, Q, H*dh] -> [1, Q, H*dh]   (reference :288-346)."""
@@ -150,12 +178,12 @@ class LongTermAttention(nn.Module):
         kf = k[0]
         if kf.dtype != torch.float32 or not kf.is_contiguous():
             kf = kf.float().contiguous()
-        key = (k.data_ptr(), k._version, tuple(k.shape), str(k.device), str(k.dtype))
-        if _pool_cache["key"] == key:
+        ref = _pool_cache["ref"]
+        if ref is not None and ref() is k and _pool_cache["version"] == k._version:
             kbar = _pool_cache["kbar"]
         else:
             kbar = eng.pool(kf)                           # :304
-            _pool_cache["key"], _pool_cache["kbar"] = key, kbar
+            _pool_cache["ref"], _pool_cache["version"], _pool_cache["kbar"] = weakref.ref(k), k._version, kbar
         u = None
         if eng.has_memory and self.sticky_memories:
             # torch.multinomial on the CPU path draws its uniforms from the global CPU generator

@@ -102,3 +102,27 @@ def test_install_redirects_reference_import_site():
         assert mod.LongTermAttention is LongTermAttention
     finally:
         sys.modules.pop("InfVideoLLaMA.models.long_term_attention_gibbs", None)
+
+
+def test_memory_state_roundtrip_through_cpu():
+    """memory_state()/load_memory_state(): a second module continues the document exactly where the first stopped."""
+    dev = torch.device("cuda:0")
+    case = CASES[0]
+    ks, qs, ws = case_inputs(case)
+    a, b = _module(case, ws, 0, dev), _module(case, ws, 0, dev)
+    q = torch.from_numpy(qs[0]).unsqueeze(0).to(dev)
+    assert a.memory_state() is None
+    with torch.no_grad():
+        for c in range(3):
+            torch.manual_seed(call_seed(case, c, 0))
+            a(torch.from_numpy(ks[c]).unsqueeze(0).to(dev), q, new_doc=(c == 0), layer_n=0)
+        state = a.memory_state()
+        assert state["B_past"].device.type == "cpu" and state["B_past"].shape == (case.N, case.d)
+        b.load_memory_state(state, dev)
+        k3 = torch.from_numpy(ks[3]).unsqueeze(0).to(dev)
+        torch.manual_seed(call_seed(case, 3, 0)); ya = a(k3, q, new_doc=False, layer_n=0)
+        torch.manual_seed(call_seed(case, 3, 0)); yb = b(k3, q, new_doc=False, layer_n=0)
+    np.testing.assert_array_equal(a._engine.last_draw(0)[0], b._engine.last_draw(0)[0])
+    np.testing.assert_allclose(ya.cpu().numpy(), yb.cpu().numpy(), rtol=0, atol=2e-5)
+    g = load_golden(case)
+    np.testing.assert_allclose(yb[0].cpu().numpy(), g["c3_l0_ctx"], rtol=0, atol=CTX_TOL)
