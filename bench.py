@@ -183,7 +183,8 @@ def main():
         "kernel": "pool_frames_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "achieved_alone": alone_gbs, "frac_alone": alone_gbs / HBM_PEAK_GBS,
-        "note": "achieved = in situ, while the pool shares the chip with the chain and UC streams; achieved_alone = same kernel, same launch size, nothing else running",
+        "note": "achieved = in situ (512-thread instantiation, LDS-padded to 1 WG/CU), while the pool shares the chip with the chain and UC streams; "
+                "achieved_alone = same launch size through infv_ltm_pool (256-thread instantiation, no pad), nothing else running",
         "launches": pool_n, "avg_launch_ms": pool_ms / max(pool_n, 1),
         "bytes_per_full_launch": min(args.batch_chunks, c_local) * BYTES_POOL_PER_CHUNK,
         "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
