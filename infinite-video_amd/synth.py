@@ -63,3 +63,47 @@ def gibbs_uniforms(n_chunks: int, n_layers: int, seed: int = SEED_U, nb_samples:
             u[c, l] = torch.rand(nb_samples, dtype=torch.float64, generator=gen)
             torch.rand(nb_samples, dtype=torch.float64, generator=gen)
     return u.numpy()
+
+
+SEED_QF = 777
+
+
+def video_qformer_weights(n_layers: int = 2, hidden: int = 768, inter: int = 3072, enc_width: int = 768,
+                          n_query: int = 32, proj_out: int = 4096, seed: int = SEED_QF) -> dict:
+    """Random-init weights of the video Q-former + ``llama_proj`` under the reference's own
+    state-dict names (infinityqa.py:195-209 builds it; Qformer.py:115-470 names the parameters):
+    ``bert.embeddings.LayerNorm.*``, ``bert.encoder.layer.{l}.attention.{self.query|self.key|self.value|output.dense|
+    output.LayerNorm}.*``, ``...crossattention...``, ``...intermediate_query.dense.*``, ``...output_query.{dense|LayerNorm}.*``,
+    plus ``video_query_tokens`` [1, n_query, hidden] and ``llama_proj.{weight,bias}``.
+    Linear weights ~ N(0, 0.02) (BERT initializer_range), biases ~ N(0, 0.02), LayerNorm gamma ~ 1 + N(0, 0.1),
+    beta ~ N(0, 0.1) -- non-trivial on purpose so every term of the path is exercised."""
+    out, idx = {}, [0]
+
+    def nrm(shape, scale, shift=0.0):
+        a = _normal(seed, idx[0], shape, scale)
+        idx[0] += 1
+        return a + np.float32(shift) if shift else a
+
+    def linear(name, n_out, n_in):
+        out[name + ".weight"] = nrm((n_out, n_in), 0.02)
+        out[name + ".bias"] = nrm((n_out,), 0.02)
+
+    def lnorm(name, n):
+        out[name + ".weight"] = nrm((n,), 0.1, 1.0)
+        out[name + ".bias"] = nrm((n,), 0.1)
+
+    out["video_query_tokens"] = nrm((1, n_query, hidden), 0.02)
+    lnorm("bert.embeddings.LayerNorm", hidden)
+    for l in range(n_layers):
+        p = f"bert.encoder.layer.{l}."
+        for att, kv_in in (("attention", hidden), ("crossattention", enc_width)):
+            linear(p + att + ".self.query", hidden, hidden)
+            linear(p + att + ".self.key", hidden, kv_in)
+            linear(p + att + ".self.value", hidden, kv_in)
+            linear(p + att + ".output.dense", hidden, hidden)
+            lnorm(p + att + ".output.LayerNorm", hidden)
+        linear(p + "intermediate_query.dense", inter, hidden)
+        linear(p + "output_query.dense", hidden, inter)
+        lnorm(p + "output_query.LayerNorm", hidden)
+    linear("llama_proj", proj_out, hidden)
+    return out
