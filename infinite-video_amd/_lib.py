@@ -50,6 +50,31 @@ class Proj(C.Structure):
     _fields_ = [("wk", C.c_void_p), ("bk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p)]
 
 
+class VqfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_layers", "n_heads", "hidden", "inter", "enc_width", "tokens_per_frame", "n_query", "proj_out",
+        "nb_samples")] + [("alpha", C.c_float), ("ln_eps", C.c_float)]
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class LayerNorm(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class VqfLayer(C.Structure):
+    _fields_ = [("self_q", Linear), ("self_k", Linear), ("self_v", Linear), ("self_o", Linear), ("self_ln", LayerNorm),
+                ("x_q", Linear), ("x_k", Linear), ("x_v", Linear), ("x_o", Linear), ("x_ln", LayerNorm),
+                ("ffn_in", Linear), ("ffn_out", Linear), ("ffn_ln", LayerNorm)]
+
+
+class VqfWeights(C.Structure):
+    _fields_ = [("query_tokens", C.c_void_p), ("emb_ln", LayerNorm), ("layer", VqfLayer * MAX_LAYERS),
+                ("llama_proj", Linear)]
+
+
 class LTMError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"infv_ltm error {code}: {msg}")
@@ -79,6 +104,15 @@ _SIGNATURES = {
     "infv_ltm_set_probs": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
     "infv_ltm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    # include/infv_vqf.h
+    "infv_vqf_create": (C.c_int, [C.POINTER(VqfConfig), C.POINTER(C.c_void_p)]),
+    "infv_vqf_destroy": (C.c_int, [C.c_void_p]),
+    "infv_vqf_short_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Linear),
+                                           C.POINTER(Linear), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "infv_vqf_encode_chunk": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
+                                        C.POINTER(VqfWeights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "infv_vqf_mean": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 KERNELS = ("pool", "rows", "project", "draw", "update", "attend", "scores", "chain", "uc")
 

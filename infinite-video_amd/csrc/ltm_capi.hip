@@ -1,6 +1,7 @@
 // C ABI of libinfv_ltm.so (include/infv_ltm.h): handle, plans, state and the launch sequences.
 #include "../../include/infv_ltm.h"
 #include "ltm_internal.h"
+#include "capi_common.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -12,8 +13,7 @@
 
 using namespace infv;
 
-namespace {
-
+namespace infv {
 thread_local char g_err[512] = "";
 
 int fail(int code, const char* fmt, ...) {
@@ -23,34 +23,9 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace infv
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(INFV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-struct DeviceBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DeviceBuf() { if (p) (void)hipFree(p); }
-    hipError_t reserve(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-template <class T>
-hipError_t upload(DeviceBuf& buf, const T* host, size_t n) {
-    hipError_t e = buf.reserve((n ? n : 1) * sizeof(T));
-    if (e != hipSuccess || n == 0) return e;
-    return hipMemcpy(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice);
-}
+namespace {
 
 struct Operator {
     int rows = 0;

@@ -1,0 +1,53 @@
+// Internal interface between the video Q-former C ABI (vqf_capi.hip) and its gfx950 kernels (vqf_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace infv {
+
+constexpr int kQfMaxSeg = 4;
+
+// C[z][m][o] (+)= sum_k A[b][m][k] * Bop[b][k][o]   for z = b * splitk + s, k in split s.
+//   NT: Bop[k][o] = B[o][k]  (B rows are output columns; up to kQfMaxSeg row segments of seg_rows rows each)
+//   NN: Bop[k][o] = B[k][o]
+struct QfGemm {
+    const float* A;  long lda;  long strideA;      // per-batch stride (0 = shared)
+    const float* B[kQfMaxSeg];  long ldb;  long strideB;  int seg_rows;
+    float* C;  long ldc;  long strideC;  long split_stride;
+    int M, N, k_per_split, splitk, nbatch;
+};
+hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream);
+int qf_pick_splitk(int M, int N, int K, int nbatch);
+
+enum QfAct { QF_ACT_NONE = 0, QF_ACT_GELU = 1 };
+// out[m][:] = LN?( act( sum_s parts[s][m][:] + bias ) + residual[m % res_rows] )    one workgroup per row
+struct QfEpilogue {
+    const float* parts;  int nsplit;  long split_stride;  long ld_in;
+    const float* bias[kQfMaxSeg];  int seg_cols;               // bias segment s covers columns [s*seg_cols, (s+1)*seg_cols); nullptr = none
+    int act;
+    const float* residual;  long ld_res;  int res_rows;        // residual row = m % res_rows (broadcast of a shared [res_rows] block)
+    const float* gamma;  const float* beta;  float eps;        // LayerNorm if gamma != nullptr
+    float* out;  long ld_out;
+    int M, width;
+};
+hipError_t launch_qf_epilogue(const QfEpilogue& e, hipStream_t stream);
+
+// qkv [nb*Q][3*hidden] (bias applied) -> ctx [nb*Q][hidden]; softmax(q k^T / sqrt(dh)) v per head, Q <= 32, dh = 64
+hipError_t launch_qf_self_attention(const float* qkv, int nb, int Q, int H, float* ctx, hipStream_t stream);
+
+// qt[b][h*Q + q][j] = sum_e xq[b][q][h*64 + e] / sqrt(64) * Wk[h*64 + e][j]
+hipError_t launch_qf_qtilde(const float* xq, int nb, int Q, int H, int d, const float* wk, float* qt, hipStream_t stream);
+
+// in-place softmax of rows [n_rows][len] (leading dimension ld)
+hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipStream_t stream);
+
+// merged[b][q][h*64+e] = alpha * (sum_j O[b][h*Q+q][j] * Wv[h*64+e][j] + bv[h*64+e]) + beta * along[b][q][h*64+e]
+// O = sum of nsplit slabs (split_stride apart); along may be nullptr (beta ignored).
+hipError_t launch_qf_headproj_merge(const float* Oparts, int nsplit, long split_stride, int nb, int Q, int H, int d,
+                                    const float* wv, const float* bv, const float* along, float alpha, float beta,
+                                    float* merged, hipStream_t stream);
+
+// out[m][:] = mean over nb of in[b][m][:]
+hipError_t launch_qf_mean(const float* in, int nb, long n, float* out, hipStream_t stream);
+
+}  // namespace infv

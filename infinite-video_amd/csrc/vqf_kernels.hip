@@ -1,0 +1,441 @@
+// gfx950 kernels of the video Q-former path around the LTM (rows a11/a12, next-row f1):
+// the short-term cross-attention over a chunk's frame tokens, re-associated so that the frame tokens are only
+// ever multiplied by [H*Q x d] operands (never projected to K/V), plus the small query-token blocks of the
+// BERT layer (linear + bias + GELU/residual/LayerNorm, 32-token self-attention).
+//
+// Reference arithmetic restated (infty-Video-LLaMA/InfVideoLLaMA/models/Qformer.py):
+//   scores  = (q W_q)_h (k W_k,h^T + b_k,h)^T / sqrt(dh)      :232,244,278
+//           = qt_h k^T + const(row)        with qt_h = (q_h / sqrt(dh)) W_k,h ; the row constant cancels in the softmax
+//   ctx_h   = softmax(scores) (k W_v,h^T + b_v,h)              :284,298
+//           = (softmax(scores) k) W_v,h^T + b_v,h             (rows of the softmax sum to one)
+// so one chunk costs two [H*Q x d x T*P] contractions (4.8 GFLOP each at the headline shape) instead of the
+// 2 x 9.7 GFLOP K/V projections plus the attention itself.
+#include "vqf_internal.h"
+#include "ltm_device.h"
+
+namespace infv {
+
+namespace {
+constexpr int kBK = 32;
+constexpr int kStride = kBK + 4;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM, 32x32x2 tiles, 4 waves (2x2), LDS-staged operands with register prefetch of the next k-tile.
+// ------------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool NN>
+__global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    __shared__ float As[BM * kStride];
+    __shared__ float Bs[BN * kStride];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int b = blockIdx.z / g.splitk, s = blockIdx.z - b * g.splitk;
+    const int kbeg = s * g.k_per_split;
+    const int ntiles = g.k_per_split / kBK;
+    const float* A = g.A + (long)b * g.strideA;
+    float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
+
+    const int c4 = tid & 7, row0 = tid >> 3;
+    const float* a_src[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        a_src[i] = (m < g.M) ? A + (long)m * g.lda + kbeg + c4 * 4 : nullptr;
+    }
+    // B staging: NT -> same map as A (rows of B are output columns); NN -> thread = (4 output columns, one k row)
+    constexpr int KT = 256 / (BN / 4);               // NN: threads along k per column group
+    const int cn = tid / KT, kr = tid - cn * KT;
+    const float* b_src[BR];
+    long b_step;
+    if (!NN) {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int o = n0 + row0 + 32 * i;
+            if (o < g.N) {
+                const int seg = o / g.seg_rows;
+                b_src[i] = g.B[seg] + (long)b * g.strideB + (long)(o - seg * g.seg_rows) * g.ldb + kbeg + c4 * 4;
+            } else {
+                b_src[i] = nullptr;
+            }
+        }
+        b_step = kBK;
+    } else {
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            b_src[i] = (n0 + 4 * cn < g.N)
+                           ? g.B[0] + (long)b * g.strideB + (long)(kbeg + kr + KT * i) * g.ldb + n0 + 4 * cn
+                           : nullptr;
+        b_step = (long)kBK * g.ldb;
+    }
+
+    floatx4 a_reg[AR], b_reg[BR];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            a_reg[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + (long)t * kBK) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            b_reg[i] = b_src[i] ? *reinterpret_cast<const floatx4*>(b_src[i] + t * b_step) : floatx4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<floatx4*>(&As[(row0 + 32 * i) * kStride + c4 * 4]) = a_reg[i];
+        if (!NN) {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                *reinterpret_cast<floatx4*>(&Bs[(row0 + 32 * i) * kStride + c4 * 4]) = b_reg[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * cn + j) * kStride + kr + KT * i] = b_reg[i][j];
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, kk = lane >> 5;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
+        floatx4 af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                af[i][v] = *reinterpret_cast<const floatx4*>(&As[(wm * (BM / 2) + i * 32 + li) * kStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                bf[j][v] = *reinterpret_cast<const floatx4*>(&Bs[(wn * (BN / 2) + j * 32 + li) * kStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int st = 0; st < 16; ++st)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st >> 2][st & 3], bf[j][st >> 2][st & 3],
+                                                                     acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int o = n0 + wn * (BN / 2) + j * 32 + li;
+                if (m < g.M && o < g.N) C[(long)m * g.ldc + o] = acc[i][j][r];
+            }
+}
+
+static bool qf_big_tiles(int M, int N) { return M >= 128 && N >= 128; }
+
+int qf_pick_splitk(int M, int N, int K, int nbatch) {
+    const int bm = qf_big_tiles(M, N) ? 128 : 64;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * nbatch;
+    int sk = 1;
+    while (tiles * sk < 192 && sk < 16 && K % (kBK * sk * 2) == 0) sk *= 2;
+    return sk;
+}
+
+hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0) return hipSuccess;
+    if (g.k_per_split % kBK != 0 || g.k_per_split <= 0) return hipErrorInvalidValue;
+    if (nn && (g.N % 4 != 0)) return hipErrorInvalidValue;
+    const bool big = qf_big_tiles(g.M, g.N);
+    const int bm = big ? 128 : 64;
+    dim3 grid((g.M + bm - 1) / bm, (g.N + bm - 1) / bm, g.nbatch * g.splitk);
+    if (big) {
+        if (nn) hipLaunchKernelGGL((qf_gemm_kernel<128, 128, true>), grid, dim3(256), 0, stream, g);
+        else    hipLaunchKernelGGL((qf_gemm_kernel<128, 128, false>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (nn) hipLaunchKernelGGL((qf_gemm_kernel<64, 64, true>), grid, dim3(256), 0, stream, g);
+        else    hipLaunchKernelGGL((qf_gemm_kernel<64, 64, false>), grid, dim3(256), 0, stream, g);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row epilogue: split-K reduction + bias + GELU + residual + LayerNorm (Qformer.py:322-326, 401-403, 415-418).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kEpiMaxPerThread = 16;      // width <= 4096
+
+__global__ __launch_bounds__(256) void qf_epilogue_kernel(QfEpilogue e) {
+    __shared__ double scratch[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float x[kEpiMaxPerThread];
+    const float* in = e.parts + (long)m * e.ld_in;
+    const float* res = e.residual ? e.residual + (long)(m % e.res_rows) * e.ld_res : nullptr;
+#pragma unroll
+    for (int i = 0; i < kEpiMaxPerThread; ++i) {
+        const int c = tid + 256 * i;
+        float v = 0.f;
+        if (c < e.width) {
+            for (int s = 0; s < e.nsplit; ++s) v += in[(long)s * e.split_stride + c];
+            const int seg = c / e.seg_cols;
+            if (e.bias[seg]) v += e.bias[seg][c - seg * e.seg_cols];
+            if (e.act == QF_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (res) v += res[c];
+        }
+        x[i] = v;
+    }
+    if (e.gamma) {
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < kEpiMaxPerThread; ++i) sum += (tid + 256 * i < e.width) ? (double)x[i] : 0.0;
+        const float mean = (float)(block_sum<256>(sum, scratch) / e.width);
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < kEpiMaxPerThread; ++i) {
+            const float dlt = x[i] - mean;
+            sq += (tid + 256 * i < e.width) ? (double)dlt * dlt : 0.0;
+        }
+        const float var = (float)(block_sum<256>(sq, scratch) / e.width);
+        const float rstd = 1.0f / sqrtf(var + e.eps);
+#pragma unroll
+        for (int i = 0; i < kEpiMaxPerThread; ++i) {
+            const int c = tid + 256 * i;
+            if (c < e.width) x[i] = (x[i] - mean) * rstd * e.gamma[c] + e.beta[c];
+        }
+    }
+    float* out = e.out + (long)m * e.ld_out;
+#pragma unroll
+    for (int i = 0; i < kEpiMaxPerThread; ++i) {
+        const int c = tid + 256 * i;
+        if (c < e.width) out[c] = x[i];
+    }
+}
+
+hipError_t launch_qf_epilogue(const QfEpilogue& e, hipStream_t stream) {
+    if (e.M <= 0) return hipSuccess;
+    if (e.width > 256 * kEpiMaxPerThread || e.seg_cols <= 0 || (e.width + e.seg_cols - 1) / e.seg_cols > kQfMaxSeg)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_epilogue_kernel, dim3(e.M), dim3(256), 0, stream, e);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Self-attention over the (<= 32) query tokens of one chunk, one workgroup per (head, chunk)   (Qformer.py:238-301)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qf_self_attention_kernel(const float* __restrict__ qkv, int Q, int H,
+                                                                float* __restrict__ ctx) {
+    __shared__ float qs[32][65], ks[32][65], vs[32][65], ps[32][33];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int hidden = H * 64;
+    const float* base = qkv + (long)b * Q * 3 * hidden;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const bool ok = r < Q;
+        const float* row = base + (long)r * 3 * hidden + h * 64 + c;
+        qs[r][c] = ok ? row[0] * 0.125f : 0.f;
+        ks[r][c] = ok ? row[hidden] : 0.f;
+        vs[r][c] = ok ? row[2 * hidden] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid >> 3, g8 = tid & 7;
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kc = g8 * 4 + j;
+        float a = 0.f;
+        for (int c = 0; c < 64; ++c) a = fmaf(qs[r][c], ks[kc][c], a);
+        sc[j] = (kc < Q) ? a : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+    for (int off = 1; off < 8; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+    for (int off = 1; off < 8; off <<= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ps[r][g8 * 4 + j] = sc[j] * inv;
+    __syncthreads();
+    if (r < Q) {
+        float* out = ctx + ((long)b * Q + r) * hidden + h * 64 + g8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+            for (int j = 0; j < 32; ++j) a = fmaf(ps[r][j], vs[j][g8 * 8 + e], a);
+            out[e] = a;
+        }
+    }
+}
+
+hipError_t launch_qf_self_attention(const float* qkv, int nb, int Q, int H, float* ctx, hipStream_t stream) {
+    if (Q > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_self_attention_kernel, dim3(H, nb), dim3(256), 0, stream, qkv, Q, H, ctx);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Pre-multiplied cross-attention queries: qt[b][h*Q+q][j] = sum_e xq[b][q][h*64+e]/8 * Wk[h*64+e][j]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict__ xq, int Q, int H, int d,
+                                                        const float* __restrict__ wk, float* __restrict__ qt) {
+    __shared__ __attribute__((aligned(16))) float qs[32 * 64];
+    const int h = blockIdx.x, b = blockIdx.z, tid = threadIdx.x;
+    const int hidden = H * 64;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        qs[e] = (r < Q) ? xq[((long)b * Q + r) * hidden + h * 64 + c] * 0.125f : 0.f;
+    }
+    __syncthreads();
+    const int j = blockIdx.y * 256 + tid;
+    if (j >= d) return;
+    float w[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) w[e] = wk[(long)(h * 64 + e) * d + j];
+    float* out = qt + ((long)b * H * Q + (long)h * Q) * d + j;
+    for (int r = 0; r < Q; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < 16; ++e4) {
+            const floatx4 qv = *reinterpret_cast<const floatx4*>(&qs[r * 64 + e4 * 4]);
+            a = fmaf(qv[0], w[e4 * 4 + 0], a);
+            a = fmaf(qv[1], w[e4 * 4 + 1], a);
+            a = fmaf(qv[2], w[e4 * 4 + 2], a);
+            a = fmaf(qv[3], w[e4 * 4 + 3], a);
+        }
+        out[(long)r * d] = a;
+    }
+}
+
+hipError_t launch_qf_qtilde(const float* xq, int nb, int Q, int H, int d, const float* wk, float* qt,
+                            hipStream_t stream) {
+    if (Q > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_qtilde_kernel, dim3(H, (d + 255) / 256, nb), dim3(256), 0, stream, xq, Q, H, d, wk, qt);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row softmax in place (Qformer.py:284); rows are L2-resident, so three passes cost little.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qf_softmax_rows_kernel(float* __restrict__ S, int len, long ld) {
+    __shared__ float red[4];
+    float* row = S + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int c = tid * 4; c < len; c += 1024) {
+        const floatx4 v = *reinterpret_cast<const floatx4*>(row + c);
+        mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid * 4; c < len; c += 1024) {
+        floatx4 v = *reinterpret_cast<const floatx4*>(row + c);
+        v[0] = expf(v[0] - mx); v[1] = expf(v[1] - mx); v[2] = expf(v[2] - mx); v[3] = expf(v[3] - mx);
+        *reinterpret_cast<floatx4*>(row + c) = v;
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = tid * 4; c < len; c += 1024) {
+        floatx4 v = *reinterpret_cast<const floatx4*>(row + c);
+        v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+        *reinterpret_cast<floatx4*>(row + c) = v;
+    }
+}
+
+hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipStream_t stream) {
+    if (len % 4 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Per-head value projection of the attention-weighted token means + bias + memory merge (Qformer.py:298-304)
+// grid (H, 4, nb): workgroup = 16 of a head's 64 output columns, all Q rows; j tiled by 128 through LDS.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qf_headproj_merge_kernel(const float* __restrict__ Oparts, int nsplit,
+                                                                long split_stride, int Q, int H, int d,
+                                                                const float* __restrict__ wv, const float* __restrict__ bv,
+                                                                const float* __restrict__ along, float alpha, float beta,
+                                                                float* __restrict__ merged) {
+    __shared__ float Ws[16][129];
+    __shared__ float Os[32][129];
+    const int h = blockIdx.x, eb = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int hidden = H * 64;
+    const int e = tid & 15, q0 = tid >> 4;                   // outputs (q0, e) and (q0 + 16, e)
+    const float* O = Oparts + ((long)b * H * Q + (long)h * Q) * d;
+    const float* W = wv + (long)(h * 64 + eb * 16) * d;
+    float a0 = 0.f, a1 = 0.f;
+    for (int j0 = 0; j0 < d; j0 += 128) {
+        for (int i = tid; i < 16 * 128; i += 256) {
+            const int r = i >> 7, c = i & 127;
+            Ws[r][c] = (j0 + c < d) ? W[(long)r * d + j0 + c] : 0.f;
+        }
+        for (int i = tid; i < 32 * 128; i += 256) {
+            const int r = i >> 7, c = i & 127;
+            float v = 0.f;
+            if (r < Q && j0 + c < d)
+                for (int s = 0; s < nsplit; ++s) v += O[(long)s * split_stride + (long)r * d + j0 + c];
+            Os[r][c] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < 128; ++c) {
+            const float w = Ws[e][c];
+            a0 = fmaf(Os[q0][c], w, a0);
+            a1 = fmaf(Os[q0 + 16][c], w, a1);
+        }
+        __syncthreads();
+    }
+    const int col = h * 64 + eb * 16 + e;
+    const float bias = bv[col];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = q0 + 16 * k;
+        if (q >= Q) continue;
+        const long o = ((long)b * Q + q) * hidden + col;
+        float v = (k ? a1 : a0) + bias;
+        if (along) v = alpha * v + beta * along[o];
+        merged[o] = v;
+    }
+}
+
+hipError_t launch_qf_headproj_merge(const float* Oparts, int nsplit, long split_stride, int nb, int Q, int H, int d,
+                                    const float* wv, const float* bv, const float* along, float alpha, float beta,
+                                    float* merged, hipStream_t stream) {
+    if (Q > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_headproj_merge_kernel, dim3(H, 4, nb), dim3(256), 0, stream, Oparts, nsplit, split_stride, Q,
+                       H, d, wv, bv, along, alpha, beta, merged);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void qf_mean_kernel(const float* __restrict__ in, int nb, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int b = 0; b < nb; ++b) a += in[(long)b * n + i];      // sequential, like torch.mean over dim 0 of a stack
+    out[i] = a / (float)nb;
+}
+
+hipError_t launch_qf_mean(const float* in, int nb, long n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(qf_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, nb, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace infv

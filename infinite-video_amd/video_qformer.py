@@ -1,0 +1,344 @@
+"""Video Q-former + ``encode_video`` + per-chunk loop on MI355X (rows a11-a13, next-row f1).
+
+Mirrors the part of the reference model that surrounds the LTM:
+
+* ``init_video_Qformer``                 infty-Video-LLaMA/InfVideoLLaMA/models/infinityqa.py:36-55
+* the slimming done after construction   infinityqa.py:202-209  (no word/position embeddings, no text FFN)
+* ``encode_video``                       infinityqa.py:280-344
+* the eval scripts' chunk loop           eval_code/eval/run_inference_inf_video_llama_nextqa.py:179-196,228
+
+The parameter tree uses the reference's own module names (``bert.embeddings.LayerNorm``,
+``bert.encoder.layer.N.{attention,crossattention}.{self.{query,key,value},output.{dense,LayerNorm}}``,
+``intermediate_query.dense``, ``output_query.{dense,LayerNorm}``), so a reference checkpoint's ``video_Qformer.*`` /
+``video_query_tokens`` / ``llama_proj.*`` / ``video_frame_position_embedding.*`` entries load with
+``load_state_dict`` unchanged.  The modules are parameter holders only: the arithmetic of a chunk runs as one
+C-ABI call (``infv_vqf_encode_chunk``, include/infv_vqf.h) into the HIP kernels; there is no PyTorch fallback.
+
+Only the configuration the video Q-former is actually run in is supported: query tokens only (no text), eval
+mode, all-ones masks, batch 1, 64-wide heads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .basis_maps import NB_SAMPLES
+from .qformer_hook import build_long_term_attention
+
+
+class _Cfg:
+    """The BertConfig attributes init_video_Qformer sets (infinityqa.py:37-48) plus bert-base defaults."""
+
+    def __init__(self, **kw):
+        self.hidden_size = 768
+        self.num_attention_heads = 12
+        self.intermediate_size = 3072
+        self.layer_norm_eps = 1e-12
+        self.add_cross_attention = True
+        self.cross_attention_freq = 1
+        self.__dict__.update(kw)
+
+
+class _SelfOutput(nn.Module):                        # Qformer.py:315-326
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _SelfAttention(nn.Module):                     # Qformer.py:115-175
+    def __init__(self, cfg, is_cross_attention: bool):
+        super().__init__()
+        self.is_cross_attention = is_cross_attention
+        self.alpha = cfg.alpha
+        self.num_attention_heads = cfg.num_attention_heads
+        self.attention_head_size = cfg.hidden_size // cfg.num_attention_heads
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        kv_in = cfg.encoder_width if is_cross_attention else cfg.hidden_size
+        self.key = nn.Linear(kv_in, cfg.hidden_size)
+        self.value = nn.Linear(kv_in, cfg.hidden_size)
+        if is_cross_attention:
+            self.long_term_attention = build_long_term_attention(cfg, self.key, self.value, self.num_attention_heads,
+                                                                 self.attention_head_size)
+
+
+class _Attention(nn.Module):                         # Qformer.py:329-334
+    def __init__(self, cfg, is_cross_attention=False):
+        super().__init__()
+        self.self = _SelfAttention(cfg, is_cross_attention)
+        self.output = _SelfOutput(cfg)
+
+
+class _Intermediate(nn.Module):                      # Qformer.py:389-403
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+
+
+class _Output(nn.Module):                            # Qformer.py:406-418
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _Layer(nn.Module):                             # Qformer.py:419-441 after infinityqa.py:206-208
+    def __init__(self, cfg, layer_num):
+        super().__init__()
+        self.layer_num = layer_num
+        self.attention = _Attention(cfg)
+        self.crossattention = _Attention(cfg, is_cross_attention=True)
+        self.has_cross_attention = True
+        self.intermediate_query = _Intermediate(cfg)
+        self.output_query = _Output(cfg)
+
+
+class _Embeddings(nn.Module):                        # Qformer.py:55-83 after infinityqa.py:203-205
+    def __init__(self, cfg):
+        super().__init__()
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(cfg, i) for i in range(cfg.num_hidden_layers)])
+
+
+class _Bert(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = _Embeddings(cfg)
+        self.encoder = _Encoder(cfg)
+
+
+class VideoQformer(nn.Module):
+    """``video_Qformer`` (the reference's BertLMHeadModel with ``cls = None``): only ``.bert`` remains."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.bert = _Bert(cfg)
+
+    @property
+    def ltm_modules(self):
+        return [layer.crossattention.self.long_term_attention for layer in self.bert.encoder.layer]
+
+
+def init_video_Qformer(num_query_token: int, vision_width: int, num_hidden_layers: int = 2, sticky: bool = True,
+                       num_basis: int = 256, sigmas=(0.005, 0.01), tau: float = 0.75, alpha: float = 0.9
+                       ) -> Tuple[VideoQformer, nn.Parameter]:
+    """Same signature and return value as the reference classmethod (infinityqa.py:36-55)."""
+    cfg = _Cfg(num_hidden_layers=num_hidden_layers, encoder_width=vision_width, query_length=num_query_token,
+               sticky=sticky, num_basis=num_basis, sigmas=list(sigmas), tau=tau, alpha=alpha, initializer_range=0.02)
+    qformer = VideoQformer(cfg)
+    query_tokens = nn.Parameter(torch.zeros(1, num_query_token, cfg.hidden_size))
+    query_tokens.data.normal_(mean=0.0, std=cfg.initializer_range)
+    return qformer, query_tokens
+
+
+def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+class InfVideoEncoder(nn.Module):
+    """The in-scope slice of the reference model ``InfinityQA``: the members ``encode_video`` touches
+    (infinityqa.py:195-209,217-236) and ``encode_video`` itself.  The ViT / image Q-former producer
+    (``encode_short_memory_frame``) and the LLM are out of scope: fill ``short_memory_buffer`` with per-frame
+    token blocks ``[num_query_token, hidden]`` and consume ``inputs_llama``."""
+
+    def __init__(self, num_video_query_token: int = 32, hidden_size: int = 768, llama_hidden: int = 4096,
+                 max_frame_pos: int = 32, sticky: bool = True, num_basis: int = 256, sigmas=(0.005, 0.01),
+                 tau: float = 0.75, alpha: float = 0.9, num_hidden_layers: int = 2, tokens_per_frame: int = 32):
+        super().__init__()
+        self.video_frame_position_embedding = nn.Embedding(max_frame_pos, hidden_size)   # used as a flag only (Qformer.py:216)
+        self.num_video_query_token = num_video_query_token
+        self.video_Qformer, self.video_query_tokens = init_video_Qformer(
+            num_video_query_token, hidden_size, num_hidden_layers, sticky, num_basis, sigmas, tau, alpha)
+        self.llama_proj = nn.Linear(hidden_size, llama_hidden)
+        self.short_memory_buffer: List[torch.Tensor] = []
+        self.sticky = sticky
+        self.n_position = 8
+        self.tokens_per_frame = tokens_per_frame
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+        self._vqf = None
+        self._vqf_dev = None
+        self.last_hidden: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ weights
+    def load_reference_state_dict(self, sd: dict, strict: bool = True):
+        """Load tensors named as in the reference model's checkpoint.  Accepts both the model-level names
+        (``video_Qformer.bert...``) and the bare ``bert...`` names of ``synth.video_qformer_weights``."""
+        own = {}
+        for k, v in sd.items():
+            v = torch.as_tensor(v)
+            if k.startswith("bert."):
+                k = "video_Qformer." + k
+            own[k] = v
+        res = self.load_state_dict(own, strict=False)
+        # long_term_attention.proj_{key,value} alias the layer's key/value Linear (Qformer.py:156-157)
+        missing = [k for k in res.missing_keys if ".long_term_attention.proj_" not in k
+                   and not k.startswith("video_frame_position_embedding")]
+        if strict and (missing or res.unexpected_keys):
+            raise KeyError(f"missing {missing}, unexpected {res.unexpected_keys}")
+        return res
+
+    def _weights(self, device: torch.device):
+        keep = []                                             # keeps converted copies alive during the call
+
+        def t(x):
+            y = _dev_f32(x, device)
+            keep.append(y)
+            return y.data_ptr()
+
+        def lin(m: nn.Linear):
+            return _lib.Linear(t(m.weight), t(m.bias))
+
+        def ln(m: nn.LayerNorm):
+            return _lib.LayerNorm(t(m.weight), t(m.bias))
+
+        w = _lib.VqfWeights()
+        w.query_tokens = t(self.video_query_tokens)
+        bert = self.video_Qformer.bert
+        w.emb_ln = ln(bert.embeddings.LayerNorm)
+        for l, layer in enumerate(bert.encoder.layer):
+            a, x = layer.attention, layer.crossattention
+            w.layer[l] = _lib.VqfLayer(
+                lin(a.self.query), lin(a.self.key), lin(a.self.value), lin(a.output.dense), ln(a.output.LayerNorm),
+                lin(x.self.query), lin(x.self.key), lin(x.self.value), lin(x.output.dense), ln(x.output.LayerNorm),
+                lin(layer.intermediate_query.dense), lin(layer.output_query.dense), ln(layer.output_query.LayerNorm))
+        w.llama_proj = lin(self.llama_proj)
+        return w, keep
+
+    def _handle(self, device: torch.device):
+        if self._vqf is not None and self._vqf_dev == device:
+            return self._vqf
+        cfg = self.video_Qformer.config
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("the video Q-former path needs a HIP device (no CPU fallback exists)")
+        c = _lib.VqfConfig(cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size, cfg.intermediate_size,
+                           cfg.encoder_width, self.tokens_per_frame, self.num_video_query_token,
+                           self.llama_proj.out_features, NB_SAMPLES, float(cfg.alpha), float(cfg.layer_norm_eps))
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.infv_vqf_create(C.byref(c), C.byref(h)))
+        self._release()
+        self._vqf, self._vqf_dev = h, device
+        return h
+
+    def _release(self):
+        h, self._vqf = getattr(self, "_vqf", None), None
+        if h:
+            try:
+                _lib.load().infv_vqf_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._release()
+
+    # ------------------------------------------------------------------ one chunk
+    def encode_frames(self, frame_hidden_state: torch.Tensor, new_video: bool,
+                      u: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """frame_hidden_state [1, T*P, d] (device) -> (last_hidden_state [1, Q, hidden], inputs_llama [1, Q, llama]).
+        ``u`` [n_layers, 512] float64: the Gibbs uniforms; by default drawn from torch's global CPU generator in
+        the order the reference's CPU path consumes them (512 + 512 discarded per LTM call that resamples)."""
+        if not frame_hidden_state.is_cuda:
+            raise RuntimeError("the video Q-former path runs on the HIP device only (no CPU fallback)")
+        if frame_hidden_state.dim() != 3 or frame_hidden_state.size(0) != 1:
+            raise ValueError("frame_hidden_state must be [1, T*P, d] (batch 1, infinityqa.py:283)")
+        device = frame_hidden_state.device
+        cfg = self.video_Qformer.config
+        P, Q = self.tokens_per_frame, self.num_video_query_token
+        if frame_hidden_state.size(2) != cfg.encoder_width or frame_hidden_state.size(1) % P:
+            raise ValueError(f"frame_hidden_state must be [1, T*{P}, {cfg.encoder_width}]")
+        T = frame_hidden_state.size(1) // P
+        k = _dev_f32(frame_hidden_state[0], device)
+        h = self._handle(device)
+        lib = _lib.load()
+        use_ltm = cfg.alpha != 1.0
+        handles = (C.c_void_p * cfg.num_hidden_layers)()
+        if use_ltm:
+            need_u = False
+            for l, m in enumerate(self.video_Qformer.ltm_modules):
+                m.length = m.target_len = frame_hidden_state.size(1)             # Qformer.py:218-219
+                eng = m._get_engine(device, Q)
+                eng.ensure_plan(T)
+                handles[l] = eng._h
+                need_u = need_u or (eng.has_memory and not new_video and bool(m.sticky_memories))
+                m.count += 1
+            if u is None and need_u:
+                draws = []
+                for _ in range(cfg.num_hidden_layers):
+                    draws.append(torch.rand(NB_SAMPLES, dtype=torch.float64))
+                    torch.rand(NB_SAMPLES, dtype=torch.float64)                  # the in-bin draw of LTM.py:206
+                u = torch.stack(draws)
+            if u is not None:
+                u = u.to(device=device, dtype=torch.float64).contiguous()
+                if tuple(u.shape) != (cfg.num_hidden_layers, NB_SAMPLES):
+                    raise ValueError(f"u must be [{cfg.num_hidden_layers}, {NB_SAMPLES}]")
+        w, keep = self._weights(device)
+        hidden = torch.empty(1, Q, cfg.hidden_size, device=device, dtype=torch.float32)
+        llama = torch.empty(1, Q, self.llama_proj.out_features, device=device, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            _lib.check(lib.infv_vqf_encode_chunk(h, handles if use_ltm else None, C.c_void_p(k.data_ptr()), T,
+                                                 C.byref(w), C.c_void_p(0 if u is None else u.data_ptr()),
+                                                 int(bool(new_video)), C.c_void_p(hidden.data_ptr()),
+                                                 C.c_void_p(llama.data_ptr()), stream))
+        del keep
+        self.last_hidden = hidden
+        return hidden, llama
+
+    # ------------------------------------------------------------------ encode_video (infinityqa.py:280-344)
+    def encode_video(self, new_video: bool = True):
+        if not self.short_memory_buffer:
+            raise RuntimeError("short_memory_buffer is empty")
+        buf = [f if f.dim() == 3 else f.unsqueeze(0) for f in self.short_memory_buffer]   # :285
+        self.n_position = min(32, math.ceil(math.sqrt(len(buf))))                            # :286-288
+        cap = self.n_position * self.n_position
+        while len(buf) > cap:                                                                # :306-307
+            buf.pop(0)
+        self.short_memory_buffer = buf
+        device = buf[0].device
+        if not buf[0].is_cuda:
+            raise RuntimeError("the video Q-former path runs on the HIP device only (no CPU fallback)")
+        frame_hidden_state = torch.cat(buf, dim=0).reshape(1, -1, buf[0].size(-1))          # :317-323  b (t q) h
+        _, inputs_llama = self.encode_frames(frame_hidden_state, new_video)
+        atts_llama = torch.ones(inputs_llama.size()[:-1], dtype=torch.long, device=device)   # :343
+        return inputs_llama, atts_llama
+
+
+def encode_long_video(model: InfVideoEncoder, frame_tokens: torch.Tensor, max_int: int,
+                      u_of_chunk=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """The eval scripts' loop (run_inference_inf_video_llama_nextqa.py:179-196,228): split the video's per-frame
+    token blocks [F, P, d] into chunks of ``max_int`` frames (ragged tail kept), ``new_video=(i == 0)``, mean of the
+    per-chunk LLM-side embeddings.  Returns (mean [1, Q, llama], per-chunk list)."""
+    embs = []
+    for i, blk in enumerate(torch.split(frame_tokens, max_int, dim=0)):
+        if u_of_chunk is None:
+            model.short_memory_buffer = list(blk)
+            emb, _ = model.encode_video(new_video=(i == 0))
+        else:
+            _, emb = model.encode_frames(blk.reshape(1, -1, blk.size(-1)), new_video=(i == 0), u=u_of_chunk(i))
+        embs.append(emb)
+    stacked = torch.stack(embs).contiguous()
+    out = torch.empty_like(embs[0])
+    lib = _lib.load()
+    dev = stacked.device
+    with torch.cuda.device(dev):
+        _lib.check(lib.infv_vqf_mean(C.c_void_p(stacked.data_ptr()), len(embs), embs[0].numel(),
+                                     C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out, embs

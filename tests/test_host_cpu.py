@@ -73,7 +73,8 @@ def test_plan_rejects_single_frame_chunks():
 def test_library_exports_every_declared_symbol():
     """include/infv_ltm.h <-> libinfv_ltm.so <-> the ctypes table, without touching a GPU."""
     header = open(os.path.join(ROOT, "include", "infv_ltm.h")).read()
-    declared = set(re.findall(r"\b(infv_ltm_[a-z_]+)\s*\(", header))
+    header += open(os.path.join(ROOT, "include", "infv_vqf.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(infv_(?:ltm|vqf)_[a-z_]+)\s*\(", header, re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
@@ -87,6 +88,9 @@ def test_library_exports_every_declared_symbol():
     h = ctypes.c_void_p()
     assert lib.infv_ltm_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
     assert lib.infv_ltm_has_plan(None, 8) == -1
+    assert lib.infv_vqf_create(None, None) == -1
+    vcfg = _lib.VqfConfig(2, 12, 700, 3072, 768, 32, 32, 4096, 512, 0.9, 1e-12)    # hidden != 12 * 64
+    assert lib.infv_vqf_create(ctypes.byref(vcfg), ctypes.byref(h)) == -2
 
 
 def test_product_package_never_imports_the_oracle():

@@ -1,0 +1,140 @@
+"""HIP video Q-former path (infv_vqf_*) against the goldens captured from the REAL reference BertEncoder and
+against the CPU oracle.  Tolerance: the north star asks 1e-3 fp32; these tests hold 2e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.qformer_cases import QF_CASES, chunk_seed, chunk_uniforms, load_qf_golden, qf_inputs
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-4
+
+
+def make_model(case, weights, dev):
+    from infinite_video_amd.video_qformer import InfVideoEncoder
+    m = InfVideoEncoder(num_video_query_token=case.n_query, hidden_size=case.hidden, llama_hidden=case.proj_out,
+                        sticky=case.sticky, num_basis=case.N, tau=case.tau, alpha=case.alpha,
+                        num_hidden_layers=case.n_layers)
+    m.load_reference_state_dict(weights)
+    return m.to(dev)
+
+
+def torch_short_attention(frames, xq, wk, bk, wv, bv, H=12):
+    """Plain PyTorch fp32 reference of the short-term cross-attention (Qformer.py:225-301 with zero masks)."""
+    dh = xq.shape[1] // H
+    K = torch.nn.functional.linear(frames, wk, bk)
+    V = torch.nn.functional.linear(frames, wv, bv)
+    heads = lambda x: x.reshape(x.shape[0], H, dh).permute(1, 0, 2)
+    s = torch.matmul(heads(xq), heads(K).transpose(-1, -2)) / math.sqrt(dh)
+    return torch.matmul(torch.softmax(s, -1), heads(V)).permute(1, 0, 2).reshape(xq.shape[0], -1)
+
+
+@pytest.mark.parametrize("T,gain", [(8, 1.0), (5, 1.0), (1, 4.0), (64, 6.0), (256, 1.0), (256, 10.0)])
+def test_short_attention_matches_torch(T, gain):
+    import ctypes as C
+    from infinite_video_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(100 + T)
+    frames = torch.randn(T * 32, 768, generator=g)
+    xq = torch.randn(32, 768, generator=g) * gain
+    wk, wv = torch.randn(768, 768, generator=g) * 0.02, torch.randn(768, 768, generator=g) * 0.02
+    bk, bv = torch.randn(768, generator=g) * 0.02, torch.randn(768, generator=g) * 0.02
+    along = torch.randn(32, 768, generator=g)
+    want_short = torch_short_attention(frames.double(), xq.double(), wk.double(), bk.double(), wv.double(), bv.double())
+    lib = _lib.load()
+    for alpha, use_long in ((0.9, True), (1.0, False)):
+        cfg = _lib.VqfConfig(2, 12, 768, 3072, 768, 32, 32, 4096, 512, alpha, 1e-12)
+        h = C.c_void_p()
+        _lib.check(lib.infv_vqf_create(C.byref(cfg), C.byref(h)))
+        d = lambda t: t.to(dev).contiguous()
+        fr, q, a = d(frames), d(xq), d(along)
+        dwk, dbk, dwv, dbv = d(wk), d(bk), d(wv), d(bv)
+        key, val = _lib.Linear(dwk.data_ptr(), dbk.data_ptr()), _lib.Linear(dwv.data_ptr(), dbv.data_ptr())
+        out = torch.empty(32, 768, device=dev)
+        _lib.check(lib.infv_vqf_short_attention(h, C.c_void_p(fr.data_ptr()), T * 32, C.c_void_p(q.data_ptr()),
+                                                C.byref(key), C.byref(val),
+                                                C.c_void_p(a.data_ptr() if use_long else 0),
+                                                C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        want = alpha * want_short + (1 - alpha) * along.double() if use_long else want_short
+        np.testing.assert_allclose(out.cpu().numpy(), want.float().numpy(), atol=2e-5, rtol=1e-4)
+        _lib.check(lib.infv_vqf_destroy(h))
+
+
+@pytest.mark.parametrize("case", QF_CASES, ids=lambda c: c.name)
+def test_encode_chunks_match_reference_goldens(case):
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    for c in range(len(case.chunk_T)):
+        k = torch.from_numpy(frames[c]).unsqueeze(0).to(dev)
+        hid, llama = m.encode_frames(k, new_video=(c == 0), u=torch.from_numpy(chunk_uniforms(case, c)))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(hid[0].cpu().numpy(), g[f"c{c}_hidden"], atol=ATOL, err_msg=f"hidden c{c}")
+        np.testing.assert_allclose(llama[0].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL, err_msg=f"llama c{c}")
+        if case.alpha != 1.0:
+            for l, ltm in enumerate(m.video_Qformer.ltm_modules):
+                Bsum = ltm.B_past[0].double().sum(1).cpu().numpy()
+                np.testing.assert_allclose(Bsum, g[f"c{c}_l{l}_Bsum"], atol=5e-4, err_msg=f"B c{c} l{l}")
+
+
+def test_encode_video_consumes_global_rng_like_the_reference():
+    case = QF_CASES[0]
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    for c, T in enumerate(case.chunk_T):
+        blocks = torch.from_numpy(frames[c]).reshape(T, case.P, case.hidden).to(dev)
+        m.short_memory_buffer = list(blocks)
+        torch.manual_seed(chunk_seed(case, c))
+        inputs_llama, atts = m.encode_video(new_video=(c == 0))
+        nxt = torch.rand(1, dtype=torch.float64).numpy()
+        assert nxt == g[f"c{c}_next_u"], "generator position after the chunk differs from the reference"
+        assert atts.shape == (1, case.n_query) and atts.dtype == torch.long and bool((atts == 1).all())
+        np.testing.assert_allclose(inputs_llama[0].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL)
+
+
+def test_loop_counterpart_ragged_split_and_mean():
+    from infinite_video_amd.video_qformer import encode_long_video
+    case = QF_CASES[0]                                   # chunk_T = [8, 8, 5, ...]: 21 frames split at 8
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    video = torch.cat([torch.from_numpy(f).reshape(-1, case.P, case.hidden) for f in frames[:3]]).to(dev)
+    mean, embs = encode_long_video(m, video, 8, u_of_chunk=lambda i: torch.from_numpy(chunk_uniforms(case, i)))
+    assert len(embs) == 3
+    want = np.mean(np.stack([g[f"c{c}_llama"] for c in range(3)]), 0)
+    np.testing.assert_allclose(mean[0].cpu().numpy(), want, atol=ATOL)
+
+
+def test_frame_cap_drops_oldest_frames():
+    case = QF_CASES[1]                                   # alpha = 1: no memory, cheap
+    dev = torch.device("cuda:0")
+    _, weights = qf_inputs(case)
+    m = make_model(case, weights, dev)
+    gen = torch.Generator().manual_seed(5)
+    blocks = torch.randn(1030, case.P, case.hidden, generator=gen).to(dev)
+    m.short_memory_buffer = list(blocks)
+    full, _ = m.encode_video(new_video=True)
+    assert m.n_position == 32 and len(m.short_memory_buffer) == 1024
+    m.short_memory_buffer = list(blocks[6:])
+    newest, _ = m.encode_video(new_video=True)
+    np.testing.assert_array_equal(full.cpu().numpy(), newest.cpu().numpy())
+
+
+def test_errors():
+    case = QF_CASES[1]
+    _, weights = qf_inputs(case)
+    m = make_model(case, weights, torch.device("cuda:0"))
+    with pytest.raises(RuntimeError):
+        m.encode_frames(torch.zeros(1, 64, 768), new_video=True)            # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        m.encode_frames(torch.zeros(2, 64, 768, device="cuda:0"), new_video=True)
+    with pytest.raises(ValueError):
+        m.encode_frames(torch.zeros(1, 65, 768, device="cuda:0"), new_video=True)
