@@ -518,7 +518,6 @@ struct FastPipe {
         b.Sp_in = h->Sp[h->sc].as<float>(); b.Sp_out = h->Sp[h->sc ^ 1].as<float>();
         b.Snew = Snew; b.snew_ld = h->L * h->dm + h->L * h->H * Q; b.snew_splitk = sk; b.snew_split_stride = ss;
         b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
-        HIP_TRY(hipMemsetAsync(h->sync_words.p, 0, 8 * sizeof(unsigned int), stream));     // arrival counters
         {
             static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
             b.dbg = dbg;
@@ -527,7 +526,7 @@ struct FastPipe {
                 long long hb[16];
                 (void)hipStreamSynchronize(stream);
                 (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
-                fprintf(stderr, "[batch-S stamps x10ns] wait %lld draw %lld tab %lld recurrence %lld row-phase %lld atomics+arrive %lld alpha-out %lld | step %lld\n",
+                fprintf(stderr, "[batch-S stamps x10ns] wait+read %lld draw %lld tab %lld recurrence %lld row-phase+add %lld - %lld alpha-out %lld | step %lld\n",
                         hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
             }
         }

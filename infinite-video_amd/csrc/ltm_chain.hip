@@ -333,7 +333,7 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
 namespace infv {
 __global__ void acc_to_part_kernel(const unsigned long long* __restrict__ acc, int parts_pitch, float* __restrict__ part) {
     const int l = blockIdx.x, j = threadIdx.x;
-    if (j < kBins) part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)((double)acc[l * kBins + j] * (1.0 / kMassScale)) : 0.f;
+    if (j < kBins) part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)mass_of(acc[l * kBins + j]) : 0.f;
 }
 hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream) {
     hipLaunchKernelGGL(acc_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, acc, parts_pitch, part);

@@ -6,9 +6,10 @@
 // inter-workgroup dependency of a step -- the 127 sticky bin masses summed over the (head, query) rows of a
 // layer -- is exchanged in place:
 //   * every workgroup adds its masses into a fixed-point accumulator with integer atomics (performed at
-//     the memory side: exact, order-independent, no L2 coherence involved),
-//   * then bumps the layer's arrival counter; a workgroup starts step i's draw once the counter shows
-//     that all workgroups of its layer finished step i-1, and reads the totals back with returning atomics.
+//     the memory side: exact, order-independent, no L2 coherence involved); the same atomic adds 1 to an
+//     arrival count kept in the upper bits of every word,
+//   * a workgroup starts step i's draw once the words it polls (returning atomics) show that all workgroups
+//     of its layer have added their share of step i-1: the complete total arrives in the same round trip.
 // No fence / L2 write-back is needed: the exchanged words are only ever touched by device-scope atomics.
 // All workgroups of the launch must be co-resident (96 at the headline shape, one per CU of 256); waits are
 // bounded and raise an error flag instead of hanging.
@@ -141,17 +142,21 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         for (int k = 0; k < 4; ++k)
             if (sn_lds[k] >= 0) Snew[sn_lds[k]] = sn_reg[k];
         const double my_u = u_reg;
-        // ---- wait until every workgroup of this layer has finished the previous step of this launch ----
-        if (i > 0 && a.draw_mode == 1) {
-            if (tid == 0) {
-                const unsigned target = (unsigned)(blocks_per_layer * i);
+        // ---- totals of the previous step: every word carries the number of workgroups that have added their
+        // share; the lanes that need a word poll it until the count is complete (mass and arrival in ONE round trip)
+        double mass_prev = 0.0;
+        const bool steady = a.draw_mode == 1 && !((i == 0) && (((a.override_mask >> l) & 1u) || a.first_from_parts));
+        if (steady && tid < kBins - 1) {
+            unsigned long long v = coherent_read(acc_prev + tid);
+            if (i > 0) {
                 int spins = 0;
-                while (__hip_atomic_load(a.arrive + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                while ((v >> kArriveShift) < (unsigned long long)blocks_per_layer) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 22)) { atomicExch(a.error, 1u); break; }
+                    v = coherent_read(acc_prev + tid);
                 }
             }
-            __syncthreads();
+            mass_prev = mass_of(v);
         }
         BSTAMP(1);
         if (writer && tid < kBins) atomicExch(acc_clr + tid, 0ull);      // slot of the NEXT step: idle until then
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
                 const int j = tid & (kBins - 1), grp = tid / kBins;
                 if (j < kBins - 1)
                     for (int p = grp; p < a.parts; p += kBNT / kBins) dr.acc += (double)a.part_prev[((long)l * a.parts + p) * kBins + j];
-            } else if (tid < kBins - 1) {
-                dr.acc = (double)coherent_read(acc_prev + tid) * (1.0 / kMassScale);
+            } else {
+                dr.acc = mass_prev;
             }
             const bool last = (i == a.n_steps - 1);
             draw_finish<kBNT, 1>(dr, ovr, reinterpret_cast<const int32_t*>(lds + m.bin_box), a.S, lds + m.cdf, sidx,
@@ -222,12 +227,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         __syncthreads();
         BSTAMP(4);
         row_phase_wave(Ssm, sstride, N, valid, lds + m.w, a.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
-                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows);
+                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows,
+                       1ull << kArriveShift);
         BSTAMP(5);
-        // the masses are at the memory side once the atomics are acknowledged; then announce the arrival
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) atomicAdd(a.arrive + l, 1u);
         BSTAMP(6);
         // outputs for the UC kernel go out after the arrival, off the other workgroups' critical path:
         // the resolved gather table (layer's writer) and alpha_i with its row sums

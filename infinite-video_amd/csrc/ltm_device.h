@@ -14,6 +14,12 @@ constexpr int kVStride = 80;             // LDS row pitch of the V' stage: == 16
 constexpr int kDPitch = 132;             // LDS row pitch of the edge densities (129 used)
 constexpr int kMPitch = 128;             // LDS row pitch of the per-row bin masses
 constexpr double kMassScale = 1099511627776.0;   // 2^40: fixed-point scale of the sticky bin masses (integer atomics)
+// The accumulator words also carry, above the mass, the number of workgroups that have added their share
+// (persistent role S): one atomic both deposits the mass and announces the arrival, and a reader that sees the
+// full count has the complete total in the same round trip.
+constexpr int kArriveShift = 54;                                   // masses < 2^14, counts < 2^10
+constexpr unsigned long long kMassMask = (1ull << kArriveShift) - 1;
+__device__ inline double mass_of(unsigned long long word) { return (double)(word & kMassMask) * (1.0 / kMassScale); }
 
 // Sum over the NT threads of the workgroup (NT/64 waves); every thread gets the result.
 template <int NT>
@@ -116,7 +122,7 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
             if (tid + 64 < nb) r.ovr[1] = probs_override[tid + 64];
         }
     } else if (mass_acc != nullptr) {
-        if (tid < kBins - 1) r.acc = (double)mass_acc[tid] * (1.0 / kMassScale);           // group 0 holds the totals
+        if (tid < kBins - 1) r.acc = mass_of(mass_acc[tid]);           // group 0 holds the totals
     } else {
         constexpr int G = NT / kBins;                   // thread groups that split the partial rows
         const int j = tid & (kBins - 1), grp = tid / kBins;
@@ -267,7 +273,8 @@ __device__ inline void row_phase(float* Ssm, int sstride, int N, int valid_rows,
 __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_rows, const float* w,
                                       float w_out, const int32_t* edge_box, const float* edge_dx, float* Dsm,
                                       float* Msm, float* asum, float* __restrict__ part_out,
-                                      unsigned long long* __restrict__ mass_acc, int rows_in_tile) {
+                                      unsigned long long* __restrict__ mass_acc, int rows_in_tile,
+                                      unsigned long long arrive_inc = 0ull) {
     constexpr int NI = 4;                              // N <= 256: at most 4 boxes per lane
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
     float* Srow = Ssm + row * sstride;
@@ -328,7 +335,7 @@ __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_
         float t = 0.f;
         for (int r = 0; r < rows_in_tile; ++r) t += Msm[r * kMPitch + tid];
         if (part_out != nullptr) part_out[tid] = t;
-        if (mass_acc != nullptr) atomicAdd(&mass_acc[tid], (unsigned long long)((double)t * kMassScale + 0.5));
+        if (mass_acc != nullptr) atomicAdd(&mass_acc[tid], (unsigned long long)((double)t * kMassScale + 0.5) + arrive_inc);
     }
 }
 

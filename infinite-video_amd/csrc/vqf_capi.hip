@@ -52,7 +52,7 @@ int run_linear(infv_vqf_s* h, const LinearCall& c, hipStream_t stream) {
     QfEpilogue e{};
     e.parts = h->part.as<float>(); e.nsplit = sk; e.split_stride = g.split_stride; e.ld_in = width;
     for (int i = 0; i < c.n_lin; ++i) e.bias[i] = c.lin[i]->b;
-    e.seg_cols = c.n_out; e.act = c.act;
+    e.seg_cols = c.n_out; e.act = c.act; e.scale = 1.f; e.res_scale = 1.f;
     e.residual = c.residual; e.ld_res = width; e.res_rows = c.res_rows;
     e.gamma = c.ln ? c.ln->gamma : nullptr; e.beta = c.ln ? c.ln->beta : nullptr; e.eps = h->cfg.ln_eps;
     e.out = c.y; e.ld_out = width; e.M = c.M; e.width = width;
@@ -88,9 +88,30 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
     p.M = rows; p.N = d; p.k_per_split = n_tokens / sk; p.splitk = sk; p.nbatch = nb;
     HIP_TRY(launch_qf_gemm(p, true, stream));
-    const float alpha = c.alpha, beta = (float)(1.0 - (double)c.alpha);
-    HIP_TRY(launch_qf_headproj_merge(h->O.as<float>(), sk, p.split_stride, nb, Q, H, d, value->w, value->b, along,
-                                     alpha, beta, merged, stream));
+    // per-head value projection as a batched GEMM over (chunk, head): [Q x d] . Wv_h^T -> [Q x 64], then
+    // bias + merge with the long-term context in the row epilogue (Qformer.py:298-304)
+    HIP_TRY(launch_qf_sum_slabs(h->O.as<float>(), sk, p.split_stride, (long)nb * rows * d, stream));
+    const int M2 = nb * Q, hidden = c.hidden;
+    int sk2 = 8;
+    while (sk2 > 1 && d % (32 * sk2)) sk2 >>= 1;
+    const size_t needP = (size_t)sk2 * M2 * hidden * sizeof(float);
+    if (needP > h->part.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->part.reserve(needP)); }
+    for (int b = 0; b < nb; ++b) {
+        QfGemm v{};
+        v.A = h->O.as<float>() + (long)b * rows * d; v.lda = d; v.strideA = (long)Q * d;          // batch = head
+        v.B[0] = value->w; v.ldb = d; v.strideB = 64L * d; v.seg_rows = 64;
+        v.C = h->part.as<float>() + (long)b * Q * hidden; v.ldc = hidden; v.strideC = 64;
+        v.split_stride = (long)M2 * hidden;
+        v.M = Q; v.N = 64; v.k_per_split = d / sk2; v.splitk = sk2; v.nbatch = H;
+        HIP_TRY(launch_qf_gemm(v, false, stream));
+    }
+    QfEpilogue e{};
+    e.parts = h->part.as<float>(); e.nsplit = sk2; e.split_stride = (long)M2 * hidden; e.ld_in = hidden;
+    e.bias[0] = value->b; e.seg_cols = hidden; e.act = QF_ACT_NONE;
+    e.scale = along ? c.alpha : 1.f; e.res_scale = (float)(1.0 - (double)c.alpha);
+    e.residual = along; e.ld_res = hidden; e.res_rows = M2;
+    e.out = merged; e.ld_out = hidden; e.M = M2; e.width = hidden; e.eps = c.ln_eps;
+    HIP_TRY(launch_qf_epilogue(e, stream));
     return INFV_OK;
 }
 
@@ -147,7 +168,7 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     // embeddings: LayerNorm of the learned query tokens (Qformer.py:108-112)
     QfEpilogue e{};
     e.parts = w->query_tokens; e.nsplit = 1; e.split_stride = 0; e.ld_in = Hd; e.seg_cols = Hd;
-    e.gamma = w->emb_ln.gamma; e.beta = w->emb_ln.beta; e.eps = c.ln_eps;
+    e.gamma = w->emb_ln.gamma; e.beta = w->emb_ln.beta; e.eps = c.ln_eps; e.scale = 1.f; e.res_scale = 1.f;
     e.out = h->h_a.as<float>(); e.ld_out = Hd; e.M = Q; e.width = Hd; e.res_rows = 1;
     HIP_TRY(launch_qf_epilogue(e, stream));
     float* hcur = h->h_a.as<float>();

@@ -20,11 +20,12 @@ hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream);
 int qf_pick_splitk(int M, int N, int K, int nbatch);
 
 enum QfAct { QF_ACT_NONE = 0, QF_ACT_GELU = 1 };
-// out[m][:] = LN?( act( sum_s parts[s][m][:] + bias ) + residual[m % res_rows] )    one workgroup per row
+// out[m][:] = LN?( scale * act( sum_s parts[s][m][:] + bias ) + res_scale * residual[m % res_rows] )    one workgroup per row
 struct QfEpilogue {
     const float* parts;  int nsplit;  long split_stride;  long ld_in;
     const float* bias[kQfMaxSeg];  int seg_cols;               // bias segment s covers columns [s*seg_cols, (s+1)*seg_cols); nullptr = none
     int act;
+    float scale, res_scale;                                    // set both to 1 for a plain residual add
     const float* residual;  long ld_res;  int res_rows;        // residual row = m % res_rows (broadcast of a shared [res_rows] block)
     const float* gamma;  const float* beta;  float eps;        // LayerNorm if gamma != nullptr
     float* out;  long ld_out;
@@ -41,11 +42,8 @@ hipError_t launch_qf_qtilde(const float* xq, int nb, int Q, int H, int d, const 
 // in-place softmax of rows [n_rows][len] (leading dimension ld)
 hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipStream_t stream);
 
-// merged[b][q][h*64+e] = alpha * (sum_j O[b][h*Q+q][j] * Wv[h*64+e][j] + bv[h*64+e]) + beta * along[b][q][h*64+e]
-// O = sum of nsplit slabs (split_stride apart); along may be nullptr (beta ignored).
-hipError_t launch_qf_headproj_merge(const float* Oparts, int nsplit, long split_stride, int nb, int Q, int H, int d,
-                                    const float* wv, const float* bv, const float* along, float alpha, float beta,
-                                    float* merged, hipStream_t stream);
+// parts[0][i] = sum_s parts[s][i]  (slabs `stride` floats apart, n a multiple of 4)
+hipError_t launch_qf_sum_slabs(float* parts, int nsplit, long stride, long n, hipStream_t stream);
 
 // out[m][:] = mean over nb of in[b][m][:]
 hipError_t launch_qf_mean(const float* in, int nb, long n, float* out, hipStream_t stream);

@@ -183,17 +183,40 @@ __global__ __launch_bounds__(256) void qf_epilogue_kernel(QfEpilogue e) {
     const float* in = e.parts + (long)m * e.ld_in;
     const float* res = e.residual ? e.residual + (long)(m % e.res_rows) * e.ld_res : nullptr;
 #pragma unroll
+    for (int i = 0; i < kEpiMaxPerThread; ++i) x[i] = 0.f;
+    // eight slabs at a time: their loads are independent and in flight together (a plain slab loop is a chain
+    // of dependent round trips, 18 us for a 768-wide row)
+#pragma unroll
+    for (int i = 0; i < kEpiMaxPerThread; ++i) {
+        if (256 * i >= e.width) break;
+        const int c = tid + 256 * i;
+        if (c < e.width) {
+            const float* p = in + c;
+            float v = 0.f;
+            int s = 0;
+            for (; s + 8 <= e.nsplit; s += 8) {
+                float t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = p[(long)(s + k) * e.split_stride];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v += t[k];
+            }
+            for (; s < e.nsplit; ++s) v += p[(long)s * e.split_stride];
+            x[i] = v;
+        }
+    }
+#pragma unroll
     for (int i = 0; i < kEpiMaxPerThread; ++i) {
         const int c = tid + 256 * i;
-        float v = 0.f;
         if (c < e.width) {
-            for (int s = 0; s < e.nsplit; ++s) v += in[(long)s * e.split_stride + c];
+            float v = x[i];
             const int seg = c / e.seg_cols;
             if (e.bias[seg]) v += e.bias[seg][c - seg * e.seg_cols];
             if (e.act == QF_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-            if (res) v += res[c];
+            v *= e.scale;
+            if (res) v += e.res_scale * res[c];
+            x[i] = v;
         }
-        x[i] = v;
     }
     if (e.gamma) {
         double sum = 0.0;
@@ -365,63 +388,30 @@ hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipSt
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Per-head value projection of the attention-weighted token means + bias + memory merge (Qformer.py:298-304)
-// grid (H, 4, nb): workgroup = 16 of a head's 64 output columns, all Q rows; j tiled by 128 through LDS.
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qf_headproj_merge_kernel(const float* __restrict__ Oparts, int nsplit,
-                                                                long split_stride, int Q, int H, int d,
-                                                                const float* __restrict__ wv, const float* __restrict__ bv,
-                                                                const float* __restrict__ along, float alpha, float beta,
-                                                                float* __restrict__ merged) {
-    __shared__ float Ws[16][129];
-    __shared__ float Os[32][129];
-    const int h = blockIdx.x, eb = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const int hidden = H * 64;
-    const int e = tid & 15, q0 = tid >> 4;                   // outputs (q0, e) and (q0 + 16, e)
-    const float* O = Oparts + ((long)b * H * Q + (long)h * Q) * d;
-    const float* W = wv + (long)(h * 64 + eb * 16) * d;
-    float a0 = 0.f, a1 = 0.f;
-    for (int j0 = 0; j0 < d; j0 += 128) {
-        for (int i = tid; i < 16 * 128; i += 256) {
-            const int r = i >> 7, c = i & 127;
-            Ws[r][c] = (j0 + c < d) ? W[(long)r * d + j0 + c] : 0.f;
-        }
-        for (int i = tid; i < 32 * 128; i += 256) {
-            const int r = i >> 7, c = i & 127;
-            float v = 0.f;
-            if (r < Q && j0 + c < d)
-                for (int s = 0; s < nsplit; ++s) v += O[(long)s * split_stride + (long)r * d + j0 + c];
-            Os[r][c] = v;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int c = 0; c < 128; ++c) {
-            const float w = Ws[e][c];
-            a0 = fmaf(Os[q0][c], w, a0);
-            a1 = fmaf(Os[q0 + 16][c], w, a1);
-        }
-        __syncthreads();
+// out[i] = sum_s parts[s][i]   (n multiple of 4)
+__global__ __launch_bounds__(256) void qf_sum_slabs_kernel(const float* __restrict__ parts, int nsplit, long stride,
+                                                           long n4, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        const floatx4 v0 = *reinterpret_cast<const floatx4*>(parts + (long)(s + 0) * stride + 4 * i);
+        const floatx4 v1 = *reinterpret_cast<const floatx4*>(parts + (long)(s + 1) * stride + 4 * i);
+        const floatx4 v2 = *reinterpret_cast<const floatx4*>(parts + (long)(s + 2) * stride + 4 * i);
+        const floatx4 v3 = *reinterpret_cast<const floatx4*>(parts + (long)(s + 3) * stride + 4 * i);
+        a += v0; a += v1; a += v2; a += v3;
     }
-    const int col = h * 64 + eb * 16 + e;
-    const float bias = bv[col];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = q0 + 16 * k;
-        if (q >= Q) continue;
-        const long o = ((long)b * Q + q) * hidden + col;
-        float v = (k ? a1 : a0) + bias;
-        if (along) v = alpha * v + beta * along[o];
-        merged[o] = v;
-    }
+    for (; s < nsplit; ++s) a += *reinterpret_cast<const floatx4*>(parts + (long)s * stride + 4 * i);
+    *reinterpret_cast<floatx4*>(out + 4 * i) = a;
 }
 
-hipError_t launch_qf_headproj_merge(const float* Oparts, int nsplit, long split_stride, int nb, int Q, int H, int d,
-                                    const float* wv, const float* bv, const float* along, float alpha, float beta,
-                                    float* merged, hipStream_t stream) {
-    if (Q > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qf_headproj_merge_kernel, dim3(H, 4, nb), dim3(256), 0, stream, Oparts, nsplit, split_stride, Q,
-                       H, d, wv, bv, along, alpha, beta, merged);
+// in-place reduction of split-K slabs into slab 0
+hipError_t launch_qf_sum_slabs(float* parts, int nsplit, long stride, long n, hipStream_t stream) {
+    if (nsplit <= 1) return hipSuccess;
+    if (n % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qf_sum_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, parts, nsplit,
+                       stride, n / 4, parts);
     return hipGetLastError();
 }
 
