@@ -105,8 +105,10 @@ struct infv_ltm_s {
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
-    DeviceBuf kbar_ws, kbar_side, R_ws[3], P_ws[3], Snew_ws[3];
+    DeviceBuf kbar_ws, kbar_side[3], R_ws[3], P_ws[3], Snew_ws[3];
     hipStream_t side = nullptr;
+    hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
+    hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
@@ -125,6 +127,8 @@ struct infv_ltm_s {
         for (auto& kv : plans) delete kv.second;
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         if (ucs) { (void)hipStreamSynchronize(ucs); (void)hipStreamDestroy(ucs); }
+        if (pools) { (void)hipStreamSynchronize(pools); (void)hipStreamDestroy(pools); }
+        for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
@@ -626,10 +630,12 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_s[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
     }
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
     HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+    HIP_TRY(hipStreamCreateWithPriority(&h->pools, hipStreamNonBlocking, lo));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     return INFV_OK;
 }
@@ -722,25 +728,55 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         *c0 = first_c + b * h->maxC;
         *nb = (n_chunks - *c0 < h->maxC) ? n_chunks - *c0 : h->maxC;
     };
-    auto stage_parallel = [&](int b) -> int {                  // pool -> rows -> project -> scores of batch b, on `side`
+    // INFV_SPLIT_POOL=1 puts the pooling on its own stream so that the HBM-bound pooling of batch b+2 overlaps the
+    // MFMA-bound projection of batch b+1 (pooled frames are triple-buffered either way).  Measured: WORSE (87 k vs
+    // 95 k chunks/s) -- four concurrent kernels slow each other and role S more than the overlap gains; default off.
+    static const bool split_pool = [] { const char* e = getenv("INFV_SPLIT_POOL"); return e && atoi(e) != 0; }();
+    hipStream_t pools = split_pool ? h->pools : side;
+    bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
+    {
+        const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
+        if (need > h->kbar_side[0].bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) HIP_TRY(h->kbar_side[i].reserve(need));
+        }
+    }
+    auto stage_pool = [&](int b) -> int {                      // frame means of batch b, on `pools`
+        int c0, nb; batch_range(b, &c0, &nb);
+        const int set = b % 3;
+        // the rows kernel that read this set's pooled frames (batch b-3) is done once its projection is
+        if (split_pool && p_pending[set]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_p[set], 0));
+        {
+            Timed t_(h->prof, INFV_KERNEL_POOL, pools);
+            HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side[set].as<float>(), (int64_t)nb * T, h->P, h->d, pools, kPoolPad));
+        }
+        if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
+        return INFV_OK;
+    };
+    auto stage_project = [&](int b) -> int {                   // rows -> [V'new | S'new] GEMM of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % 3;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
-        if ((size_t)nb * T * h->d * sizeof(float) > h->kbar_side.bytes) HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(h->kbar_side.reserve((size_t)nb * T * h->d * sizeof(float)));
-        {
-            Timed t_(h->prof, INFV_KERNEL_POOL, side);
-            HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side.as<float>(), (int64_t)nb * T, h->P, h->d, side, kPoolPad));
-        }
-        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side.as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
+        if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
+        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side[set].as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
+        p_pending[set] = true;
         return INFV_OK;
     };
     if (n_batches > 0) {
         HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
         HIP_TRY(hipStreamWaitEvent(side, h->ev_in, 0));
-        if (int rc = stage_parallel(0)) return rc;
+        if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_in, 0));
+        if (int rc = stage_pool(0)) return rc;
+        if (n_batches > 1)
+            if (int rc = stage_pool(1)) return rc;
+        if (int rc = stage_project(0)) return rc;
     }
+    auto stage_parallel = [&](int b) -> int {                  // issued while batch b-1's chain is about to start
+        if (b + 1 < n_batches)
+            if (int rc = stage_pool(b + 1)) return rc;
+        return stage_project(b);
+    };
     for (int b = 0; b < n_batches; ++b) {
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % 3;
@@ -749,12 +785,12 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
         const long slot0 = pipe.counter;
         static const bool serial = getenv("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
-        if (serial) { HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
+        if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
         if (persistent) {
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
-            if (serial) HIP_TRY(hipStreamSynchronize(side));
+            if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); }
             if (int rc = pipe.launch_s_batch(nb, h->P_ws[set].as<float>() + (size_t)h->L * h->dm, sks[b], sss[b],
                                              u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
             if (serial) HIP_TRY(hipStreamSynchronize(stream));

@@ -130,13 +130,17 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     __syncthreads();
 
 #define BSTAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) a.dbg[k] = wall_clock64(); } while (0)
+    // running ring indices (global step g = a.step0 + i): g % 3 and g % ring without per-step 64-bit division
+    int g3 = (int)(a.step0 % 3), slot_run = (int)(a.step0 % a.ring);
+    const int ring_n = (int)a.ring;
     for (int i = 0; i < a.n_steps; ++i) {
         BSTAMP(0);
-        const long g = a.step0 + i;                      // global step index of this call
-        unsigned long long* acc_prev = a.acc[(g + 2) % 3] + l * kBins;
-        unsigned long long* acc_cur = a.acc[g % 3] + l * kBins;
-        unsigned long long* acc_clr = a.acc[(g + 1) % 3] + l * kBins;
-        const long slot = g % a.ring;
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;      // (g + 2) % 3
+        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;      // (g + 1) % 3
+        const long slot = slot_run;
+        if (++g3 == 3) g3 = 0;
+        if (++slot_run == ring_n) slot_run = 0;
         // park the prefetched S'new tile
 #pragma unroll
         for (int k = 0; k < 4; ++k)

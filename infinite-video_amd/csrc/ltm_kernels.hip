@@ -325,31 +325,28 @@ __global__ __launch_bounds__(256) void qtilde_kernel(const float* __restrict__ q
     const float* wk = proj.wk[l] + (long)h * kHeadSize * d;
     const float* bk = proj.bk[l] + h * kHeadSize;
     const long row0 = ((long)l * H + h) * Q;
-    if ((int)threadIdx.x < Q) {
+    if (blockIdx.z == 0 && (int)threadIdx.x < Q) {
         float c = 0.f;
         for (int e = 0; e < kHeadSize; ++e) c = fmaf(qs[threadIdx.x * kHeadSize + e], bk[e], c);
         cq[row0 + threadIdx.x] = c;
     }
-    for (int k = threadIdx.x; k < d; k += 256) {
-        for (int r0 = 0; r0 < Q; r0 += 32) {
-            float acc[32];
+    // one 256-column block per workgroup; the 64 weights of a column are fetched up front (independent loads)
+    const int k = blockIdx.z * 256 + threadIdx.x;
+    if (k >= d) return;
+    float w[kHeadSize];
 #pragma unroll
-            for (int r = 0; r < 32; ++r) acc[r] = 0.f;
-            for (int e = 0; e < kHeadSize; ++e) {
-                const float w = wk[(long)e * d + k];
+    for (int e = 0; e < kHeadSize; ++e) w[e] = wk[(long)e * d + k];
+    for (int r = 0; r < Q; ++r) {
+        float acc = 0.f;
 #pragma unroll
-                for (int r = 0; r < 32; ++r) acc[r] = fmaf(qs[min(r0 + r, Q - 1) * kHeadSize + e], w, acc[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 32; ++r)
-                if (r0 + r < Q) qt[(row0 + r0 + r) * d + k] = acc[r];
-        }
+        for (int e = 0; e < kHeadSize; ++e) acc = fmaf(qs[r * kHeadSize + e], w[e], acc);
+        qt[(row0 + r) * d + k] = acc;
     }
 }
 
 hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, const ProjPtrs& proj, float* qt, float* cq,
                          hipStream_t stream) {
-    hipLaunchKernelGGL(qtilde_kernel, dim3(H, n_layers), dim3(256), (size_t)Q * kHeadSize * sizeof(float), stream, q, Q, H,
+    hipLaunchKernelGGL(qtilde_kernel, dim3(H, n_layers, (d + 255) / 256), dim3(256), (size_t)Q * kHeadSize * sizeof(float), stream, q, Q, H,
                        d, proj, qt, cq);
     return hipGetLastError();
 }

@@ -11,6 +11,8 @@
 // on the MFMA pipe.  The sequential dimension (chunks) costs only LDS latency here, not kernel launches.
 #include "ltm_device.h"
 
+#include <cstdlib>
+
 namespace infv {
 
 constexpr int kUcNT = 512;
@@ -115,8 +117,12 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
     const long al_slot = (long)a.L * H * Q * N, as_slot = (long)a.L * H * Q;
     const float* al_base = a.alpha + ((long)l * H + h) * (long)Q * N;
     const float* as_base = a.asum + ((long)l * H + h) * (long)Q;
+    // ring slots advance by one per chunk (a 64-bit modulo per chunk costs ~0.5 us of scalar division)
+    int slot_cur = (int)(a.slot0 % a.ring), slot_pf = slot_cur;
+    const int ring = (int)a.ring;
     auto prefetch = [&](int i) {
-        const long slot = (a.slot0 + i) % a.ring;
+        const long slot = slot_pf;
+        if (++slot_pf == ring) slot_pf = 0;
         if (a.gather && tid * 4 < N * tabw)
             t_reg = *reinterpret_cast<const int4*>(a.tab + slot * a.tab_slot + (long)l * N * tabw + tid * 4);
         const float* nb = nr_base + (long)i * nr_chunk;
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
     prefetch(0);
     for (int i = 0; i < a.n_chunks; ++i) {
         USTAMP(0);
-        const long slot = (a.slot0 + i) % a.ring;        // ring slot of this chunk's alpha / tab
+        const long slot = slot_cur;                      // ring slot of this chunk's alpha / tab
+        if (++slot_cur == ring) slot_cur = 0;
         // ---- park this chunk's prefetched inputs in LDS, start fetching the next chunk's ----
         if (tid * 4 < N * tabw) *reinterpret_cast<int4*>(&tab[tid * 4]) = a.gather ? t_reg : make_int4(-1, -1, -1, -1);
 #pragma unroll
@@ -288,6 +295,194 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Fast variant for tabw == 4, Q <= 32, N in {64, 128, 192, 256}: nothing per-chunk is staged through LDS.
+//   * update: a thread owns 4 consecutive columns (ds_read/write_b128) of the boxes (tid >> 3) + 64 p; its
+//     gather-table rows and new-row values are prefetched from global straight into registers (the box ->
+//     new-row map and 1/(count+ridge) are static, kept in registers);
+//   * read-out: the MFMA A operand (alpha) is prefetched from global straight into the lane that consumes it
+//     (lane (c, g) takes the contiguous box range [kb + g*KL, kb + (g+1)*KL) of query row 16*qt + c);
+//   * the slice lives in LDS with pitch 32 and an XOR swizzle of column bit 4 by row bit 5, so both the
+//     b128 row gathers and the strided MFMA B reads are at the 2-way minimum of a 64-lane access.
+// LDS: 2 * N * 128 B + 8 KB (72 KB at N = 256), so a role-S workgroup fits on the same CU.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kUfNP = 4;                  // passes of 64 boxes
+constexpr int kUfKL = 32;                 // boxes per lane of the read-out (N / 8)
+
+__device__ inline int uf_slot(int r, int j4) { return r * 8 + (j4 ^ (((r >> 5) & 1) << 2)); }   // float4 index
+
+__global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, rows = a.op.rows;
+    floatx4* cur = reinterpret_cast<floatx4*>(lds);
+    floatx4* nxt = cur + N * 8;
+    float* red = lds + 2 * N * 32;
+
+    const int sb = a.d / kUcCols, sv = a.dm / kUcCols;
+    const int per_layer = sb + sv;
+    const int l = blockIdx.x / per_layer;
+    const int sl = blockIdx.x - l * per_layer;
+    const bool isV = sl >= sb;
+    const int col0 = (isV ? sl - sb : sl) * kUcCols;
+    const int dm = a.dm, H = a.H, Q = a.Q;
+    const int h = col0 / kHeadSize;
+    const int pitch = isV ? 2 * dm : a.d;
+    const float* src = isV ? a.KV_prev + (long)l * N * 2 * dm + dm + col0 : a.B_prev + (long)l * N * a.d + col0;
+    float* dst = isV ? a.KV_next + (long)l * N * 2 * dm + dm + col0 : a.B_next + (long)l * N * a.d + col0;
+
+    const int bi = tid >> 3, c4 = tid & 7;
+    const int NP = N / 64;
+    // ---- load the slice; static operator entries of this thread's boxes ----
+    float val[kUfNP]; int brow[kUfNP];
+#pragma unroll
+    for (int p = 0; p < kUfNP; ++p) {
+        const int n = bi + 64 * p;
+        val[p] = 0.f; brow[p] = -1;
+        if (p < NP) {
+            val[p] = a.op.box_val[n]; brow[p] = a.op.box_row[n];
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.have_state) v = *reinterpret_cast<const floatx4*>(src + (long)n * pitch + 4 * c4);
+            cur[uf_slot(n, c4)] = v;
+        }
+    }
+    // ---- per-chunk prefetch state ----
+    int4 tabv[kUfNP];
+    floatx4 newv[kUfNP];
+    floatx4 alv[kUfKL / 4];
+    float asv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nsplit = isV ? a.splitk : 1;
+    const long nr_chunk = isV ? (long)rows * a.p_ld : (long)rows * a.d;
+    const long nr_ld = isV ? a.p_ld : a.d;
+    const float* nr_base = (isV ? a.Pnew + (long)l * dm : a.R) + col0 + 4 * c4;
+    const int ring = a.ring;
+    int slot_cur = (int)(a.slot0 % a.ring), slot_t = slot_cur, slot_a = slot_cur;
+    auto prefetch_tab_new = [&](int i) {
+        const int32_t* tb = a.tab + (long)slot_t * a.tab_slot + (long)l * N * 4;
+        if (++slot_t == ring) slot_t = 0;
+        const float* nb = nr_base + (long)i * nr_chunk;
+#pragma unroll
+        for (int p = 0; p < kUfNP; ++p) {
+            tabv[p] = make_int4(-1, -1, -1, -1);
+            newv[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (p < NP) {
+                if (a.gather) tabv[p] = *reinterpret_cast<const int4*>(tb + (bi + 64 * p) * 4);
+                if (brow[p] >= 0) {
+                    floatx4 v = *reinterpret_cast<const floatx4*>(nb + (long)brow[p] * nr_ld);
+                    for (int k = 1; k < nsplit; ++k) v += *reinterpret_cast<const floatx4*>(nb + (long)brow[p] * nr_ld + k * a.split_stride);
+                    newv[p] = v;
+                }
+            }
+        }
+    };
+    // read-out geometry: 8 waves = 2 query tiles x 2 column tiles x 2 halves of the box dimension
+    const int c = lane & 15, g = lane >> 4;
+    const int qt = wave & 1, ct = (wave >> 1) & 1, ks = wave >> 2;
+    const int per = N / 2, KL = per / 4;                  // boxes per wave half, per lane
+    const int kb = ks * per + g * KL;
+    const int qrow = 16 * qt + c;
+    const long al_slot = (long)a.L * H * Q * N, as_slot = (long)a.L * H * Q;
+    const float* al_base = a.alpha + (((long)l * H + h) * Q + qrow) * N + kb;
+    const float* as_base = a.asum + ((long)l * H + h) * Q + 16 * qt + 4 * g;
+    auto prefetch_alpha = [&]() {
+        const float* ab = al_base + slot_a * al_slot;
+        const float* sbp = as_base + slot_a * as_slot;
+        if (++slot_a == ring) slot_a = 0;
+#pragma unroll
+        for (int v = 0; v < kUfKL / 4; ++v)
+            alv[v] = (qrow < Q && 4 * v < KL) ? *reinterpret_cast<const floatx4*>(ab + 4 * v) : floatx4{0.f, 0.f, 0.f, 0.f};
+        if (ks == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asv[r] = (16 * qt + 4 * g + r < Q) ? sbp[r] : 0.f;
+        }
+    };
+    prefetch_tab_new(0);
+    if (isV) prefetch_alpha();
+    const float* bvp = a.bv[l] + col0;
+    const float bvc = isV ? bvp[16 * ct + c] : 0.f;
+    const bool stamp_me = a.dbg != nullptr && tid == 0 && blockIdx.x == sb && a.n_chunks > 4;
+    lds_barrier();
+    for (int i = 0; i < a.n_chunks; ++i) {
+        USTAMP(0);
+        // ---- memory update: X_c[n] = val_n * sum_k X_{c-1}[tab[n][k]] + new row of n ----
+#pragma unroll
+        for (int p = 0; p < kUfNP; ++p) {
+            if (p < NP) {
+                const int n = bi + 64 * p;
+                const int4 t = tabv[p];
+                const floatx4 g0 = cur[uf_slot(max(t.x, 0), c4)], g1 = cur[uf_slot(max(t.y, 0), c4)];
+                const floatx4 g2 = cur[uf_slot(max(t.z, 0), c4)], g3 = cur[uf_slot(max(t.w, 0), c4)];
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float vn = val[p];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = 0.f;
+                    if (t.x >= 0) x = fmaf(vn, g0[e], x);
+                    if (t.y >= 0) x = fmaf(vn, g1[e], x);
+                    if (t.z >= 0) x = fmaf(vn, g2[e], x);
+                    if (t.w >= 0) x = fmaf(vn, g3[e], x);
+                    if (brow[p] >= 0) x += newv[p][e];
+                    acc[e] = x;
+                }
+                nxt[uf_slot(n, c4)] = acc;
+            }
+        }
+        USTAMP(3);
+        if (i + 1 < a.n_chunks) prefetch_tab_new(i + 1);
+        lds_barrier();
+        USTAMP(4);
+        { floatx4* t = cur; cur = nxt; nxt = t; }
+        if (isV) {
+            const float* curf = reinterpret_cast<const float*>(cur);
+            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const int colj = 16 * ct + c;
+#pragma unroll
+            for (int v = 0; v < kUfKL / 4; ++v) {
+                if (4 * v < KL) {
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int r0 = kb + 4 * v + e, r1 = r0 + 1;
+                        const float b0 = curf[r0 * 32 + (colj ^ (((r0 >> 5) & 1) << 4))];
+                        const float b1 = curf[r1 * 32 + (colj ^ (((r1 >> 5) & 1) << 4))];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alv[v][e], b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alv[v][e + 1], b1, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            USTAMP(5);
+            const floatx4 accw = acc0 + acc1;
+            const float as0 = asv[0], as1 = asv[1], as2 = asv[2], as3 = asv[3];
+            if (i + 1 < a.n_chunks) prefetch_alpha();
+            *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
+            lds_barrier();
+            USTAMP(6);
+            if (ks == 0) {
+                floatx4 tot = accw;
+                tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
+                float* ctx = a.ctx + (long)i * a.L * Q * dm + (long)l * Q * dm + col0;
+                const float asr[4] = {as0, as1, as2, as3};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * qt + 4 * g + r;
+                    if (rr < Q) ctx[(long)rr * dm + 16 * ct + c] = tot[r] + asr[r] * bvc;
+                }
+            }
+        }
+        USTAMP(7);
+    }
+    lds_barrier();
+    // ---- write the slice back ----
+#pragma unroll
+    for (int p = 0; p < kUfNP; ++p)
+        if (p < NP) {
+            const int n = bi + 64 * p;
+            *reinterpret_cast<floatx4*>(dst + (long)n * pitch + 4 * c4) = cur[uf_slot(n, c4)];
+        }
+}
+
+bool uc_fast_supported(int N, int Q, int tabw) { return tabw == 4 && Q <= kUcQ && N % 64 == 0 && N <= 256; }
+
 size_t uc_lds_bytes(int N, int tabw, int rows_max) { return (size_t)uc_smem(N, tabw, rows_max).total * sizeof(float); }
 
 bool uc_supported(int N, int d, int dm, int tabw, int rows_max) {
@@ -300,12 +495,19 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (a.n_chunks <= 0) return hipSuccess;
     if (!uc_supported(a.N, a.d, a.dm, a.tabw, a.op.rows)) return hipErrorInvalidValue;
     const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
+    static const bool want_fast = [] { const char* e = getenv("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
+    if (want_fast && uc_fast_supported(a.N, a.Q, a.tabw)) {
+        hipLaunchKernelGGL(uc_fast_kernel, dim3(blocks), dim3(kUcNT), (size_t)(2 * a.N * 32 + 8 * 64 * 4) * sizeof(float), stream, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
     return hipGetLastError();
 }
