@@ -27,6 +27,10 @@ int fail(int code, const char* fmt, ...) {
 
 namespace {
 
+// Timing experiments only (results become garbage): INFV_SKIP bit 0 = no pooling launches, bit 1 = no projection GEMM,
+// bit 2 = no UC launches, bit 3 = no role-S launches.  Shows how much each stream slows the others.
+int skip_mask() { static const int m = [] { const char* e = getenv("INFV_SKIP"); return e ? atoi(e) : 0; }(); return m; }
+
 struct Operator {
     int rows = 0;
     DeviceBuf row_box, row_begin, row_end, box_val, box_row, old_ptr, old_slot, slot_tab;
@@ -536,7 +540,7 @@ struct FastPipe {
         }
         {
             Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
-            HIP_TRY(launch_chain_batch(b, stream));
+            if (!(skip_mask() & 8)) HIP_TRY(launch_chain_batch(b, stream));
         }
         if (b.draw_mode == 1) h->override_mask = 0;
         h->sc ^= 1;
@@ -575,7 +579,7 @@ struct FastPipe {
                         hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
             }
             Timed t_(h->prof, INFV_KERNEL_UC, ucs);
-            HIP_TRY(::infv::launch_uc(u, ucs));
+            if (!(skip_mask() & 4)) HIP_TRY(::infv::launch_uc(u, ucs));
         }
         h->cur ^= 1;
         h->has_memory = true;
@@ -600,10 +604,12 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
         HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[set].as<float>(), stream));
     }
-    {
+    if (!(skip_mask() & 2)) {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
                                     h->P_ws[set].as<float>(), splitk, stream, gemm_pad));
+    } else {
+        *splitk = project_splitk((int)M, h->d);
     }
     *split_stride = M * ld;
     return INFV_OK;
@@ -746,7 +752,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         const int set = b % 3;
         // the rows kernel that read this set's pooled frames (batch b-3) is done once its projection is
         if (split_pool && p_pending[set]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_p[set], 0));
-        {
+        if (!(skip_mask() & 1)) {
             Timed t_(h->prof, INFV_KERNEL_POOL, pools);
             HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side[set].as<float>(), (int64_t)nb * T, h->P, h->d, pools, kPoolPad));
         }
