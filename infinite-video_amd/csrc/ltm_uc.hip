@@ -301,11 +301,13 @@ __global__ __launch_bounds__(kUcNT) void uc_kernel(UcArgs a) {
 //   * update: a thread owns 4 consecutive columns (ds_read/write_b128) of the boxes (tid >> 3) + 64 p; its
 //     gather-table rows and new-row values are prefetched from global straight into registers (the box ->
 //     new-row map and 1/(count+ridge) are static, kept in registers);
-//   * read-out: the MFMA A operand (alpha) is prefetched from global straight into the lane that consumes it
-//     (lane (c, g) takes the contiguous box range [kb + g*KL, kb + (g+1)*KL) of query row 16*qt + c);
+//   * read-out: the alpha tile is fetched with coalesced float4 loads one chunk ahead, parked in LDS with b128
+//     stores and read back as the MFMA A operand with b128 loads (lane (c, g) takes the contiguous box range
+//     [kb + g*KL, kb + (g+1)*KL) of query row 16*qt + c); loading it per lane straight from global touched 64 cache
+//     lines per instruction and cost 2 us per chunk;
 //   * the slice lives in LDS with pitch 32 and an XOR swizzle of column bit 4 by row bit 5, so both the
 //     b128 row gathers and the strided MFMA B reads are at the 2-way minimum of a 64-lane access.
-// LDS: 2 * N * 128 B + 8 KB (72 KB at N = 256), so a role-S workgroup fits on the same CU.
+// LDS: 2 * N * 128 B + 8 KB + 32 * (N + 4) * 4 B (105 KB at N = 256).
 // ------------------------------------------------------------------------------------------------------
 constexpr int kUfNP = 4;                  // passes of 64 boxes
 constexpr int kUfKL = 32;                 // boxes per lane of the read-out (N / 8)
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     floatx4* cur = reinterpret_cast<floatx4*>(lds);
     floatx4* nxt = cur + N * 8;
     float* red = lds + 2 * N * 32;
+    float* Asm = red + 8 * 64 * 4;                      // alpha tile [32][N + 4] of the current chunk
+    const int apitch = N + 4;
 
     const int sb = a.d / kUcCols, sv = a.dm / kUcCols;
     const int per_layer = sb + sv;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     // ---- per-chunk prefetch state ----
     int4 tabv[kUfNP];
     floatx4 newv[kUfNP];
-    floatx4 alv[kUfKL / 4];
+    floatx4 al_reg[4];                                  // coalesced tile loads of the NEXT chunk's alpha
     float asv[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsplit = isV ? a.splitk : 1;
     const long nr_chunk = isV ? (long)rows * a.p_ld : (long)rows * a.d;
@@ -383,15 +387,24 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     const int kb = ks * per + g * KL;
     const int qrow = 16 * qt + c;
     const long al_slot = (long)a.L * H * Q * N, as_slot = (long)a.L * H * Q;
-    const float* al_base = a.alpha + (((long)l * H + h) * Q + qrow) * N + kb;
+    const float* al_base = a.alpha + ((long)l * H + h) * (long)Q * N;
     const float* as_base = a.asum + ((long)l * H + h) * Q + 16 * qt + 4 * g;
+    const int n4 = N / 4;
+    int al_off[4], al_lds[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * kUcNT;
+        const int r = e / n4, cc = e - r * n4;
+        al_off[u] = (r < kUcQ && r < Q) ? r * N + cc * 4 : -1;
+        al_lds[u] = (r < kUcQ) ? r * apitch + cc * 4 : -1;
+    }
     auto prefetch_alpha = [&]() {
         const float* ab = al_base + slot_a * al_slot;
         const float* sbp = as_base + slot_a * as_slot;
         if (++slot_a == ring) slot_a = 0;
 #pragma unroll
-        for (int v = 0; v < kUfKL / 4; ++v)
-            alv[v] = (qrow < Q && 4 * v < KL) ? *reinterpret_cast<const floatx4*>(ab + 4 * v) : floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 4; ++u)
+            al_reg[u] = (al_off[u] >= 0) ? *reinterpret_cast<const floatx4*>(ab + al_off[u]) : floatx4{0.f, 0.f, 0.f, 0.f};
         if (ks == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) asv[r] = (16 * qt + 4 * g + r < Q) ? sbp[r] : 0.f;
@@ -405,6 +418,15 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     lds_barrier();
     for (int i = 0; i < a.n_chunks; ++i) {
         USTAMP(0);
+        float as0 = 0.f, as1 = 0.f, as2 = 0.f, as3 = 0.f;
+        if (isV) {
+            // park this chunk's alpha tile (readers of the previous tile are past the last barrier) and request the next
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (al_lds[u] >= 0) *reinterpret_cast<floatx4*>(&Asm[al_lds[u]]) = al_reg[u];
+            as0 = asv[0]; as1 = asv[1]; as2 = asv[2]; as3 = asv[3];
+            if (i + 1 < a.n_chunks) prefetch_alpha();
+        }
         // ---- memory update: X_c[n] = val_n * sum_k X_{c-1}[tab[n][k]] + new row of n ----
 #pragma unroll
         for (int p = 0; p < kUfNP; ++p) {
@@ -437,23 +459,23 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
             const float* curf = reinterpret_cast<const float*>(cur);
             floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const int colj = 16 * ct + c;
+            const float* arow = Asm + qrow * apitch + kb;
 #pragma unroll
             for (int v = 0; v < kUfKL / 4; ++v) {
                 if (4 * v < KL) {
+                    const floatx4 av = *reinterpret_cast<const floatx4*>(arow + 4 * v);
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         const int r0 = kb + 4 * v + e, r1 = r0 + 1;
                         const float b0 = curf[r0 * 32 + (colj ^ (((r0 >> 5) & 1) << 4))];
                         const float b1 = curf[r1 * 32 + (colj ^ (((r1 >> 5) & 1) << 4))];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alv[v][e], b0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alv[v][e + 1], b1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e + 1], b1, acc1, 0, 0, 0);
                     }
                 }
             }
             USTAMP(5);
             const floatx4 accw = acc0 + acc1;
-            const float as0 = asv[0], as1 = asv[1], as2 = asv[2], as3 = asv[3];
-            if (i + 1 < a.n_chunks) prefetch_alpha();
             *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
             lds_barrier();
             USTAMP(6);
@@ -505,7 +527,7 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
     static const bool want_fast = [] { const char* e = getenv("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
     if (want_fast && uc_fast_supported(a.N, a.Q, a.tabw)) {
-        hipLaunchKernelGGL(uc_fast_kernel, dim3(blocks), dim3(kUcNT), (size_t)(2 * a.N * 32 + 8 * 64 * 4) * sizeof(float), stream, a);
+        hipLaunchKernelGGL(uc_fast_kernel, dim3(blocks), dim3(kUcNT), (size_t)(2 * a.N * 32 + 8 * 64 * 4 + kUcQ * (a.N + 4)) * sizeof(float), stream, a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
