@@ -47,6 +47,7 @@ def parse():
                     help="chunks per sub-batch (28 x 64 new rows = 14 row tiles x 18 column tiles = 252 GEMM workgroups)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode-video", action="store_true", help="skip the secondary per-chunk Q-former leg")
     return ap.parse_args()
 
 
@@ -191,6 +192,31 @@ def main():
         "kernel_ms_per_pass": {name: round(ms, 3) for name, (n, ms) in prof.items()},
     }
 
+    # ---- secondary leg (rank 0, N = 1): the same chunk shape through the whole video Q-former (encode_video
+    #      counterpart: short-term cross-attention + LTM + merge + query FFN + llama_proj), per-chunk calls ----
+    encode_video = None
+    if rank == 0 and world == 1 and not args.no_encode_video:
+        from infinite_video_amd.video_qformer import InfVideoEncoder
+        model = InfVideoEncoder(num_basis=N, tau=TAU, alpha=0.9, sticky=True)
+        model.load_reference_state_dict(synth.video_qformer_weights())
+        model = model.to(dev)
+        n_enc = 48
+        uu = torch.from_numpy(synth.gibbs_uniforms(n_enc + 2, L)).to(dev)
+        for c in range(2):
+            model.encode_frames(k[c % c_local].unsqueeze(0), new_video=(c == 0), u=uu[c])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for c in range(n_enc):
+            model.encode_frames(k[c % c_local].unsqueeze(0), new_video=False, u=uu[2 + c])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        flop = L * 2 * (2 * H * Q * D * T * P)                       # two [H*Q x d x T*P] contractions per layer
+        encode_video = {"what": "per-chunk encode_video counterpart (2-layer video Q-former + LTM + llama_proj), alpha=0.9",
+                        "chunks_per_s": n_enc / dt, "ms_per_chunk": 1e3 * dt / n_enc, "chunks": n_enc,
+                        "short_attention_gflop_per_chunk": flop / 1e9,
+                        "short_attention_tflops_over_whole_chunk_time": flop * n_enc / dt / 1e12}
+        del model
+
     if rank == 0:
         value = args.chunks * args.steps / elapsed
         out = {
@@ -205,6 +231,8 @@ def main():
                        "parallelism": f"chunk-block sharding x{world} + 1 all-gather of consolidated memory"},
             "roofline": roofline,
         }
+        if encode_video is not None:
+            out["encode_video"] = encode_video
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
