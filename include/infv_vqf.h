@@ -76,6 +76,21 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                           const infv_vqf_weights* w, const double* u, int32_t new_video,
                           float* hidden_out, float* llama_out, void* stream);
 
+/* A whole video (n_chunks chunks of T frames each) through the video Q-former, layer-major:
+ *   - layer 0's hidden states do not depend on the chunk (they come from the learned query tokens only), so its LTM
+ *     runs as ONE infv_ltm_consolidate over all chunks (constant query) and its short-term attention shares one
+ *     pre-multiplied query block;
+ *   - later layers have per-chunk queries: their LTM is the sequential per-call chain, issued on an internal side
+ *     stream while the caller's stream runs the layer's short-term attention for all chunks;
+ *   - every query-token block (linear / LayerNorm / GELU / self-attention) is batched over chunks.
+ * Results equal n_chunks calls of infv_vqf_encode_chunk (new_video on the first only).
+ *   frames [n_chunks][T * tokens_per_frame][enc_width], u [n_chunks][n_layers][nb_samples] or NULL,
+ *   hidden_out [n_chunks][n_query][hidden] / llama_out [n_chunks][n_query][proj_out] / llama_mean [n_query][proj_out]
+ *   (the eval loop's mean over chunks, run_inference_inf_video_llama_nextqa.py:194); each may be NULL. */
+int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const float* frames, int32_t n_chunks,
+                          int32_t T, const infv_vqf_weights* w, const double* u, int32_t new_video,
+                          float* hidden_out, float* llama_out, float* llama_mean, void* stream);
+
 /* out[i] = mean over n of in[n][i]  (the eval loop's mean over chunk embeddings,
  * run_inference_inf_video_llama_nextqa.py:194) */
 int infv_vqf_mean(const float* in, int32_t n, int64_t elems, float* out, void* stream);

@@ -112,6 +112,9 @@ _SIGNATURES = {
     "infv_vqf_encode_chunk": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
                                         C.POINTER(VqfWeights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "infv_vqf_encode_video": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32,
+                                        C.POINTER(VqfWeights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "infv_vqf_mean": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 KERNELS = ("pool", "rows", "project", "draw", "update", "attend", "scores", "chain", "uc")

@@ -16,6 +16,8 @@
 // Wavefront = 64 lanes everywhere; MFMA shapes are the f32-input ones (exact fp32 fma chains).
 #include "ltm_device.h"
 
+#include <cstdlib>
+
 namespace infv {
 
 // ======================================================================================
@@ -29,26 +31,27 @@ __global__ __launch_bounds__(NT) void pool_frames_kernel(const float* __restrict
                                                           float* __restrict__ kbar,
                                                           long n_units, int P, int d4, int slices) {
     const int lane = threadIdx.x & 63;
-    const long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (unit >= n_units) return;
-    const long frame = unit / slices;
-    const int c4 = (int)(unit - frame * slices) * 64 + lane;
-    if (c4 >= d4) return;
-    const floatx4* src = reinterpret_cast<const floatx4*>(k) + frame * (long)P * d4 + c4;
-    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    int p = 0;
-    for (; p + UNROLL <= P; p += UNROLL) {
-        floatx4 v[UNROLL];
+    // grid-stride over units: with a full grid every wave takes exactly one unit; a smaller grid throttles the kernel
+    for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
+        const long frame = unit / slices;
+        const int c4 = (int)(unit - frame * slices) * 64 + lane;
+        if (c4 >= d4) continue;
+        const floatx4* src = reinterpret_cast<const floatx4*>(k) + frame * (long)P * d4 + c4;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        int p = 0;
+        for (; p + UNROLL <= P; p += UNROLL) {
+            floatx4 v[UNROLL];
 #pragma unroll
-        for (int i = 0; i < UNROLL; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
+            for (int i = 0; i < UNROLL; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
 #pragma unroll
-        for (int i = 0; i < UNROLL; ++i) acc += v[i];
+            for (int i = 0; i < UNROLL; ++i) acc += v[i];
+        }
+        for (; p < P; ++p) acc += __builtin_nontemporal_load(src + (long)p * d4);
+        const float fp = (float)P;
+        acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does
+        // streaming store: leave no dirty lines in L2 (every kernel boundary of the concurrent chain writes L2 back)
+        __builtin_nontemporal_store(acc, reinterpret_cast<floatx4*>(kbar) + frame * d4 + c4);
     }
-    for (; p < P; ++p) acc += __builtin_nontemporal_load(src + (long)p * d4);
-    const float fp = (float)P;
-    acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does
-    // streaming store: leave no dirty lines in L2 (every kernel boundary of the concurrent chain writes L2 back)
-    __builtin_nontemporal_store(acc, reinterpret_cast<floatx4*>(kbar) + frame * d4 + c4);
 }
 
 // `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
@@ -68,7 +71,10 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3((unsigned)((n_units + 7) / 8)), dim3(512), lds_pad, stream,
+        static const int max_wgs = [] { const char* e = getenv("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
+        unsigned grid = (unsigned)((n_units + 7) / 8);
+        if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
+        hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3(grid), dim3(512), lds_pad, stream,
                            k, kbar, n_units, P, d4, slices);
     } else {
         hipLaunchKernelGGL((pool_frames_kernel<16, 256>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,

@@ -12,6 +12,15 @@ struct infv_vqf_s {
     int dev = 0;
     // workspaces (grown on demand; a growing call synchronises the device first)
     DeviceBuf part, h_a, h_b, h1, h2, qkv, sa, xq, along, qt, S, O, merged, inter, kbar;
+    // whole-video (layer-major) path
+    DeviceBuf vA, v1, v2, vxq, valong, vshort, vmerged, vqkv, vsa, vinter, vu, vkbar, v_h1s, v_xqs;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    ~infv_vqf_s() {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+    }
 };
 
 namespace {
@@ -60,23 +69,27 @@ int run_linear(infv_vqf_s* h, const LinearCall& c, hipStream_t stream) {
     return INFV_OK;
 }
 
-// frames [nb][n_tokens][d], xq [nb*Q][hidden] -> merged [nb*Q][hidden]
-int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, const float* xq, const infv_linear* key,
-                    const infv_linear* value, const float* along, float* merged, hipStream_t stream) {
+// frames [nb][n_tokens][d]; xq: per-chunk [nb*Q][hidden] (shared_q = false) or one [Q][hidden] block used by every
+// chunk (shared_q = true: layer 0 of the video Q-former, whose query does not depend on the chunk)
+//   -> merged [nb*Q][hidden] = alpha * short-term context + (1 - alpha) * along   (along == nullptr: short-term only)
+int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, const float* xq, bool shared_q,
+                    const infv_linear* key, const infv_linear* value, const float* along, float* merged,
+                    hipStream_t stream) {
     const infv_vqf_config& c = h->cfg;
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
     const int sk = qf_pick_splitk(rows, d, n_tokens, nb);
+    const int nq = shared_q ? 1 : nb;
     const size_t needS = (size_t)nb * rows * n_tokens * sizeof(float);
     const size_t needO = (size_t)sk * nb * rows * d * sizeof(float);
-    const size_t needQt = (size_t)nb * rows * d * sizeof(float);
+    const size_t needQt = (size_t)nq * rows * d * sizeof(float);
     if (needS > h->S.bytes || needO > h->O.bytes || needQt > h->qt.bytes) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(h->S.reserve(needS)); HIP_TRY(h->O.reserve(needO)); HIP_TRY(h->qt.reserve(needQt));
     }
-    HIP_TRY(launch_qf_qtilde(xq, nb, Q, H, d, key->w, h->qt.as<float>(), stream));
+    HIP_TRY(launch_qf_qtilde(xq, nq, Q, H, d, key->w, h->qt.as<float>(), stream));
     QfGemm g{};                                             // S[b] = qt[b] . frames[b]^T
-    g.A = h->qt.as<float>(); g.lda = d; g.strideA = (long)rows * d;
+    g.A = h->qt.as<float>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
     g.B[0] = frames; g.ldb = d; g.strideB = (long)n_tokens * d; g.seg_rows = n_tokens;
     g.C = h->S.as<float>(); g.ldc = n_tokens; g.strideC = (long)rows * n_tokens; g.split_stride = 0;
     g.M = rows; g.N = n_tokens; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
@@ -88,23 +101,21 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
     p.M = rows; p.N = d; p.k_per_split = n_tokens / sk; p.splitk = sk; p.nbatch = nb;
     HIP_TRY(launch_qf_gemm(p, true, stream));
-    // per-head value projection as a batched GEMM over (chunk, head): [Q x d] . Wv_h^T -> [Q x 64], then
+    // per-head value projection as a GEMM batched over (chunk, head): [Q x d] . Wv_h^T -> [Q x 64], then
     // bias + merge with the long-term context in the row epilogue (Qformer.py:298-304)
     HIP_TRY(launch_qf_sum_slabs(h->O.as<float>(), sk, p.split_stride, (long)nb * rows * d, stream));
     const int M2 = nb * Q, hidden = c.hidden;
     int sk2 = 8;
-    while (sk2 > 1 && d % (32 * sk2)) sk2 >>= 1;
+    while (sk2 > 1 && (d % (32 * sk2) || nb * H * sk2 > 4096)) sk2 >>= 1;
     const size_t needP = (size_t)sk2 * M2 * hidden * sizeof(float);
     if (needP > h->part.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->part.reserve(needP)); }
-    for (int b = 0; b < nb; ++b) {
-        QfGemm v{};
-        v.A = h->O.as<float>() + (long)b * rows * d; v.lda = d; v.strideA = (long)Q * d;          // batch = head
-        v.B[0] = value->w; v.ldb = d; v.strideB = 64L * d; v.seg_rows = 64;
-        v.C = h->part.as<float>() + (long)b * Q * hidden; v.ldc = hidden; v.strideC = 64;
-        v.split_stride = (long)M2 * hidden;
-        v.M = Q; v.N = 64; v.k_per_split = d / sk2; v.splitk = sk2; v.nbatch = H;
-        HIP_TRY(launch_qf_gemm(v, false, stream));
-    }
+    QfGemm v{};
+    v.A = h->O.as<float>(); v.lda = d; v.strideA = (long)Q * d; v.strideA2 = (long)rows * d;   // inner = head, outer = chunk
+    v.B[0] = value->w; v.ldb = d; v.strideB = 64L * d; v.strideB2 = 0; v.seg_rows = 64;
+    v.C = h->part.as<float>(); v.ldc = hidden; v.strideC = 64; v.strideC2 = (long)Q * hidden;
+    v.split_stride = (long)M2 * hidden;
+    v.M = Q; v.N = 64; v.k_per_split = d / sk2; v.splitk = sk2; v.nbatch = nb * H; v.inner = H;
+    HIP_TRY(launch_qf_gemm(v, false, stream));
     QfEpilogue e{};
     e.parts = h->part.as<float>(); e.nsplit = sk2; e.split_stride = (long)M2 * hidden; e.ld_in = hidden;
     e.bias[0] = value->b; e.seg_cols = hidden; e.act = QF_ACT_NONE;
@@ -112,6 +123,14 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     e.residual = along; e.ld_res = hidden; e.res_rows = M2;
     e.out = merged; e.ld_out = hidden; e.M = M2; e.width = hidden; e.eps = c.ln_eps;
     HIP_TRY(launch_qf_epilogue(e, stream));
+    return INFV_OK;
+}
+
+int ensure_streams(infv_vqf_s* h) {
+    if (h->side) return INFV_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
     return INFV_OK;
 }
 
@@ -150,7 +169,7 @@ int infv_vqf_short_attention(infv_vqf_handle h, const float* frames, int32_t n_t
                              float* merged, void* stream) {
     if (!h || !frames || !xq || !key || !value || !merged || !key->w || !value->w || !value->b)
         return fail(INFV_ERR_INVALID, "null argument");
-    return short_attention(h, frames, 1, n_tokens, xq, key, value, a_long, merged, static_cast<hipStream_t>(stream));
+    return short_attention(h, frames, 1, n_tokens, xq, false, key, value, a_long, merged, static_cast<hipStream_t>(stream));
 }
 
 int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const float* frames, int32_t T,
@@ -206,7 +225,7 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                                        h->along.as<float>(), stream_)) return rc;
             along = h->along.as<float>();
         }
-        if (int rc = short_attention(h, frames, 1, n_tokens, h->xq.as<float>(), &L.x_k, &L.x_v, along,
+        if (int rc = short_attention(h, frames, 1, n_tokens, h->xq.as<float>(), false, &L.x_k, &L.x_v, along,
                                      h->merged.as<float>(), stream)) return rc;
         LinearCall xo{h->merged.as<float>(), Q, Hd, {&L.x_o}, 1, Hd};
         xo.residual = h->h1.as<float>(); xo.res_rows = Q; xo.ln = &L.x_ln; xo.y = h->h2.as<float>();
@@ -226,6 +245,176 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
         LinearCall pj{hcur, Q, Hd, {&w->llama_proj}, 1, c.proj_out};
         pj.y = llama_out;
         if (int rc = run_linear(h, pj, stream)) return rc;
+    }
+    return INFV_OK;
+}
+
+int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const float* frames, int32_t n_chunks,
+                          int32_t T, const infv_vqf_weights* w, const double* u, int32_t new_video,
+                          float* hidden_out, float* llama_out, float* llama_mean, void* stream_) {
+    if (!h || !frames || !w || n_chunks < 1) return fail(INFV_ERR_INVALID, "bad argument");
+    const infv_vqf_config& c = h->cfg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool use_ltm = c.alpha != 1.0f;
+    if (use_ltm && !ltm) return fail(INFV_ERR_INVALID, "alpha != 1 needs the per-layer LTM handles");
+    if (T < 1) return fail(INFV_ERR_INVALID, "T must be >= 1");
+    if ((llama_out || llama_mean) && (c.proj_out <= 0 || !w->llama_proj.w)) return fail(INFV_ERR_INVALID, "llama output without llama_proj");
+    if (int rc = ensure_streams(h)) return rc;
+    const int Q = c.n_query, Hd = c.hidden, C = n_chunks, S = c.nb_samples;
+    const int n_tokens = T * c.tokens_per_frame;
+    const long chunk_k = (long)n_tokens * c.enc_width;
+    const long M = (long)C * Q;                               // rows of the whole-video activations
+    // ---- workspaces: whole-video activations + per-block scratch ----
+    const int RB = C < 64 ? C : 64;                           // chunks per row block of the query-token GEMMs
+    const int NB = C < 16 ? C : 16;                           // chunks per sub-batch of the short-term attention
+    {
+        const size_t act = (size_t)M * Hd * sizeof(float);
+        bool grow = act > h->vA.bytes || (size_t)RB * Q * 3 * Hd * sizeof(float) > h->vqkv.bytes ||
+                    (size_t)RB * Q * c.inter * sizeof(float) > h->vinter.bytes ||
+                    (use_ltm && ((size_t)C * S * sizeof(double) > h->vu.bytes || (size_t)C * T * c.enc_width * sizeof(float) > h->vkbar.bytes));
+        if (grow) HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(h->vA.reserve(act)); HIP_TRY(h->v1.reserve(act)); HIP_TRY(h->v2.reserve(act)); HIP_TRY(h->vxq.reserve(act));
+        HIP_TRY(h->vshort.reserve(act)); HIP_TRY(h->vmerged.reserve(act));
+        if (use_ltm) {
+            HIP_TRY(h->valong.reserve(act));
+            HIP_TRY(h->vu.reserve((size_t)C * S * sizeof(double)));
+            HIP_TRY(h->vkbar.reserve((size_t)C * T * c.enc_width * sizeof(float)));
+        }
+        HIP_TRY(h->vqkv.reserve((size_t)RB * Q * 3 * Hd * sizeof(float)));
+        HIP_TRY(h->vsa.reserve((size_t)RB * Q * Hd * sizeof(float)));
+        HIP_TRY(h->vinter.reserve((size_t)RB * Q * c.inter * sizeof(float)));
+        HIP_TRY(h->v_h1s.reserve((size_t)Q * Hd * sizeof(float)));
+        HIP_TRY(h->v_xqs.reserve((size_t)Q * Hd * sizeof(float)));
+    }
+    float* vA = h->vA.as<float>(); float* v1 = h->v1.as<float>(); float* v2 = h->v2.as<float>();
+    float* vxq = h->vxq.as<float>(); float* valong = h->valong.as<float>();
+    float* vshort = h->vshort.as<float>(); float* vmerged = h->vmerged.as<float>();
+
+    // embeddings: LayerNorm of the learned query tokens (chunk-independent)
+    QfEpilogue e0{};
+    e0.parts = w->query_tokens; e0.nsplit = 1; e0.ld_in = Hd; e0.seg_cols = Hd; e0.scale = 1.f; e0.res_scale = 1.f;
+    e0.gamma = w->emb_ln.gamma; e0.beta = w->emb_ln.beta; e0.eps = c.ln_eps;
+    e0.out = h->h_a.as<float>(); e0.ld_out = Hd; e0.M = Q; e0.width = Hd; e0.res_rows = 1;
+    HIP_TRY(launch_qf_epilogue(e0, stream));
+
+    auto ltm_u = [&](int l) -> int {                          // u[:, l, :] -> contiguous [C][S] for a one-layer handle
+        if (!u) return INFV_OK;
+        HIP_TRY(hipMemcpy2DAsync(h->vu.p, (size_t)S * sizeof(double), u + (size_t)l * S, (size_t)c.n_layers * S * sizeof(double),
+                                 (size_t)S * sizeof(double), (size_t)C, hipMemcpyDeviceToDevice, stream));
+        return INFV_OK;
+    };
+
+    for (int l = 0; l < c.n_layers; ++l) {
+        const infv_vqf_layer& L = w->layer[l];
+        infv_ltm_proj pr{};
+        pr.wk = L.x_k.w; pr.bk = L.x_k.b; pr.wv = L.x_v.w; pr.bv = L.x_v.b;
+        const bool shared = (l == 0);                         // layer 0: the hidden states entering it do not depend on the chunk
+        const float* res1;                                    // residual / input of the cross-attention block
+        int res1_rows;
+        if (shared) {
+            // ---- self-attention block + cross query once ----
+            LinearCall qkv{h->h_a.as<float>(), Q, Hd, {&L.self_q, &L.self_k, &L.self_v}, 3, Hd};
+            qkv.y = h->qkv.as<float>();
+            if (int rc = run_linear(h, qkv, stream)) return rc;
+            HIP_TRY(launch_qf_self_attention(h->qkv.as<float>(), 1, Q, c.n_heads, h->sa.as<float>(), stream));
+            LinearCall so{h->sa.as<float>(), Q, Hd, {&L.self_o}, 1, Hd};
+            so.residual = h->h_a.as<float>(); so.res_rows = Q; so.ln = &L.self_ln; so.y = h->v_h1s.as<float>();
+            if (int rc = run_linear(h, so, stream)) return rc;
+            LinearCall xq{h->v_h1s.as<float>(), Q, Hd, {&L.x_q}, 1, Hd};
+            xq.y = h->v_xqs.as<float>();
+            if (int rc = run_linear(h, xq, stream)) return rc;
+            res1 = h->v_h1s.as<float>(); res1_rows = Q;
+            // ---- long-term memory of every chunk with the constant query: the whole-video fast path ----
+            if (use_ltm) {
+                if (int rc = ltm_u(l)) return rc;
+                if (int rc = infv_ltm_consolidate(ltm[l], frames, C, T, h->v_xqs.as<float>(), Q, &pr, u ? h->vu.as<double>() : nullptr,
+                                                  new_video, valong, stream_)) return rc;
+            }
+            // ---- short-term attention, merged with the long-term context ----
+            for (int c0 = 0; c0 < C; c0 += NB) {
+                const int nb = C - c0 < NB ? C - c0 : NB;
+                if (int rc = short_attention(h, frames + c0 * chunk_k, nb, n_tokens, h->v_xqs.as<float>(), true, &L.x_k, &L.x_v,
+                                             use_ltm ? valong + (long)c0 * Q * Hd : nullptr, vmerged + (long)c0 * Q * Hd, stream)) return rc;
+            }
+        } else {
+            // ---- self-attention block + cross query of every chunk (row blocks) ----
+            for (int c0 = 0; c0 < C; c0 += RB) {
+                const int nb = C - c0 < RB ? C - c0 : RB;
+                const long r0 = (long)c0 * Q * Hd;
+                LinearCall qkv{vA + r0, nb * Q, Hd, {&L.self_q, &L.self_k, &L.self_v}, 3, Hd};
+                qkv.y = h->vqkv.as<float>();
+                if (int rc = run_linear(h, qkv, stream)) return rc;
+                HIP_TRY(launch_qf_self_attention(h->vqkv.as<float>(), nb, Q, c.n_heads, h->vsa.as<float>(), stream));
+                LinearCall so{h->vsa.as<float>(), nb * Q, Hd, {&L.self_o}, 1, Hd};
+                so.residual = vA + r0; so.res_rows = nb * Q; so.ln = &L.self_ln; so.y = v1 + r0;
+                if (int rc = run_linear(h, so, stream)) return rc;
+                LinearCall xq{v1 + r0, nb * Q, Hd, {&L.x_q}, 1, Hd};
+                xq.y = vxq + r0;
+                if (int rc = run_linear(h, xq, stream)) return rc;
+            }
+            res1 = v1; res1_rows = (int)M;
+            // ---- long-term memory with per-chunk queries: the sequential per-call chain, on the side stream, while
+            //      the main stream runs this layer's short-term attention ----
+            if (use_ltm) {
+                if (int rc = ltm_u(l)) return rc;
+                HIP_TRY(hipEventRecord(h->ev_main, stream));
+                HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
+                if (new_video)
+                    if (int rc = infv_ltm_reset(ltm[l])) return rc;
+                if (int rc = infv_ltm_pool(ltm[l], frames, (int64_t)C * T, h->vkbar.as<float>(), h->side)) return rc;
+                for (int ch = 0; ch < C; ++ch)
+                    if (int rc = infv_ltm_step(ltm[l], h->vkbar.as<float>() + (long)ch * T * c.enc_width, T, vxq + (long)ch * Q * Hd, Q, &pr,
+                                               u ? h->vu.as<double>() + (size_t)ch * S : nullptr, valong + (long)ch * Q * Hd, h->side)) return rc;
+                HIP_TRY(hipEventRecord(h->ev_side, h->side));
+            }
+            for (int c0 = 0; c0 < C; c0 += NB) {
+                const int nb = C - c0 < NB ? C - c0 : NB;
+                if (int rc = short_attention(h, frames + c0 * chunk_k, nb, n_tokens, vxq + (long)c0 * Q * Hd, false, &L.x_k, &L.x_v,
+                                             nullptr, (use_ltm ? vshort : vmerged) + (long)c0 * Q * Hd, stream)) return rc;
+            }
+            if (use_ltm) {
+                HIP_TRY(hipStreamWaitEvent(stream, h->ev_side, 0));
+                for (long m0 = 0; m0 < M; m0 += 32768) {       // merged = alpha * short + (1 - alpha) * long
+                    QfEpilogue em{};
+                    em.parts = vshort + m0 * Hd; em.nsplit = 1; em.ld_in = Hd; em.seg_cols = Hd;
+                    em.scale = c.alpha; em.res_scale = (float)(1.0 - (double)c.alpha);
+                    em.residual = valong + m0 * Hd; em.ld_res = Hd; em.res_rows = (int)(M - m0 < 32768 ? M - m0 : 32768);
+                    em.out = vmerged + m0 * Hd; em.ld_out = Hd; em.M = em.res_rows; em.width = Hd; em.eps = c.ln_eps;
+                    HIP_TRY(launch_qf_epilogue(em, stream));
+                }
+            }
+        }
+        // ---- cross-attention output + query FFN of every chunk (row blocks) ----
+        for (int c0 = 0; c0 < C; c0 += RB) {
+            const int nb = C - c0 < RB ? C - c0 : RB;
+            const long r0 = (long)c0 * Q * Hd;
+            LinearCall xo{vmerged + r0, nb * Q, Hd, {&L.x_o}, 1, Hd};
+            xo.residual = shared ? res1 : res1 + r0; xo.res_rows = shared ? res1_rows : nb * Q; xo.ln = &L.x_ln; xo.y = v2 + r0;
+            if (int rc = run_linear(h, xo, stream)) return rc;
+            LinearCall fi{v2 + r0, nb * Q, Hd, {&L.ffn_in}, 1, c.inter};
+            fi.act = QF_ACT_GELU; fi.y = h->vinter.as<float>();
+            if (int rc = run_linear(h, fi, stream)) return rc;
+            LinearCall fo{h->vinter.as<float>(), nb * Q, c.inter, {&L.ffn_out}, 1, Hd};
+            fo.residual = v2 + r0; fo.res_rows = nb * Q; fo.ln = &L.ffn_ln; fo.y = vA + r0;
+            if (int rc = run_linear(h, fo, stream)) return rc;
+        }
+    }
+    if (hidden_out)
+        HIP_TRY(hipMemcpyAsync(hidden_out, vA, (size_t)M * Hd * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (llama_out || llama_mean) {
+        float* lo = llama_out;
+        if (!lo) {                                             // only the mean is wanted: project into scratch
+            const size_t need = (size_t)M * c.proj_out * sizeof(float);
+            if (need > h->S.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->S.reserve(need)); }
+            lo = h->S.as<float>();
+        }
+        for (int c0 = 0; c0 < C; c0 += RB) {
+            const int nb = C - c0 < RB ? C - c0 : RB;
+            LinearCall pj{vA + (long)c0 * Q * Hd, nb * Q, Hd, {&w->llama_proj}, 1, c.proj_out};
+            pj.y = lo + (long)c0 * Q * c.proj_out;
+            if (int rc = run_linear(h, pj, stream)) return rc;
+        }
+        if (llama_mean) HIP_TRY(launch_qf_mean(lo, C, (long)Q * c.proj_out, llama_mean, stream));
     }
     return INFV_OK;
 }

@@ -8,6 +8,7 @@ namespace infv {
 constexpr int kQfMaxSeg = 4;
 
 // C[z][m][o] (+)= sum_k A[b][m][k] * Bop[b][k][o]   for z = b * splitk + s, k in split s.
+// The batch index b = bo * inner + bi addresses operands as  X + bi * strideX + bo * strideX2  (inner = 0: one level).
 //   NT: Bop[k][o] = B[o][k]  (B rows are output columns; up to kQfMaxSeg row segments of seg_rows rows each)
 //   NN: Bop[k][o] = B[k][o]
 struct QfGemm {
@@ -15,6 +16,7 @@ struct QfGemm {
     const float* B[kQfMaxSeg];  long ldb;  long strideB;  int seg_rows;
     float* C;  long ldc;  long strideC;  long split_stride;
     int M, N, k_per_split, splitk, nbatch;
+    int inner;  long strideA2, strideB2, strideC2;   // optional second batch level (zero-initialised = unused)
 };
 hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream);
 int qf_pick_splitk(int M, int N, int K, int nbatch);

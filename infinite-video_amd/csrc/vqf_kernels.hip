@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
     const int b = blockIdx.z / g.splitk, s = blockIdx.z - b * g.splitk;
     const int kbeg = s * g.k_per_split;
     const int ntiles = g.k_per_split / kBK;
-    const float* A = g.A + (long)b * g.strideA;
-    float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
+    const int bo = g.inner > 0 ? b / g.inner : 0, bi = g.inner > 0 ? b - bo * g.inner : b;
+    const float* A = g.A + (long)bi * g.strideA + (long)bo * g.strideA2;
+    float* C = g.C + (long)bi * g.strideC + (long)bo * g.strideC2 + (long)s * g.split_stride;
+    const long boff = (long)bi * g.strideB + (long)bo * g.strideB2;
 
     const int c4 = tid & 7, row0 = tid >> 3;
     const float* a_src[AR];
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
             const int o = n0 + row0 + 32 * i;
             if (o < g.N) {
                 const int seg = o / g.seg_rows;
-                b_src[i] = g.B[seg] + (long)b * g.strideB + (long)(o - seg * g.seg_rows) * g.ldb + kbeg + c4 * 4;
+                b_src[i] = g.B[seg] + boff + (long)(o - seg * g.seg_rows) * g.ldb + kbeg + c4 * 4;
             } else {
                 b_src[i] = nullptr;
             }
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
 #pragma unroll
         for (int i = 0; i < BR; ++i)
             b_src[i] = (n0 + 4 * cn < g.N)
-                           ? g.B[0] + (long)b * g.strideB + (long)(kbeg + kr + KT * i) * g.ldb + n0 + 4 * cn
+                           ? g.B[0] + boff + (long)(kbeg + kr + KT * i) * g.ldb + n0 + 4 * cn
                            : nullptr;
         b_step = (long)kBK * g.ldb;
     }

@@ -302,6 +302,63 @@ class InfVideoEncoder(nn.Module):
         self.last_hidden = hidden
         return hidden, llama
 
+    # ------------------------------------------------------------------ a whole video, layer-major
+    def encode_frames_batch(self, frames: torch.Tensor, new_video: bool, u: Optional[torch.Tensor] = None,
+                            want_hidden: bool = False):
+        """frames [C, T*P, d] (C chunks of equal length, device) -> (inputs_llama per chunk [C, Q, llama],
+        their mean over chunks [1, Q, llama], last_hidden_state per chunk [C, Q, hidden] or None).
+        Equals C calls of :meth:`encode_frames` (``new_video`` on the first only) but runs layer-major in one C call
+        (``infv_vqf_encode_video``): layer 0's LTM takes the whole-video fast path, every query-token block is batched
+        over chunks.  ``u`` [C, n_layers, 512] float64; by default drawn from torch's global CPU generator in the
+        order a per-chunk run of the reference would consume it."""
+        if not frames.is_cuda:
+            raise RuntimeError("the video Q-former path runs on the HIP device only (no CPU fallback)")
+        cfg = self.video_Qformer.config
+        P, Q, Ln = self.tokens_per_frame, self.num_video_query_token, cfg.num_hidden_layers
+        if frames.dim() != 3 or frames.size(2) != cfg.encoder_width or frames.size(1) % P:
+            raise ValueError(f"frames must be [C, T*{P}, {cfg.encoder_width}]")
+        device = frames.device
+        Cn, T = frames.size(0), frames.size(1) // P
+        k = _dev_f32(frames, device)
+        h = self._handle(device)
+        lib = _lib.load()
+        use_ltm = cfg.alpha != 1.0
+        handles = (C.c_void_p * Ln)()
+        if use_ltm:
+            had_memory = False
+            for l, m in enumerate(self.video_Qformer.ltm_modules):
+                m.length = m.target_len = frames.size(1)
+                eng = m._get_engine(device, Q)
+                eng.ensure_plan(T)
+                handles[l] = eng._h
+                had_memory = had_memory or eng.has_memory
+                m.count += Cn
+            sticky = bool(self.video_Qformer.ltm_modules[0].sticky_memories)
+            if u is None and sticky:
+                first_draws = 0 if (had_memory and not new_video) else 1      # chunk 0 of a new video resamples nothing
+                u = torch.zeros(Cn, Ln, NB_SAMPLES, dtype=torch.float64)
+                for c in range(first_draws, Cn):
+                    for l in range(Ln):
+                        u[c, l] = torch.rand(NB_SAMPLES, dtype=torch.float64)
+                        torch.rand(NB_SAMPLES, dtype=torch.float64)              # the in-bin draw of LTM.py:206
+            if u is not None:
+                u = u.to(device=device, dtype=torch.float64).contiguous()
+                if tuple(u.shape) != (Cn, Ln, NB_SAMPLES):
+                    raise ValueError(f"u must be [{Cn}, {Ln}, {NB_SAMPLES}]")
+        w, keep = self._weights(device)
+        hidden = torch.empty(Cn, Q, cfg.hidden_size, device=device, dtype=torch.float32) if want_hidden else None
+        llama = torch.empty(Cn, Q, self.llama_proj.out_features, device=device, dtype=torch.float32)
+        mean = torch.empty(1, Q, self.llama_proj.out_features, device=device, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            _lib.check(lib.infv_vqf_encode_video(h, handles if use_ltm else None, C.c_void_p(k.data_ptr()), Cn, T,
+                                                 C.byref(w), C.c_void_p(0 if u is None else u.data_ptr()),
+                                                 int(bool(new_video)),
+                                                 C.c_void_p(0 if hidden is None else hidden.data_ptr()),
+                                                 C.c_void_p(llama.data_ptr()), C.c_void_p(mean.data_ptr()), stream))
+        del keep
+        return llama, mean, hidden
+
     # ------------------------------------------------------------------ encode_video (infinityqa.py:280-344)
     def encode_video(self, new_video: bool = True):
         if not self.short_memory_buffer:
@@ -322,12 +379,27 @@ class InfVideoEncoder(nn.Module):
 
 
 def encode_long_video(model: InfVideoEncoder, frame_tokens: torch.Tensor, max_int: int,
-                      u_of_chunk=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                      u_of_chunk=None, batched: bool = False) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """The eval scripts' loop (run_inference_inf_video_llama_nextqa.py:179-196,228): split the video's per-frame
     token blocks [F, P, d] into chunks of ``max_int`` frames (ragged tail kept), ``new_video=(i == 0)``, mean of the
-    per-chunk LLM-side embeddings.  Returns (mean [1, Q, llama], per-chunk list)."""
-    embs = []
-    for i, blk in enumerate(torch.split(frame_tokens, max_int, dim=0)):
+    per-chunk LLM-side embeddings.  Returns (mean [1, Q, llama], per-chunk list).
+    ``batched=True`` pushes the full-length chunks through the layer-major whole-video path
+    (:meth:`InfVideoEncoder.encode_frames_batch`) and only a ragged tail chunk through the per-chunk path."""
+    blocks = list(torch.split(frame_tokens, max_int, dim=0))
+    embs: List[torch.Tensor] = []
+    start = 0
+    if batched:
+        n_full = sum(1 for b in blocks if b.size(0) == max_int)
+        if n_full > 0:
+            full = frame_tokens[:n_full * max_int].reshape(n_full, -1, frame_tokens.size(-1))
+            u = None
+            if u_of_chunk is not None:
+                u = torch.stack([torch.as_tensor(u_of_chunk(i)) for i in range(n_full)])
+            llama, _, _ = model.encode_frames_batch(full, new_video=True, u=u)
+            embs.extend(llama[i:i + 1] for i in range(n_full))
+            start = n_full
+    for i in range(start, len(blocks)):
+        blk = blocks[i]
         if u_of_chunk is None:
             model.short_memory_buffer = list(blk)
             emb, _ = model.encode_video(new_video=(i == 0))

@@ -100,3 +100,13 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_memory_file_format_rejects_foreign_files(tmp_path):
+    import torch
+    from safetensors.torch import save_file
+    from infinite_video_amd.memory_io import load_memory
+    p = str(tmp_path / "x.safetensors")
+    save_file({"a": torch.zeros(2)}, p, metadata={"format": "something-else"})
+    with pytest.raises(ValueError):
+        load_memory(p, [], "cpu")

@@ -138,3 +138,65 @@ def test_errors():
         m.encode_frames(torch.zeros(2, 64, 768, device="cuda:0"), new_video=True)
     with pytest.raises(ValueError):
         m.encode_frames(torch.zeros(1, 65, 768, device="cuda:0"), new_video=True)
+
+
+def test_memory_file_roundtrip_continues_the_document(tmp_path):
+    """Consolidate two chunks, write the memory file, load it into a fresh model: chunk 3 matches the golden."""
+    from infinite_video_amd.memory_io import load_memory, save_memory
+    case = QF_CASES[0]
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    a = make_model(case, weights, dev)
+    with pytest.raises(RuntimeError):
+        save_memory(str(tmp_path / "empty.safetensors"), a.video_Qformer.ltm_modules)
+    for c in range(2):
+        a.encode_frames(torch.from_numpy(frames[c]).unsqueeze(0).to(dev), new_video=(c == 0),
+                        u=torch.from_numpy(chunk_uniforms(case, c)))
+    path = str(tmp_path / "video.safetensors")
+    save_memory(path, a.video_Qformer.ltm_modules, user={"video": "qf_small", "chunks": 2})
+    b = make_model(case, weights, dev)
+    assert load_memory(path, b.video_Qformer.ltm_modules, dev) == {"video": "qf_small", "chunks": "2"}
+    for c in (2, 3):
+        _, llama = b.encode_frames(torch.from_numpy(frames[c]).unsqueeze(0).to(dev), new_video=False,
+                                   u=torch.from_numpy(chunk_uniforms(case, c)))
+        np.testing.assert_allclose(llama[0].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL)
+
+
+@pytest.mark.parametrize("case", [c for c in QF_CASES if len(set(c.chunk_T)) == 1], ids=lambda c: c.name)
+def test_layer_major_whole_video_matches_goldens_and_per_chunk(case):
+    """infv_vqf_encode_video (layer-major, LTM layer 0 on the whole-video fast path) == per-chunk encode == reference."""
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    Cn = len(case.chunk_T)
+    k = torch.from_numpy(np.stack(frames)).to(dev)
+    u = torch.from_numpy(np.stack([chunk_uniforms(case, c) for c in range(Cn)]))
+    llama, mean, hidden = m.encode_frames_batch(k, new_video=True, u=u, want_hidden=True)
+    torch.cuda.synchronize()
+    for c in range(Cn):
+        np.testing.assert_allclose(hidden[c].cpu().numpy(), g[f"c{c}_hidden"], atol=ATOL, err_msg=f"hidden c{c}")
+        np.testing.assert_allclose(llama[c].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL, err_msg=f"llama c{c}")
+    want = np.mean(np.stack([g[f"c{c}_llama"] for c in range(Cn)]), 0)
+    np.testing.assert_allclose(mean[0].cpu().numpy(), want, atol=ATOL)
+    if case.alpha != 1.0:
+        for l, ltm in enumerate(m.video_Qformer.ltm_modules):
+            Bsum = ltm.B_past[0].double().sum(1).cpu().numpy()
+            np.testing.assert_allclose(Bsum, g[f"c{Cn - 1}_l{l}_Bsum"], atol=5e-4, err_msg=f"final B l{l}")
+
+
+def test_layer_major_path_with_ragged_tail_and_global_rng():
+    from infinite_video_amd.video_qformer import encode_long_video
+    case = QF_CASES[0]                                   # 8, 8, 5: two full chunks batched + ragged tail per chunk
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    video = torch.cat([torch.from_numpy(f).reshape(-1, case.P, case.hidden) for f in frames[:3]]).to(dev)
+    mean, embs = encode_long_video(m, video, 8, u_of_chunk=lambda i: torch.from_numpy(chunk_uniforms(case, i)),
+                                   batched=True)
+    assert len(embs) == 3
+    for c in range(3):
+        np.testing.assert_allclose(embs[c][0].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL, err_msg=f"c{c}")
+    np.testing.assert_allclose(mean[0].cpu().numpy(), np.mean(np.stack([g[f"c{c}_llama"] for c in range(3)]), 0), atol=ATOL)
