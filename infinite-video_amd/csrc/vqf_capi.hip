@@ -78,9 +78,13 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     const infv_vqf_config& c = h->cfg;
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
-    const int sk = qf_pick_splitk(rows, d, n_tokens, nb);
+    int kps = n_tokens;
+    const int sk = qf_pick_splitk_fill(rows, d, n_tokens, nb, &kps);
     const int nq = shared_q ? 1 : nb;
-    const size_t needS = (size_t)nb * rows * n_tokens * sizeof(float);
+    // leading dimension of the score matrix: padded by 256 B so that its rows (the A operand of the second
+    // contraction, one 128-B line per row per k-tile) do not all map to the same memory channel
+    const long ldS = n_tokens + 64;
+    const size_t needS = (size_t)nb * rows * ldS * sizeof(float);
     const size_t needO = (size_t)sk * nb * rows * d * sizeof(float);
     const size_t needQt = (size_t)nq * rows * d * sizeof(float);
     if (needS > h->S.bytes || needO > h->O.bytes || needQt > h->qt.bytes) {
@@ -91,15 +95,15 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     QfGemm g{};                                             // S[b] = qt[b] . frames[b]^T
     g.A = h->qt.as<float>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
     g.B[0] = frames; g.ldb = d; g.strideB = (long)n_tokens * d; g.seg_rows = n_tokens;
-    g.C = h->S.as<float>(); g.ldc = n_tokens; g.strideC = (long)rows * n_tokens; g.split_stride = 0;
+    g.C = h->S.as<float>(); g.ldc = ldS; g.strideC = (long)rows * ldS; g.split_stride = 0;
     g.M = rows; g.N = n_tokens; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
     HIP_TRY(launch_qf_gemm(g, false, stream));
-    HIP_TRY(launch_qf_softmax_rows(h->S.as<float>(), (long)nb * rows, n_tokens, n_tokens, stream));
+    HIP_TRY(launch_qf_softmax_rows(h->S.as<float>(), (long)nb * rows, n_tokens, ldS, stream));
     QfGemm p{};                                             // O[b] = P[b] . frames[b]
-    p.A = h->S.as<float>(); p.lda = n_tokens; p.strideA = (long)rows * n_tokens;
+    p.A = h->S.as<float>(); p.lda = ldS; p.strideA = (long)rows * ldS;
     p.B[0] = frames; p.ldb = d; p.strideB = (long)n_tokens * d; p.seg_rows = d;
     p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
-    p.M = rows; p.N = d; p.k_per_split = n_tokens / sk; p.splitk = sk; p.nbatch = nb;
+    p.M = rows; p.N = d; p.k_per_split = kps; p.splitk = sk; p.nbatch = nb; p.K = n_tokens;
     HIP_TRY(launch_qf_gemm(p, true, stream));
     // per-head value projection as a GEMM batched over (chunk, head): [Q x d] . Wv_h^T -> [Q x 64], then
     // bias + merge with the long-term context in the row epilogue (Qformer.py:298-304)
@@ -266,7 +270,19 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     const long M = (long)C * Q;                               // rows of the whole-video activations
     // ---- workspaces: whole-video activations + per-block scratch ----
     const int RB = C < 64 ? C : 64;                           // chunks per row block of the query-token GEMMs
-    const int NB = C < 16 ? C : 16;                           // chunks per sub-batch of the short-term attention
+    // chunks per sub-batch of the short-term attention: the second contraction has few, long tiles per chunk
+    // (rows/128 x d/128 = 18 at the headline shape, K = T*P), so pick the count whose tile total fills whole rounds
+    // of the 256 CUs (16 chunks = 288 tiles ran at 56 % of 14 chunks' rate per tile)
+    int NB = C;
+    if (C > 8) {
+        const int tiles = ((c.n_heads * Q + 127) / 128) * ((c.enc_width + 127) / 128);
+        double best = -1.0;
+        for (int nb = 8; nb <= 32 && nb <= C; ++nb) {
+            const long t = (long)tiles * nb;
+            const double eff = (double)t / (double)(((t + 255) / 256) * 256);
+            if (eff >= best - 1e-9) { best = eff; NB = nb; }
+        }
+    }
     {
         const size_t act = (size_t)M * Hd * sizeof(float);
         bool grow = act > h->vA.bytes || (size_t)RB * Q * 3 * Hd * sizeof(float) > h->vqkv.bytes ||

@@ -16,10 +16,13 @@ struct QfGemm {
     const float* B[kQfMaxSeg];  long ldb;  long strideB;  int seg_rows;
     float* C;  long ldc;  long strideC;  long split_stride;
     int M, N, k_per_split, splitk, nbatch;
+    int K;                                           // total depth; 0 = splitk * k_per_split (the last split may be shorter)
     int inner;  long strideA2, strideB2, strideC2;   // optional second batch level (zero-initialised = unused)
 };
 hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream);
 int qf_pick_splitk(int M, int N, int K, int nbatch);
+// split-K that fills whole rounds of the 256 CUs: returns the split count and the (32-aligned) depth per split
+int qf_pick_splitk_fill(int M, int N, int K, int nbatch, int* k_per_split);
 
 enum QfAct { QF_ACT_NONE = 0, QF_ACT_GELU = 1 };
 // out[m][:] = LN?( scale * act( sum_s parts[s][m][:] + bias ) + res_scale * residual[m % res_rows] )    one workgroup per row

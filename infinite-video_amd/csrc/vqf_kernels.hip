@@ -27,15 +27,17 @@ template <int BM, int BN, bool NN>
 __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int kBPitch = BN + 4;                  // NN: B tile kept [k][n] as it lies in memory (b128 stores, b32 fragment reads)
     __shared__ float As[BM * kStride];
-    __shared__ float Bs[BN * kStride];
+    __shared__ float Bs[NN ? kBK * kBPitch : BN * kStride];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int b = blockIdx.z / g.splitk, s = blockIdx.z - b * g.splitk;
     const int kbeg = s * g.k_per_split;
-    const int ntiles = g.k_per_split / kBK;
+    const int kend = (g.K > 0 && kbeg + g.k_per_split > g.K) ? g.K : kbeg + g.k_per_split;   // the last split may be shorter
+    const int ntiles = kend > kbeg ? (kend - kbeg) / kBK : 0;
     const int bo = g.inner > 0 ? b / g.inner : 0, bi = g.inner > 0 ? b - bo * g.inner : b;
     const float* A = g.A + (long)bi * g.strideA + (long)bo * g.strideA2;
     float* C = g.C + (long)bi * g.strideC + (long)bo * g.strideC2 + (long)s * g.split_stride;
@@ -48,9 +50,10 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
         const int m = m0 + row0 + 32 * i;
         a_src[i] = (m < g.M) ? A + (long)m * g.lda + kbeg + c4 * 4 : nullptr;
     }
-    // B staging: NT -> same map as A (rows of B are output columns); NN -> thread = (4 output columns, one k row)
-    constexpr int KT = 256 / (BN / 4);               // NN: threads along k per column group
-    const int cn = tid / KT, kr = tid - cn * KT;
+    // B staging: NT -> same map as A (rows of B are output columns); NN -> thread = (one k row, 4 consecutive output
+    // columns), consecutive lanes along the row
+    constexpr int KT = 256 / (BN / 4);               // NN: k rows covered per pass
+    const int kr = tid / (BN / 4), cn = tid - kr * (BN / 4);
     const float* b_src[BR];
     long b_step;
     if (!NN) {
@@ -94,8 +97,7 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
         } else {
 #pragma unroll
             for (int i = 0; i < BR; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(4 * cn + j) * kStride + kr + KT * i] = b_reg[i][j];
+                *reinterpret_cast<floatx4*>(&Bs[(kr + KT * i) * kBPitch + 4 * cn]) = b_reg[i];
         }
     };
 
@@ -113,25 +115,43 @@ __global__ __launch_bounds__(256) void qf_gemm_kernel(QfGemm g) {
         store_tile();
         __syncthreads();
         if (t + 1 < ntiles) load_tile(t + 1);
-        floatx4 af[TM][4], bf[TN][4];
+        floatx4 af[TM][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
                 af[i][v] = *reinterpret_cast<const floatx4*>(&As[(wm * (BM / 2) + i * 32 + li) * kStride + 16 * kk + 4 * v]);
+        if (!NN) {
+            floatx4 bf[TN][4];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                bf[j][v] = *reinterpret_cast<const floatx4*>(&Bs[(wn * (BN / 2) + j * 32 + li) * kStride + 16 * kk + 4 * v]);
+                for (int v = 0; v < 4; ++v)
+                    bf[j][v] = *reinterpret_cast<const floatx4*>(&Bs[(wn * (BN / 2) + j * 32 + li) * kStride + 16 * kk + 4 * v]);
 #pragma unroll
-        for (int st = 0; st < 16; ++st)
+            for (int st = 0; st < 16; ++st)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st >> 2][st & 3], bf[j][st >> 2][st & 3],
-                                                                     acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st >> 2][st & 3], bf[j][st >> 2][st & 3],
+                                                                         acc[i][j], 0, 0, 0);
+        } else {
+            // lane (li, kk) of MFMA step st needs B[k = 16 kk + st][column li]: 32 consecutive floats per half wave
+            float bs[TN][16];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int st = 0; st < 16; ++st)
+                    bs[j][st] = Bs[(16 * kk + st) * kBPitch + wn * (BN / 2) + j * 32 + li];
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st >> 2][st & 3], bs[j][st], acc[i][j], 0, 0, 0);
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -154,6 +174,26 @@ int qf_pick_splitk(int M, int N, int K, int nbatch) {
     int sk = 1;
     while (tiles * sk < 192 && sk < 16 && K % (kBK * sk * 2) == 0) sk *= 2;
     return sk;
+}
+
+int qf_pick_splitk_fill(int M, int N, int K, int nbatch, int* k_per_split) {
+    const int bm = qf_big_tiles(M, N) ? 128 : 64;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * nbatch;
+    const int ktiles = K / kBK;
+    int best_sk = 1;
+    double best = -1.0;
+    for (int sk = 1; sk <= 16 && sk <= ktiles; ++sk) {
+        const int per = (ktiles + sk - 1) / sk;
+        if ((long)per * (sk - 1) >= ktiles) continue;                 // an empty last split
+        const long wgs = tiles * sk;
+        // rounds of 256 CUs, each as long as its longest workgroup (per k-tiles)
+        const double work = (double)tiles * ktiles;
+        const double cost = (double)((wgs + 255) / 256) * 256.0 * per;
+        const double eff = work / cost - 0.002 * sk;                  // prefer fewer slabs at equal fill
+        if (eff > best) { best = eff; best_sk = sk; }
+    }
+    *k_per_split = ((ktiles + best_sk - 1) / best_sk) * kBK;
+    return best_sk;
 }
 
 hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream) {

@@ -22,11 +22,27 @@ def main():
     ap.add_argument("--T", type=int, default=256)
     ap.add_argument("--alpha", type=float, default=0.9)
     ap.add_argument("--distinct", type=int, default=16, help="distinct chunk tensors cycled through")
+    ap.add_argument("--batched", type=int, default=0, help="chunks of one layer-major whole-video call (0 = per-chunk mode)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     m = InfVideoEncoder(num_basis=256, tau=0.75, alpha=args.alpha, sticky=True)
     m.load_reference_state_dict(synth.video_qformer_weights())
     m = m.to(dev)
+    if args.batched:
+        Cn = args.batched
+        frames = torch.randn(Cn, args.T * 32, 768, device=dev)
+        u = torch.from_numpy(synth.gibbs_uniforms(Cn, 2)).to(dev)
+        m.encode_frames_batch(frames[:min(Cn, 32)], new_video=True, u=u[:min(Cn, 32)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.encode_frames_batch(frames, new_video=True, u=u)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flops = 2 * 2 * (2 * 384 * 768 * args.T * 32)
+        print(json.dumps({"what": "encode_video counterpart, layer-major whole video", "T": args.T, "alpha": args.alpha,
+                          "chunks": Cn, "ms_per_chunk": 1e3 * dt / Cn, "chunks_per_s": Cn / dt,
+                          "short_attention_tflops": flops * Cn / dt / 1e12}))
+        return
     ks = [torch.randn(1, args.T * 32, 768, device=dev) for _ in range(args.distinct)]
     u = torch.from_numpy(synth.gibbs_uniforms(args.chunks + 4, 2)).to(dev)
     for c in range(4):
