@@ -57,6 +57,12 @@ typedef struct {
 int infv_vqf_create(const infv_vqf_config* cfg, infv_vqf_handle* out);
 int infv_vqf_destroy(infv_vqf_handle h);
 
+/* Arithmetic of the two big contractions of the short-term attention ([H*Q x d x T*P] each):
+ *   0 (default)  split-bf16: every fp32 operand as hi + lo bf16, three bf16 MFMA products, fp32 accumulation
+ *                (error ~1e-5 relative, inside the path's 1e-3 budget, ~2.5x faster);
+ *   1            exact fp32 MFMA (bitwise an fp32 fma chain). */
+int infv_vqf_set_precision(infv_vqf_handle h, int32_t exact_fp32);
+
 /* Short-term cross-attention of one layer over one chunk's frame tokens, merged with the long-term context:
  *   merged = alpha * softmax((xq W-free restatement, see vqf_kernels.hip)) ... = Qformer.py:232-304 for a cross layer.
  * frames [n_tokens][enc_width], xq [n_query][hidden] (= self.query(hidden_states), bias applied),

@@ -3,6 +3,7 @@
 #include "capi_common.h"
 #include "vqf_internal.h"
 
+#include <cstdlib>
 #include <new>
 
 using namespace infv;
@@ -10,8 +11,10 @@ using namespace infv;
 struct infv_vqf_s {
     infv_vqf_config cfg;
     int dev = 0;
+    bool exact_fp32 = false;
     // workspaces (grown on demand; a growing call synchronises the device first)
     DeviceBuf part, h_a, h_b, h1, h2, qkv, sa, xq, along, qt, S, O, merged, inter, kbar;
+    DeviceBuf sFh, sFl, sTh, sTl, sPh, sPl, sQh, sQl;   // split-bf16 operands of the short-term attention
     // whole-video (layer-major) path
     DeviceBuf vA, v1, v2, vxq, valong, vshort, vmerged, vqkv, vsa, vinter, vu, vkbar, v_h1s, v_xqs;
     hipStream_t side = nullptr;
@@ -92,6 +95,32 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
         HIP_TRY(h->S.reserve(needS)); HIP_TRY(h->O.reserve(needO)); HIP_TRY(h->qt.reserve(needQt));
     }
     HIP_TRY(launch_qf_qtilde(xq, nq, Q, H, d, key->w, h->qt.as<float>(), stream));
+    // Both big contractions ( [H*Q x d x n_tokens] each ) run as split-bf16 (three bf16 MFMA products, fp32 accumulate):
+    // their rounding (~1e-5) only feeds the read-out.  INFV_VQF_FP32=1 selects the exact-fp32 MFMA kernels instead.
+    static const bool want_fp32 = [] { const char* e = getenv("INFV_VQF_FP32"); return e && atoi(e) != 0; }();
+    if (!want_fp32 && !h->exact_fp32 && d % 64 == 0) {
+        const size_t szF = (size_t)nb * n_tokens * d * 2, szP = (size_t)nb * rows * n_tokens * 2, szQ = (size_t)nq * rows * d * 2;
+        if (szF > h->sFh.bytes || szP > h->sPh.bytes || szQ > h->sQh.bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->sFh.reserve(szF)); HIP_TRY(h->sFl.reserve(szF)); HIP_TRY(h->sTh.reserve(szF)); HIP_TRY(h->sTl.reserve(szF));
+            HIP_TRY(h->sPh.reserve(szP)); HIP_TRY(h->sPl.reserve(szP)); HIP_TRY(h->sQh.reserve(szQ)); HIP_TRY(h->sQl.reserve(szQ));
+        }
+        HIP_TRY(launch_split_transpose(frames, nb, n_tokens, d, h->sFh.p, h->sFl.p, h->sTh.p, h->sTl.p, stream));
+        HIP_TRY(launch_split_rows(h->qt.as<float>(), d, (long)nq * rows, d, h->sQh.p, h->sQl.p, d, stream));
+        SplitGemm g{};                                        // S[b] = qt[b] . frames[b]^T
+        g.A_hi = h->sQh.as<__bf16>(); g.A_lo = h->sQl.as<__bf16>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
+        g.B_hi = h->sFh.as<__bf16>(); g.B_lo = h->sFl.as<__bf16>(); g.ldb = d; g.strideB = (long)n_tokens * d;
+        g.C = h->S.as<float>(); g.ldc = ldS; g.strideC = (long)rows * ldS; g.split_stride = 0;
+        g.M = rows; g.N = n_tokens; g.K = d; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
+        HIP_TRY(launch_split_gemm(g, stream));
+        HIP_TRY(launch_softmax_rows_split(h->S.as<float>(), (long)nb * rows, n_tokens, ldS, h->sPh.p, h->sPl.p, n_tokens, stream));
+        SplitGemm p{};                                        // O[b] = P[b] . frames[b]
+        p.A_hi = h->sPh.as<__bf16>(); p.A_lo = h->sPl.as<__bf16>(); p.lda = n_tokens; p.strideA = (long)rows * n_tokens;
+        p.B_hi = h->sTh.as<__bf16>(); p.B_lo = h->sTl.as<__bf16>(); p.ldb = n_tokens; p.strideB = (long)d * n_tokens;
+        p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
+        p.M = rows; p.N = d; p.K = n_tokens; p.k_per_split = kps; p.splitk = sk; p.nbatch = nb;
+        HIP_TRY(launch_split_gemm(p, stream));
+    } else {
     QfGemm g{};                                             // S[b] = qt[b] . frames[b]^T
     g.A = h->qt.as<float>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
     g.B[0] = frames; g.ldb = d; g.strideB = (long)n_tokens * d; g.seg_rows = n_tokens;
@@ -105,9 +134,11 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
     p.M = rows; p.N = d; p.k_per_split = kps; p.splitk = sk; p.nbatch = nb; p.K = n_tokens;
     HIP_TRY(launch_qf_gemm(p, true, stream));
+    }
+    const long o_split_stride = (long)nb * rows * d;
     // per-head value projection as a GEMM batched over (chunk, head): [Q x d] . Wv_h^T -> [Q x 64], then
     // bias + merge with the long-term context in the row epilogue (Qformer.py:298-304)
-    HIP_TRY(launch_qf_sum_slabs(h->O.as<float>(), sk, p.split_stride, (long)nb * rows * d, stream));
+    HIP_TRY(launch_qf_sum_slabs(h->O.as<float>(), sk, o_split_stride, (long)nb * rows * d, stream));
     const int M2 = nb * Q, hidden = c.hidden;
     int sk2 = 8;
     while (sk2 > 1 && (d % (32 * sk2) || nb * H * sk2 > 4096)) sk2 >>= 1;
@@ -165,6 +196,12 @@ int infv_vqf_destroy(infv_vqf_handle h) {
     if (!h) return INFV_OK;
     (void)hipDeviceSynchronize();
     delete h;
+    return INFV_OK;
+}
+
+int infv_vqf_set_precision(infv_vqf_handle h, int32_t exact_fp32) {
+    if (!h) return fail(INFV_ERR_INVALID, "null handle");
+    h->exact_fp32 = exact_fp32 != 0;
     return INFV_OK;
 }
 

@@ -50,6 +50,22 @@ hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipSt
 // parts[0][i] = sum_s parts[s][i]  (slabs `stride` floats apart, n a multiple of 4)
 hipError_t launch_qf_sum_slabs(float* parts, int nsplit, long stride, long n, hipStream_t stream);
 
+// ---- split-bf16 contractions (split_gemm.hip) ----
+// C[z][m][o] = sum_k (A_hi + A_lo)[b][m][k] * (B_hi + B_lo)[b][o][k], z = b * splitk + s; all operands K-contiguous bf16
+struct SplitGemm {
+    const __bf16* A_hi; const __bf16* A_lo; long lda, strideA;
+    const __bf16* B_hi; const __bf16* B_lo; long ldb, strideB;
+    float* C; long ldc, strideC, split_stride;
+    int M, N, K, k_per_split, splitk, nbatch;
+};
+hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream);
+// x [rows][cols] fp32 -> hi = bf16(x), lo = bf16(x - hi)
+hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, void* hi, void* lo, long ld_out, hipStream_t stream);
+// F [nb][n][d] fp32 -> Fh/Fl [nb][n][d] and Th/Tl [nb][d][n] (bf16 hi/lo)
+hipError_t launch_split_transpose(const float* F, int nb, int n, int d, void* Fh, void* Fl, void* Th, void* Tl, hipStream_t stream);
+// softmax of fp32 score rows, written as bf16 hi/lo
+hipError_t launch_softmax_rows_split(const float* S, long n_rows, int len, long ld, void* Ph, void* Pl, long ld_out, hipStream_t stream);
+
 // out[m][:] = mean over nb of in[b][m][:]
 hipError_t launch_qf_mean(const float* in, int nb, long n, float* out, hipStream_t stream);
 

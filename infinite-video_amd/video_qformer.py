@@ -174,6 +174,7 @@ class InfVideoEncoder(nn.Module):
             p.requires_grad = False
         self._vqf = None
         self._vqf_dev = None
+        self.exact_fp32 = False        # True: exact-fp32 MFMA for the short-term attention instead of split-bf16
         self.last_hidden: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ weights
@@ -222,6 +223,13 @@ class InfVideoEncoder(nn.Module):
         return w, keep
 
     def _handle(self, device: torch.device):
+        h = self._handle_raw(device)
+        if getattr(self, "_vqf_exact", None) != bool(self.exact_fp32):
+            _lib.check(_lib.load().infv_vqf_set_precision(h, int(bool(self.exact_fp32))))
+            self._vqf_exact = bool(self.exact_fp32)
+        return h
+
+    def _handle_raw(self, device: torch.device):
         if self._vqf is not None and self._vqf_dev == device:
             return self._vqf
         cfg = self.video_Qformer.config
@@ -236,6 +244,7 @@ class InfVideoEncoder(nn.Module):
             _lib.check(lib.infv_vqf_create(C.byref(c), C.byref(h)))
         self._release()
         self._vqf, self._vqf_dev = h, device
+        self._vqf_exact = None
         return h
 
     def _release(self):

@@ -44,10 +44,11 @@ def test_short_attention_matches_torch(T, gain):
     along = torch.randn(32, 768, generator=g)
     want_short = torch_short_attention(frames.double(), xq.double(), wk.double(), bk.double(), wv.double(), bv.double())
     lib = _lib.load()
-    for alpha, use_long in ((0.9, True), (1.0, False)):
+    for alpha, use_long, exact in ((0.9, True, True), (1.0, False, True), (0.9, True, False), (1.0, False, False)):
         cfg = _lib.VqfConfig(2, 12, 768, 3072, 768, 32, 32, 4096, 512, alpha, 1e-12)
         h = C.c_void_p()
         _lib.check(lib.infv_vqf_create(C.byref(cfg), C.byref(h)))
+        _lib.check(lib.infv_vqf_set_precision(h, int(exact)))
         d = lambda t: t.to(dev).contiguous()
         fr, q, a = d(frames), d(xq), d(along)
         dwk, dbk, dwv, dbv = d(wk), d(bk), d(wv), d(bv)
@@ -60,7 +61,9 @@ def test_short_attention_matches_torch(T, gain):
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
         want = alpha * want_short + (1 - alpha) * along.double() if use_long else want_short
-        np.testing.assert_allclose(out.cpu().numpy(), want.float().numpy(), atol=2e-5, rtol=1e-4)
+        # exact fp32 MFMA: fp32 round-off only; split-bf16 (default): ~1e-5 relative, a tenth of the 1e-3 budget
+        tol = dict(atol=2e-5, rtol=1e-4) if exact else dict(atol=1e-4, rtol=1e-3)
+        np.testing.assert_allclose(out.cpu().numpy(), want.float().numpy(), **tol)
         _lib.check(lib.infv_vqf_destroy(h))
 
 
