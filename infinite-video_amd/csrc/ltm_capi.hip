@@ -2,6 +2,7 @@
 #include "../../include/infv_ltm.h"
 #include "ltm_internal.h"
 #include "capi_common.h"
+#include "vqf_internal.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -110,6 +111,8 @@ struct infv_ltm_s {
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
     DeviceBuf kbar_ws, kbar_side[3], R_ws[3], P_ws[3], Snew_ws[3];
+    DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
+    bool wv_split_valid = false;         // the value weights of this consolidate call have been split
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
@@ -604,12 +607,44 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
         HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[set].as<float>(), stream));
     }
-    if (!(skip_mask() & 2)) {
+    // INFV_LTM_SPLIT=1 (experiment, off by default): the V' half of a sub-batch's projection only feeds the read-out, so
+    // it can run as a split-bf16 contraction (three bf16 MFMA products, ~1e-5 relative) while the score half stays on
+    // the exact fp32 MFMA kernel (its rounding feeds the bit-exact draw).  Measured: no gain (95 k vs 95-100 k
+    // chunks/s) -- the two launches (168 + 84 workgroups) serialise on the side stream and each under-fills the chip,
+    // where the single fp32 launch runs its 252 workgroups side by side.
+    static const bool want_split = [] { const char* e = getenv("INFV_LTM_SPLIT"); return e && atoi(e) != 0; }();
+    const int v_cols = h->L * h->dm;
+    if (skip_mask() & 2) {
+        *splitk = project_splitk((int)M, h->d);
+    } else if (want_split && M >= 1024 && h->d % 32 == 0 && v_cols % 128 == 0) {
+        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
+        const size_t szW = (size_t)v_cols * h->d * 2, szR = (size_t)M * h->d * 2;
+        if (szW > h->wv_hi.bytes || szR > h->R_hi.bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->wv_hi.reserve(szW)); HIP_TRY(h->wv_lo.reserve(szW));
+            HIP_TRY(h->R_hi.reserve(szR)); HIP_TRY(h->R_lo.reserve(szR));
+            h->wv_split_valid = false;
+        }
+        if (!h->wv_split_valid) {
+            for (int l = 0; l < h->L; ++l)
+                HIP_TRY(launch_split_rows(pp.wv[l], h->d, h->dm, h->d, h->wv_hi.as<__bf16>() + (size_t)l * h->dm * h->d,
+                                          h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, stream));
+            h->wv_split_valid = true;
+        }
+        HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, M, h->d, h->R_hi.p, h->R_lo.p, h->d, stream));
+        SplitGemm g{};
+        g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
+        g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
+        g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.strideC = 0; g.split_stride = 0;
+        g.M = (int)M; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
+        HIP_TRY(launch_split_gemm(g, stream, gemm_pad));
+        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+                                      h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
+        *splitk = 1;
+    } else {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
                                     h->P_ws[set].as<float>(), splitk, stream, gemm_pad));
-    } else {
-        *splitk = project_splitk((int)M, h->d);
     }
     *split_stride = M * ld;
     return INFV_OK;
@@ -680,6 +715,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
     static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 90 * 1024; }();
     FastPipe pipe{h, *plan, Q, pp, stream};
+    h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
     {   // rings of role S's per-chunk outputs (sized for this call's Q)
         const size_t need_a = (size_t)h->ring * pipe.alpha_slot() * sizeof(float);

@@ -315,6 +315,17 @@ hipError_t launch_project_fast(int M, int d, int dm, int n_layers, int n_out, co
     return launch_gemm(R, M, d, s, n_cols, C, n_cols, *splitk, (long)M * n_cols, stream, lds_pad);
 }
 
+// Score columns only (exact fp32: their rounding feeds the bit-exact draw): C[m][o] = R[m] . qt[o], o < n_out
+hipError_t launch_project_scores(int M, int d, int n_out, const float* qt, const float* R, float* C, int ldc,
+                                 hipStream_t stream, int lds_pad) {
+    if (M == 0) return hipSuccess;
+    WSegs s;
+    segs_clear(s);
+    int n = 0;
+    segs_push(s, n, qt, n_out);
+    return launch_gemm(R, M, d, s, n_out, C, ldc, 1, 0, stream, lds_pad);
+}
+
 // qt[(l*H + h)*Q + q][:] = sum_e (q[l][q][h*64+e] / sqrt(dh)) * Wk[l][h*64+e][:]   and   cq[(l*H+h)*Q + q] = q_h . bk_h / sqrt(dh)
 // so that  S'new = (q/sqrt(dh)) . (R Wk^T)_h^T = R . qt^T  without projecting the K half of the new rows.
 __global__ __launch_bounds__(256) void qtilde_kernel(const float* __restrict__ q, int Q, int H, int d, ProjPtrs proj,

@@ -117,12 +117,21 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
             }
 }
 
-hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream) {
+hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad) {
     if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0) return hipSuccess;
+    if (lds_pad > 0) {                                  // unused dynamic LDS: caps the kernel at one workgroup per CU
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
     if (g.K % kSBK || g.k_per_split % kSBK || g.k_per_split <= 0 || g.lda % 8 || g.ldb % 8 || g.strideA % 8 || g.strideB % 8)
         return hipErrorInvalidValue;
     dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, g.nbatch * g.splitk);
-    hipLaunchKernelGGL(split_gemm_kernel, grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(split_gemm_kernel, grid, dim3(256), lds_pad > 0 ? lds_pad : 0, stream, g);
     return hipGetLastError();
 }
 
