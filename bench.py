@@ -103,6 +103,32 @@ def cpu_baseline(budget_s: float):
                       f"oracle.DenseOracle (reference-shaped ATen sequence), {elapsed:.1f}s"}
 
 
+def cpu_closed_form(budget_s: float):
+    """The oracle's closed-form CPU restatement (same algebra as the HIP kernels: sparse operator, closed-form
+    read-out) on the host cores -- the honest best-CPU comparison next to the reference-shaped port (SURVEY.md 8d ii)."""
+    from infinite_video_amd import synth
+    from oracle.ltm_oracle import ClosedFormOracle
+    ws = [synth.layer_projections(l, D, DM) for l in range(L)]
+    orcs = [ClosedFormOracle(N, H, DH, TAU, True, *ws[l], tokens_per_frame=P) for l in range(L)]
+    qs = [synth.layer_query(l, Q, DM) for l in range(L)]
+    u = synth.gibbs_uniforms(64, L)
+    done, elapsed, c = 0, 0.0, 0
+    while True:
+        k = synth.frame_tokens(c, T, P, D)
+        t0 = time.perf_counter()
+        for l in range(L):
+            orcs[l].step(k, qs[l], new_doc=(c == 0), u=u[c, l])
+        dt = time.perf_counter() - t0
+        if c > 0:
+            done += 1
+            elapsed += dt
+        c += 1
+        if (elapsed >= budget_s and done >= 2) or done >= 63:
+            break
+    return {"value": done / elapsed, "unit": "frame-chunks/s", "cores": torch.get_num_threads(), "kind": "port (closed form)",
+            "sample": f"{done} steady-state sticky chunks, oracle.ClosedFormOracle (numpy/torch CPU), {elapsed:.1f}s"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +262,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["cpu_closed_form"] = cpu_closed_form(min(args.cpu_seconds, 6.0))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

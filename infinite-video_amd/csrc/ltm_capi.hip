@@ -539,6 +539,9 @@ struct FastPipe {
                 (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[batch-S stamps x10ns] wait+read %lld draw %lld tab %lld recurrence %lld row-phase+add %lld - %lld alpha-out %lld | step %lld\n",
                         hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
+                // shader cycles of the same step (s_memtime): cycles / (10 ns ticks) = effective clock in units of 100 MHz
+                fprintf(stderr, "[batch-S clock] step %lld shader cycles over %lld x10ns -> %.2f GHz\n", hb[15] - hb[8], hb[7] - hb[0],
+                        (hb[7] - hb[0]) > 0 ? 0.1 * (double)(hb[15] - hb[8]) / (double)(hb[7] - hb[0]) : 0.0);
             }
         }
         {

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     prefetch(0);
     __syncthreads();
 
-#define BSTAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) a.dbg[k] = wall_clock64(); } while (0)
+#define BSTAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
     // running ring indices (global step g = a.step0 + i): g % 3 and g % ring without per-step 64-bit division
     int g3 = (int)(a.step0 % 3), slot_run = (int)(a.step0 % a.ring);
     const int ring_n = (int)a.ring;

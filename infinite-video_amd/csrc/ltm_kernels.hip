@@ -68,14 +68,26 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 512>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
         static const int max_wgs = [] { const char* e = getenv("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
+        // loads in flight per wave (KiB): the kernel's outstanding bytes set the queueing delay every other kernel's
+        // memory operation (role S's atomics!) sees while the pool runs
+        static const int unroll = [] { const char* e = getenv("INFV_POOL_UNROLL"); return e ? atoi(e) : 16; }();
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
-        hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3(grid), dim3(512), lds_pad, stream,
-                           k, kbar, n_units, P, d4, slices);
+        if (unroll <= 2)
+            hipLaunchKernelGGL((pool_frames_kernel<2, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+        else if (unroll <= 4)
+            hipLaunchKernelGGL((pool_frames_kernel<4, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+        else if (unroll <= 8)
+            hipLaunchKernelGGL((pool_frames_kernel<8, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+        else
+            hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
     } else {
         hipLaunchKernelGGL((pool_frames_kernel<16, 256>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
                            n_units, P, d4, slices);
