@@ -63,6 +63,12 @@ int infv_vqf_destroy(infv_vqf_handle h);
  *   1            exact fp32 MFMA (bitwise an fp32 fma chain). */
 int infv_vqf_set_precision(infv_vqf_handle h, int32_t exact_fp32);
 
+/* Layer 0's hidden states entering the cross-attention come from the learned query tokens and the weights only, so
+ * infv_vqf_encode_chunk can reuse them (embedding LayerNorm, self-attention block, cross query, pre-multiplied query)
+ * from one chunk to the next.  The host vouches for the weights with an epoch: while the same non-zero epoch is set,
+ * the cached prefix is reused; change it whenever any weight of that prefix changes; 0 (default) disables reuse. */
+int infv_vqf_set_weights_epoch(infv_vqf_handle h, uint64_t epoch);
+
 /* Short-term cross-attention of one layer over one chunk's frame tokens, merged with the long-term context:
  *   merged = alpha * softmax((xq W-free restatement, see vqf_kernels.hip)) ... = Qformer.py:232-304 for a cross layer.
  * frames [n_tokens][enc_width], xq [n_query][hidden] (= self.query(hidden_states), bias applied),

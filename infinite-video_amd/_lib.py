@@ -108,6 +108,7 @@ _SIGNATURES = {
     "infv_vqf_create": (C.c_int, [C.POINTER(VqfConfig), C.POINTER(C.c_void_p)]),
     "infv_vqf_destroy": (C.c_int, [C.c_void_p]),
     "infv_vqf_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "infv_vqf_set_weights_epoch": (C.c_int, [C.c_void_p, C.c_uint64]),
     "infv_vqf_short_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Linear),
                                            C.POINTER(Linear), C.c_void_p, C.c_void_p, C.c_void_p]),
     "infv_vqf_encode_chunk": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,

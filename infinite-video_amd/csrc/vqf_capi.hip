@@ -12,6 +12,11 @@ struct infv_vqf_s {
     infv_vqf_config cfg;
     int dev = 0;
     bool exact_fp32 = false;
+    // chunk-independent prefix of layer 0 (embedding LayerNorm, self-attention block, cross query, pre-multiplied query):
+    // reused across encode_chunk calls while the host keeps the weights epoch unchanged (0 = never reuse)
+    unsigned long long epoch = 0, c_epoch = 0;
+    bool c_valid = false, c_qt_valid = false, c_qsplit_valid = false;
+    DeviceBuf c_h1, c_xq, c_qt, c_qh, c_ql;
     // workspaces (grown on demand; a growing call synchronises the device first)
     DeviceBuf part, h_a, h_b, h1, h2, qkv, sa, xq, along, qt, S, O, merged, inter, kbar;
     DeviceBuf sFh, sFl, sTh, sTl, sPh, sPl, sQh, sQl;   // split-bf16 operands of the short-term attention
@@ -77,7 +82,7 @@ int run_linear(infv_vqf_s* h, const LinearCall& c, hipStream_t stream) {
 //   -> merged [nb*Q][hidden] = alpha * short-term context + (1 - alpha) * along   (along == nullptr: short-term only)
 int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, const float* xq, bool shared_q,
                     const infv_linear* key, const infv_linear* value, const float* along, float* merged,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool use_cache = false) {
     const infv_vqf_config& c = h->cfg;
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
@@ -94,7 +99,21 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(h->S.reserve(needS)); HIP_TRY(h->O.reserve(needO)); HIP_TRY(h->qt.reserve(needQt));
     }
-    HIP_TRY(launch_qf_qtilde(xq, nq, Q, H, d, key->w, h->qt.as<float>(), stream));
+    float* qt = h->qt.as<float>();
+    void* qh = h->sQh.p; void* ql = h->sQl.p;
+    if (use_cache) {                                           // nq == 1: the cached query block of layer 0
+        const size_t szq = (size_t)rows * d;
+        if (szq * 4 > h->c_qt.bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->c_qt.reserve(szq * 4)); HIP_TRY(h->c_qh.reserve(szq * 2)); HIP_TRY(h->c_ql.reserve(szq * 2));
+            h->c_qt_valid = h->c_qsplit_valid = false;
+        }
+        qt = h->c_qt.as<float>(); qh = h->c_qh.p; ql = h->c_ql.p;
+    }
+    if (!use_cache || !h->c_qt_valid) {
+        HIP_TRY(launch_qf_qtilde(xq, nq, Q, H, d, key->w, qt, stream));
+        if (use_cache) { h->c_qt_valid = true; h->c_qsplit_valid = false; }
+    }
     // Both big contractions ( [H*Q x d x n_tokens] each ) run as split-bf16 (three bf16 MFMA products, fp32 accumulate):
     // their rounding (~1e-5) only feeds the read-out.  INFV_VQF_FP32=1 selects the exact-fp32 MFMA kernels instead.
     static const bool want_fp32 = [] { const char* e = getenv("INFV_VQF_FP32"); return e && atoi(e) != 0; }();
@@ -106,9 +125,17 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
             HIP_TRY(h->sPh.reserve(szP)); HIP_TRY(h->sPl.reserve(szP)); HIP_TRY(h->sQh.reserve(szQ)); HIP_TRY(h->sQl.reserve(szQ));
         }
         HIP_TRY(launch_split_transpose(frames, nb, n_tokens, d, h->sFh.p, h->sFl.p, h->sTh.p, h->sTl.p, stream));
-        HIP_TRY(launch_split_rows(h->qt.as<float>(), d, (long)nq * rows, d, h->sQh.p, h->sQl.p, d, stream));
+        if (use_cache) {                                      // (the buffers may just have been (re)allocated above)
+            qh = h->c_qh.p; ql = h->c_ql.p;
+        } else {
+            qh = h->sQh.p; ql = h->sQl.p;
+        }
+        if (!use_cache || !h->c_qsplit_valid) {
+            HIP_TRY(launch_split_rows(qt, d, (long)nq * rows, d, qh, ql, d, stream));
+            if (use_cache) h->c_qsplit_valid = true;
+        }
         SplitGemm g{};                                        // S[b] = qt[b] . frames[b]^T
-        g.A_hi = h->sQh.as<__bf16>(); g.A_lo = h->sQl.as<__bf16>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
+        g.A_hi = static_cast<const __bf16*>(qh); g.A_lo = static_cast<const __bf16*>(ql); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
         g.B_hi = h->sFh.as<__bf16>(); g.B_lo = h->sFl.as<__bf16>(); g.ldb = d; g.strideB = (long)n_tokens * d;
         g.C = h->S.as<float>(); g.ldc = ldS; g.strideC = (long)rows * ldS; g.split_stride = 0;
         g.M = rows; g.N = n_tokens; g.K = d; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
@@ -122,7 +149,7 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
         HIP_TRY(launch_split_gemm(p, stream));
     } else {
     QfGemm g{};                                             // S[b] = qt[b] . frames[b]^T
-    g.A = h->qt.as<float>(); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
+    g.A = qt; g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
     g.B[0] = frames; g.ldb = d; g.strideB = (long)n_tokens * d; g.seg_rows = n_tokens;
     g.C = h->S.as<float>(); g.ldc = ldS; g.strideC = (long)rows * ldS; g.split_stride = 0;
     g.M = rows; g.N = n_tokens; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
@@ -205,6 +232,12 @@ int infv_vqf_set_precision(infv_vqf_handle h, int32_t exact_fp32) {
     return INFV_OK;
 }
 
+int infv_vqf_set_weights_epoch(infv_vqf_handle h, uint64_t epoch) {
+    if (!h) return fail(INFV_ERR_INVALID, "null handle");
+    h->epoch = epoch;
+    return INFV_OK;
+}
+
 int infv_vqf_short_attention(infv_vqf_handle h, const float* frames, int32_t n_tokens, const float* xq,
                              const infv_linear* key, const infv_linear* value, const float* a_long,
                              float* merged, void* stream) {
@@ -225,12 +258,23 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     if (llama_out && (c.proj_out <= 0 || !w->llama_proj.w)) return fail(INFV_ERR_INVALID, "llama_out without llama_proj");
     const int Q = c.n_query, Hd = c.hidden, n_tokens = T * c.tokens_per_frame;
 
-    // embeddings: LayerNorm of the learned query tokens (Qformer.py:108-112)
-    QfEpilogue e{};
-    e.parts = w->query_tokens; e.nsplit = 1; e.split_stride = 0; e.ld_in = Hd; e.seg_cols = Hd;
-    e.gamma = w->emb_ln.gamma; e.beta = w->emb_ln.beta; e.eps = c.ln_eps; e.scale = 1.f; e.res_scale = 1.f;
-    e.out = h->h_a.as<float>(); e.ld_out = Hd; e.M = Q; e.width = Hd; e.res_rows = 1;
-    HIP_TRY(launch_qf_epilogue(e, stream));
+    // The prefix of layer 0 (embedding LayerNorm -> self-attention block -> cross query) depends on the weights only,
+    // not on the chunk: with a non-zero weights epoch it is computed once and reused until the epoch changes.
+    const bool caching = h->epoch != 0;
+    const bool prefix_cached = caching && h->c_valid && h->c_epoch == h->epoch;
+    if (caching && !prefix_cached) {
+        const size_t sz = (size_t)Q * Hd * sizeof(float);
+        if (sz > h->c_h1.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->c_h1.reserve(sz)); HIP_TRY(h->c_xq.reserve(sz)); }
+        h->c_valid = false; h->c_qt_valid = false; h->c_qsplit_valid = false;
+    }
+    if (!prefix_cached) {
+        // embeddings: LayerNorm of the learned query tokens (Qformer.py:108-112)
+        QfEpilogue e{};
+        e.parts = w->query_tokens; e.nsplit = 1; e.split_stride = 0; e.ld_in = Hd; e.seg_cols = Hd;
+        e.gamma = w->emb_ln.gamma; e.beta = w->emb_ln.beta; e.eps = c.ln_eps; e.scale = 1.f; e.res_scale = 1.f;
+        e.out = h->h_a.as<float>(); e.ld_out = Hd; e.M = Q; e.width = Hd; e.res_rows = 1;
+        HIP_TRY(launch_qf_epilogue(e, stream));
+    }
     float* hcur = h->h_a.as<float>();
     float* hnext = h->h_b.as<float>();
 
@@ -245,31 +289,37 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
 
     for (int l = 0; l < c.n_layers; ++l) {
         const infv_vqf_layer& L = w->layer[l];
-        // ---- self-attention over the query tokens + output (Qformer.py:442-470 -> BertAttention)
-        LinearCall qkv{hcur, Q, Hd, {&L.self_q, &L.self_k, &L.self_v}, 3, Hd};
-        qkv.y = h->qkv.as<float>();
-        if (int rc = run_linear(h, qkv, stream)) return rc;
-        HIP_TRY(launch_qf_self_attention(h->qkv.as<float>(), 1, Q, c.n_heads, h->sa.as<float>(), stream));
-        LinearCall so{h->sa.as<float>(), Q, Hd, {&L.self_o}, 1, Hd};
-        so.residual = hcur; so.res_rows = Q; so.ln = &L.self_ln; so.y = h->h1.as<float>();
-        if (int rc = run_linear(h, so, stream)) return rc;
-        // ---- cross-attention: query, long-term memory, short-term attention, merge, output
-        LinearCall xq{h->h1.as<float>(), Q, Hd, {&L.x_q}, 1, Hd};
-        xq.y = h->xq.as<float>();
-        if (int rc = run_linear(h, xq, stream)) return rc;
+        const bool l0c = caching && l == 0;                   // this layer's prefix lives in the cache buffers
+        float* h1 = l0c ? h->c_h1.as<float>() : h->h1.as<float>();
+        float* xqb = l0c ? h->c_xq.as<float>() : h->xq.as<float>();
+        if (!(l0c && prefix_cached)) {
+            // ---- self-attention over the query tokens + output (Qformer.py:442-470 -> BertAttention)
+            LinearCall qkv{hcur, Q, Hd, {&L.self_q, &L.self_k, &L.self_v}, 3, Hd};
+            qkv.y = h->qkv.as<float>();
+            if (int rc = run_linear(h, qkv, stream)) return rc;
+            HIP_TRY(launch_qf_self_attention(h->qkv.as<float>(), 1, Q, c.n_heads, h->sa.as<float>(), stream));
+            LinearCall so{h->sa.as<float>(), Q, Hd, {&L.self_o}, 1, Hd};
+            so.residual = hcur; so.res_rows = Q; so.ln = &L.self_ln; so.y = h1;
+            if (int rc = run_linear(h, so, stream)) return rc;
+            // ---- cross-attention: query, long-term memory, short-term attention, merge, output
+            LinearCall xq{h1, Q, Hd, {&L.x_q}, 1, Hd};
+            xq.y = xqb;
+            if (int rc = run_linear(h, xq, stream)) return rc;
+            if (l0c) { h->c_valid = true; h->c_epoch = h->epoch; }
+        }
         const float* along = nullptr;
         if (use_ltm) {
             infv_ltm_proj pr{};
             pr.wk = L.x_k.w; pr.bk = L.x_k.b; pr.wv = L.x_v.w; pr.bv = L.x_v.b;
             const double* ul = u ? u + (size_t)l * c.nb_samples : nullptr;
-            if (int rc = infv_ltm_step(ltm[l], h->kbar.as<float>(), T, h->xq.as<float>(), Q, &pr, ul,
+            if (int rc = infv_ltm_step(ltm[l], h->kbar.as<float>(), T, xqb, Q, &pr, ul,
                                        h->along.as<float>(), stream_)) return rc;
             along = h->along.as<float>();
         }
-        if (int rc = short_attention(h, frames, 1, n_tokens, h->xq.as<float>(), false, &L.x_k, &L.x_v, along,
-                                     h->merged.as<float>(), stream)) return rc;
+        if (int rc = short_attention(h, frames, 1, n_tokens, xqb, false, &L.x_k, &L.x_v, along,
+                                     h->merged.as<float>(), stream, l0c)) return rc;
         LinearCall xo{h->merged.as<float>(), Q, Hd, {&L.x_o}, 1, Hd};
-        xo.residual = h->h1.as<float>(); xo.res_rows = Q; xo.ln = &L.x_ln; xo.y = h->h2.as<float>();
+        xo.residual = h1; xo.res_rows = Q; xo.ln = &L.x_ln; xo.y = h->h2.as<float>();
         if (int rc = run_linear(h, xo, stream)) return rc;
         // ---- query FFN (Qformer.py:519-522)
         LinearCall fi{h->h2.as<float>(), Q, Hd, {&L.ffn_in}, 1, c.inter};

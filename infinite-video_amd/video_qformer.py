@@ -195,6 +195,23 @@ class InfVideoEncoder(nn.Module):
             raise KeyError(f"missing {missing}, unexpected {res.unexpected_keys}")
         return res
 
+    def _weight_sources(self):
+        """The parameters in the order :meth:`_weights` visits them."""
+        out = [self.video_query_tokens]
+        bert = self.video_Qformer.bert
+
+        def lin(m):
+            out.extend((m.weight, m.bias))
+        lin(bert.embeddings.LayerNorm)
+        for layer in bert.encoder.layer:
+            a, x = layer.attention, layer.crossattention
+            for m in (a.self.query, a.self.key, a.self.value, a.output.dense, a.output.LayerNorm,
+                      x.self.query, x.self.key, x.self.value, x.output.dense, x.output.LayerNorm,
+                      layer.intermediate_query.dense, layer.output_query.dense, layer.output_query.LayerNorm):
+                lin(m)
+        lin(self.llama_proj)
+        return out
+
     def _weights(self, device: torch.device):
         keep = []                                             # keeps converted copies alive during the call
 
@@ -221,6 +238,21 @@ class InfVideoEncoder(nn.Module):
                 lin(layer.intermediate_query.dense), lin(layer.output_query.dense), ln(layer.output_query.LayerNorm))
         w.llama_proj = lin(self.llama_proj)
         return w, keep
+
+    def _prefix_epoch(self) -> int:
+        """Signature of the weights that determine layer 0's chunk-independent prefix (query tokens, embedding
+        LayerNorm, self-attention block, cross query and key weights): storage address and in-place version of each.
+        Non-zero; a new value tells the library to recompute its cached prefix."""
+        layer = self.video_Qformer.bert.encoder.layer[0]
+        a, x = layer.attention, layer.crossattention
+        mods = (self.video_Qformer.bert.embeddings.LayerNorm, a.self.query, a.self.key, a.self.value, a.output.dense,
+                a.output.LayerNorm, x.self.query)
+        sig = [(self.video_query_tokens.data_ptr(), self.video_query_tokens._version),
+               (x.self.key.weight.data_ptr(), x.self.key.weight._version)]
+        for m in mods:
+            sig.append((m.weight.data_ptr(), m.weight._version))
+            sig.append((m.bias.data_ptr(), m.bias._version))
+        return (hash(tuple(sig)) & 0x7FFFFFFFFFFFFFFF) | 1
 
     def _handle(self, device: torch.device):
         h = self._handle_raw(device)
@@ -299,6 +331,9 @@ class InfVideoEncoder(nn.Module):
                 if tuple(u.shape) != (cfg.num_hidden_layers, NB_SAMPLES):
                     raise ValueError(f"u must be [{cfg.num_hidden_layers}, {NB_SAMPLES}]")
         w, keep = self._weights(device)
+        # weights that had to be converted for this call (dtype / device / layout) live in temporaries: no reuse then
+        stable = all(k.data_ptr() == p.data_ptr() for k, p in zip(keep, self._weight_sources()))
+        _lib.check(lib.infv_vqf_set_weights_epoch(h, self._prefix_epoch() if stable else 0))
         hidden = torch.empty(1, Q, cfg.hidden_size, device=device, dtype=torch.float32)
         llama = torch.empty(1, Q, self.llama_proj.out_features, device=device, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

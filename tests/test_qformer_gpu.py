@@ -203,3 +203,24 @@ def test_layer_major_path_with_ragged_tail_and_global_rng():
     for c in range(3):
         np.testing.assert_allclose(embs[c][0].cpu().numpy(), g[f"c{c}_llama"], atol=ATOL, err_msg=f"c{c}")
     np.testing.assert_allclose(mean[0].cpu().numpy(), np.mean(np.stack([g[f"c{c}_llama"] for c in range(3)]), 0), atol=ATOL)
+
+
+def test_cached_layer0_prefix_follows_weight_updates():
+    """The chunk-independent prefix of layer 0 is reused between calls; an in-place weight update must invalidate it."""
+    case = QF_CASES[1]                                   # alpha = 1: no memory, outputs depend on weights + frames only
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    m = make_model(case, weights, dev)
+    k = torch.from_numpy(frames[0]).unsqueeze(0).to(dev)
+    a1 = m.encode_frames(k, new_video=True)[1].clone()
+    a2 = m.encode_frames(k, new_video=True)[1].clone()          # second call: cached prefix
+    np.testing.assert_array_equal(a1.cpu().numpy(), a2.cpu().numpy())
+    with torch.no_grad():
+        m.video_Qformer.bert.encoder.layer[0].attention.self.query.weight.mul_(1.5)
+    b = m.encode_frames(k, new_video=True)[1].clone()
+    fresh = make_model(case, weights, dev)
+    with torch.no_grad():
+        fresh.video_Qformer.bert.encoder.layer[0].attention.self.query.weight.mul_(1.5)
+    want = fresh.encode_frames(k, new_video=True)[1]
+    np.testing.assert_array_equal(b.cpu().numpy(), want.cpu().numpy())
+    assert float((a1 - b).abs().max()) > 1e-4
