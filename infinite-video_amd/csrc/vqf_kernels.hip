@@ -224,39 +224,42 @@ __global__ __launch_bounds__(256) void qf_epilogue_kernel(QfEpilogue e) {
     float x[kEpiMaxPerThread];
     const float* in = e.parts + (long)m * e.ld_in;
     const float* res = e.residual ? e.residual + (long)(m % e.res_rows) * e.ld_res : nullptr;
-#pragma unroll
-    for (int i = 0; i < kEpiMaxPerThread; ++i) x[i] = 0.f;
-    // eight slabs at a time: their loads are independent and in flight together (a plain slab loop is a chain
-    // of dependent round trips, 18 us for a 768-wide row)
+    // Every global load of the row is issued before anything waits: the slabs (eight at a time for all of the
+    // thread's columns), bias, residual, gamma and beta.  Chains of dependent round trips made this kernel 2-3x slower.
+    float bias_v[kEpiMaxPerThread], res_v[kEpiMaxPerThread], gam_v[kEpiMaxPerThread], bet_v[kEpiMaxPerThread];
 #pragma unroll
     for (int i = 0; i < kEpiMaxPerThread; ++i) {
-        if (256 * i >= e.width) break;
+        x[i] = 0.f; bias_v[i] = 0.f; res_v[i] = 0.f; gam_v[i] = 1.f; bet_v[i] = 0.f;
         const int c = tid + 256 * i;
-        if (c < e.width) {
-            const float* p = in + c;
-            float v = 0.f;
-            int s = 0;
-            for (; s + 8 <= e.nsplit; s += 8) {
-                float t[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = p[(long)(s + k) * e.split_stride];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v += t[k];
-            }
-            for (; s < e.nsplit; ++s) v += p[(long)s * e.split_stride];
-            x[i] = v;
+        if (256 * i < e.width && c < e.width) {
+            const int seg = c / e.seg_cols;
+            if (e.bias[seg]) bias_v[i] = e.bias[seg][c - seg * e.seg_cols];
+            if (res) res_v[i] = res[c];
+            if (e.gamma) { gam_v[i] = e.gamma[c]; bet_v[i] = e.beta[c]; }
         }
+    }
+    for (int s = 0; s < e.nsplit; s += 8) {
+        float t[kEpiMaxPerThread][8];
+#pragma unroll
+        for (int i = 0; i < kEpiMaxPerThread; ++i) {
+            const int c = tid + 256 * i;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                t[i][k] = (256 * i < e.width && c < e.width && s + k < e.nsplit) ? in[(long)(s + k) * e.split_stride + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kEpiMaxPerThread; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[i] += t[i][k];
     }
 #pragma unroll
     for (int i = 0; i < kEpiMaxPerThread; ++i) {
         const int c = tid + 256 * i;
         if (c < e.width) {
-            float v = x[i];
-            const int seg = c / e.seg_cols;
-            if (e.bias[seg]) v += e.bias[seg][c - seg * e.seg_cols];
+            float v = x[i] + bias_v[i];
             if (e.act == QF_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
             v *= e.scale;
-            if (res) v += e.res_scale * res[c];
+            if (res) v += e.res_scale * res_v[i];
             x[i] = v;
         }
     }
@@ -274,10 +277,7 @@ __global__ __launch_bounds__(256) void qf_epilogue_kernel(QfEpilogue e) {
         const float var = (float)(block_sum<256>(sq, scratch) / e.width);
         const float rstd = 1.0f / sqrtf(var + e.eps);
 #pragma unroll
-        for (int i = 0; i < kEpiMaxPerThread; ++i) {
-            const int c = tid + 256 * i;
-            if (c < e.width) x[i] = (x[i] - mean) * rstd * e.gamma[c] + e.beta[c];
-        }
+        for (int i = 0; i < kEpiMaxPerThread; ++i) x[i] = (x[i] - mean) * rstd * gam_v[i] + bet_v[i];
     }
     float* out = e.out + (long)m * e.ld_out;
 #pragma unroll
