@@ -547,24 +547,37 @@ __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q
     }
     __syncthreads();
 
-    // ---- scores: n-tiles of 16 boxes round-robin over the 4 waves ----
-    for (int nt = wave; nt < N / 16; nt += 4) {
-        const floatx4* src = reinterpret_cast<const floatx4*>(KVl + (long)(nt * 16 + c) * 2 * dm + h * kHeadSize + 16 * g);
-        floatx4 kb[4];
+    // ---- scores: n-tiles of 16 boxes round-robin over the 4 waves; the K' rows of up to four tiles of a wave are
+    //      requested together (one round trip instead of four dependent ones) ----
+    for (int nt0 = wave; nt0 < N / 16; nt0 += 16) {
+        floatx4 kb[4][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) kb[v] = src[v];
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 4; ++u) {
+            const int nt = nt0 + 4 * u;
+            if (nt < N / 16) {
+                const floatx4* src = reinterpret_cast<const floatx4*>(KVl + (long)(nt * 16 + c) * 2 * dm + h * kHeadSize + 16 * g);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[j], kb[j >> 2][j & 3], acc, 0, 0, 0);
-        // C/D map 16x16: col = lane&15 (box), row = 4*(lane>>4) + reg (query row)
+                for (int v = 0; v < 4; ++v) kb[u][v] = src[v];
+            }
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
-            const float sv = acc[r] + cq[row];
-            Ssm[row * sstride + nt * 16 + c] = sv;
-            if (scores != nullptr && qt * kQTile + row < Q)
-                scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = sv;
+        for (int u = 0; u < 4; ++u) {
+            const int nt = nt0 + 4 * u;
+            if (nt < N / 16) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[j], kb[u][j >> 2][j & 3], acc, 0, 0, 0);
+                // C/D map 16x16: col = lane&15 (box), row = 4*(lane>>4) + reg (query row)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * g + r;
+                    const float sv = acc[r] + cq[row];
+                    Ssm[row * sstride + nt * 16 + c] = sv;
+                    if (scores != nullptr && qt * kQTile + row < Q)
+                        scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = sv;
+                }
+            }
         }
     }
     __syncthreads();
