@@ -12,9 +12,11 @@ namespace infv {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int kSBK = 32;                          // k per tile (two 32x32x16 steps)
-constexpr int kSPitch = 80;                       // bytes per LDS row: 32 bf16 + 16 B (b128 reads spread over all banks)
+constexpr int kSBK = 64;                          // k per tile (four 32x32x16 steps)
+constexpr int kSPitch = 2 * kSBK + 16;            // bytes per LDS row: 64 bf16 + 16 B (b128 reads spread over all banks)
 constexpr int kSArr = 128 * kSPitch;              // bytes of one operand array tile (128 rows)
+constexpr int kSLds = 4 * kSArr;                  // A_hi, A_lo, B_hi, B_lo tiles (73.7 KB: dynamic LDS)
+constexpr int kSVec = kSBK / 16;                  // 16-byte vectors per thread per array tile (a thread owns half a row)
 
 __device__ inline void split2(float x, __bf16& hi, __bf16& lo) {
     hi = (__bf16)x;
@@ -27,10 +29,10 @@ __device__ inline unsigned pack2(__bf16 a, __bf16 b) {
 
 // ------------------------------------------------------------------------------------------------------
 // C[z][m][o] = sum_k (A_hi + A_lo)[b][m][k] * (B_hi + B_lo)[b][o][k]   (three bf16 MFMA products, fp32 accumulate)
-// 128 x 128 x 32 tiles, 4 waves as 2 x 2, register prefetch of the next k-tile.
+// 128 x 128 x 64 tiles, 4 waves as 2 x 2, register prefetch of the next k-tile.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * kSArr];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
@@ -40,20 +42,20 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
     const int ntiles = kend > kbeg ? (kend - kbeg) / kSBK : 0;
     float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
 
-    // staging: thread -> (row = tid >> 1, 32-byte half of the 64-byte row segment)
+    // staging: thread -> (row = tid >> 1, one half of the row's k-tile segment)
     const int row = tid >> 1, half = tid & 1;
     const bool a_ok = m0 + row < g.M, b_ok = n0 + row < g.N;
-    const long a_off = (long)b * g.strideA + (long)(m0 + row) * g.lda + kbeg + half * 16;
-    const long b_off = (long)b * g.strideB + (long)(n0 + row) * g.ldb + kbeg + half * 16;
+    const long a_off = (long)b * g.strideA + (long)(m0 + row) * g.lda + kbeg + half * (kSBK / 2);
+    const long b_off = (long)b * g.strideB + (long)(n0 + row) * g.ldb + kbeg + half * (kSBK / 2);
     const uint4* src[4] = {reinterpret_cast<const uint4*>(g.A_hi + a_off), reinterpret_cast<const uint4*>(g.A_lo + a_off),
                            reinterpret_cast<const uint4*>(g.B_hi + b_off), reinterpret_cast<const uint4*>(g.B_lo + b_off)};
-    uint4 reg[4][2];
+    uint4 reg[4][kSVec];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const bool ok = a < 2 ? a_ok : b_ok;
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
+            for (int v = 0; v < kSVec; ++v)
                 reg[a][v] = ok ? src[a][t * (kSBK / 8) + v] : make_uint4(0u, 0u, 0u, 0u);      // 8 bf16 per uint4
         }
     };
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
-                *reinterpret_cast<uint4*>(smem + a * kSArr + row * kSPitch + half * 32 + v * 16) = reg[a][v];
+            for (int v = 0; v < kSVec; ++v)
+                *reinterpret_cast<uint4*>(smem + a * kSArr + row * kSPitch + half * kSBK + v * 16) = reg[a][v];
     };
 
     floatx16 acc[2][2];
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
         __syncthreads();
         if (t + 1 < ntiles) load_tile(t + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < kSBK / 16; ++ks) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -119,19 +121,20 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
 
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad) {
     if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0) return hipSuccess;
-    if (lds_pad > 0) {                                  // unused dynamic LDS: caps the kernel at one workgroup per CU
+    {                                                   // tiles live in dynamic LDS; `lds_pad` more (unused) bytes cap the kernel at one workgroup per CU
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
     }
+    if (lds_pad > 160 * 1024 - kSLds) lds_pad = 160 * 1024 - kSLds;
     if (g.K % kSBK || g.k_per_split % kSBK || g.k_per_split <= 0 || g.lda % 8 || g.ldb % 8 || g.strideA % 8 || g.strideB % 8)
         return hipErrorInvalidValue;
     dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, g.nbatch * g.splitk);
-    hipLaunchKernelGGL(split_gemm_kernel, grid, dim3(256), lds_pad > 0 ? lds_pad : 0, stream, g);
+    hipLaunchKernelGGL(split_gemm_kernel, grid, dim3(256), kSLds + (lds_pad > 0 ? lds_pad : 0), stream, g);
     return hipGetLastError();
 }
 

@@ -87,7 +87,11 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
     int kps = n_tokens;
-    const int sk = qf_pick_splitk_fill(rows, d, n_tokens, nb, &kps);
+    int sk = qf_pick_splitk_fill(rows, d, n_tokens, nb, &kps);
+    if (n_tokens % 64 == 0) {                                 // the split-bf16 kernel works on 64-deep k-tiles
+        kps = (kps + 63) / 64 * 64;
+        sk = (n_tokens + kps - 1) / kps;
+    }
     const int nq = shared_q ? 1 : nb;
     // leading dimension of the score matrix: padded by 256 B so that its rows (the A operand of the second
     // contraction, one 128-B line per row per k-tile) do not all map to the same memory channel
@@ -117,7 +121,7 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     // Both big contractions ( [H*Q x d x n_tokens] each ) run as split-bf16 (three bf16 MFMA products, fp32 accumulate):
     // their rounding (~1e-5) only feeds the read-out.  INFV_VQF_FP32=1 selects the exact-fp32 MFMA kernels instead.
     static const bool want_fp32 = [] { const char* e = getenv("INFV_VQF_FP32"); return e && atoi(e) != 0; }();
-    if (!want_fp32 && !h->exact_fp32 && d % 64 == 0) {
+    if (!want_fp32 && !h->exact_fp32 && d % 64 == 0 && n_tokens % 64 == 0) {     // (odd frame counts: exact-fp32 kernels)
         const size_t szF = (size_t)nb * n_tokens * d * 2, szP = (size_t)nb * rows * n_tokens * 2, szQ = (size_t)nq * rows * d * 2;
         if (szF > h->sFh.bytes || szP > h->sPh.bytes || szQ > h->sQh.bytes) {
             HIP_TRY(hipDeviceSynchronize());
