@@ -213,7 +213,19 @@ class InfVideoEncoder(nn.Module):
         return out
 
     def _weights(self, device: torch.device):
-        keep = []                                             # keeps converted copies alive during the call
+        """ctypes view of the parameters.  Rebuilt only when a parameter moved or was updated in place (the signature
+        is every parameter's storage address and version), so a steady-state call costs one pass over ~55 tensors."""
+        src = self._weight_sources()
+        sig = (str(device),) + tuple((p.data_ptr(), p._version, p.dtype) for p in src)
+        cached = getattr(self, "_w_cache", None)
+        if cached is not None and cached[0] == sig:
+            return cached[1], cached[2]
+        w, keep = self._build_weights(device)
+        self._w_cache = (sig, w, keep)
+        return w, keep
+
+    def _build_weights(self, device: torch.device):
+        keep = []                                             # keeps converted copies alive while the struct is cached
 
         def t(x):
             y = _dev_f32(x, device)
