@@ -470,3 +470,54 @@ def encode_long_video(model: InfVideoEncoder, frame_tokens: torch.Tensor, max_in
         _lib.check(lib.infv_vqf_mean(C.c_void_p(stacked.data_ptr()), len(embs), embs[0].numel(),
                                      C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out, embs
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU (chunk blocks)
+def gather_video_embeddings(emb_sum: torch.Tensor, n_chunks: int, memories: Sequence[torch.Tensor], group=None):
+    """One all-gather (RCCL over xGMI under backend ``nccl``) of what the LLM side needs from every rank's block of
+    chunks: the SUM of its per-chunk embeddings with the chunk count (the eval loop's reduction is a plain mean over
+    chunks, run_inference_inf_video_llama_nextqa.py:194, so block sums + counts reproduce it exactly) and the rank's
+    consolidated memories (flat tensors, e.g. ``B_past`` / bin masses per layer).
+    Returns (global mean embedding, list over ranks of the memory tensors, per-rank chunk counts).
+    Works without an initialised process group (world = 1, no collective)."""
+    import torch.distributed as dist
+    shapes = [tuple(m.shape) for m in memories]
+    flat = [emb_sum.reshape(-1).float(), torch.tensor([float(n_chunks)], device=emb_sum.device)] + \
+           [m.reshape(-1).float() for m in memories]
+    payload = torch.cat(flat).contiguous()
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=payload.dtype)
+        dist.all_gather_into_tensor(gathered, payload, group=group)
+    else:
+        gathered = payload
+    gathered = gathered.reshape(world, -1)
+    n_emb = emb_sum.numel()
+    counts = gathered[:, n_emb]
+    mean = (gathered[:, :n_emb].sum(0) / counts.sum()).reshape(emb_sum.shape)
+    mems, off = [], n_emb + 1
+    per_rank = []
+    for r in range(world):
+        o, items = off, []
+        for shp in shapes:
+            n = int(torch.tensor(shp).prod()) if len(shp) else 1
+            items.append(gathered[r, o:o + n].reshape(shp))
+            o += n
+        per_rank.append(items)
+    return mean, per_rank, counts
+
+
+def encode_long_video_sharded(model: InfVideoEncoder, frames_local: torch.Tensor, u_local: Optional[torch.Tensor] = None,
+                              group=None):
+    """This rank's contiguous block of chunks [C_local, T*P, d] through the layer-major path as its own document
+    (``new_video=True``, the reference's semantics for a new video), then one all-gather.
+    Returns (mean LLM-side embedding over ALL ranks' chunks [1, Q, llama], per-rank memories, per-chunk embeddings of
+    this rank)."""
+    llama, _, _ = model.encode_frames_batch(frames_local, new_video=True, u=u_local)
+    mems = []
+    if model.video_Qformer.config.alpha != 1.0:
+        for m in model.video_Qformer.ltm_modules:
+            st = m.memory_state()
+            mems.extend((st["B_past"].to(llama.device), st["bin_mass"].to(llama.device)))
+    mean, per_rank, _ = gather_video_embeddings(llama.sum(0, keepdim=True), llama.size(0), mems, group)
+    return mean, per_rank, llama

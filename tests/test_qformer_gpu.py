@@ -224,3 +224,21 @@ def test_cached_layer0_prefix_follows_weight_updates():
     want = fresh.encode_frames(k, new_video=True)[1]
     np.testing.assert_array_equal(b.cpu().numpy(), want.cpu().numpy())
     assert float((a1 - b).abs().max()) > 1e-4
+
+
+def test_sharded_entry_point_single_rank():
+    """world = 1 (no process group): the sharded entry point equals the layer-major path and returns the memories."""
+    from infinite_video_amd.video_qformer import encode_long_video_sharded
+    case = QF_CASES[3]                                    # peaked, 3 equal chunks
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    g = load_qf_golden(case)
+    m = make_model(case, weights, dev)
+    Cn = len(case.chunk_T)
+    k = torch.from_numpy(np.stack(frames)).to(dev)
+    u = torch.from_numpy(np.stack([chunk_uniforms(case, c) for c in range(Cn)]))
+    mean, per_rank, llama = encode_long_video_sharded(m, k, u)
+    want = np.mean(np.stack([g[f"c{c}_llama"] for c in range(Cn)]), 0)
+    np.testing.assert_allclose(mean[0].cpu().numpy(), want, atol=ATOL)
+    assert len(per_rank) == 1 and len(per_rank[0]) == 2 * case.n_layers
+    np.testing.assert_allclose(per_rank[0][0].double().sum(1).cpu().numpy(), g[f"c{Cn - 1}_l0_Bsum"], atol=5e-4)

@@ -103,3 +103,35 @@ def test_two_rank_gloo_equals_single_process_subvideos():
         np.testing.assert_array_equal(B[rank, 0], ref.export_state(0)[0].numpy())
         np.testing.assert_allclose(ctx_sum[rank], ctx_ref.sum(0).numpy(), rtol=1e-6, atol=1e-6)
     assert list(ret[0][4]) == [3.0, 3.0]
+
+
+def _qf_gather_worker(rank, world, port, out_q):
+    import torch
+    import torch.distributed as dist
+    from infinite_video_amd.video_qformer import gather_video_embeddings
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    embs = torch.randn(5, 1, 4, 8, generator=g)                  # 5 chunks of the "video": rank 0 takes 3, rank 1 takes 2
+    mine = embs[:3] if rank == 0 else embs[3:]
+    mem = [torch.full((2, 3), float(rank)), torch.full((4,), 10.0 + rank)]
+    mean, per_rank, counts = gather_video_embeddings(mine.sum(0), mine.size(0), mem)
+    ok = torch.allclose(mean, embs.mean(0), atol=1e-6) and counts.tolist() == [3.0, 2.0]
+    ok = ok and all(float(per_rank[r][0][0, 0]) == float(r) and float(per_rank[r][1][0]) == 10.0 + r for r in range(world))
+    ok = ok and tuple(per_rank[1][0].shape) == (2, 3)
+    out_q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_qformer_block_sums_reproduce_the_global_mean_over_chunks():
+    """world_size 2, gloo: uneven chunk blocks; sum + count per rank == the eval loop's plain mean over chunks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_qf_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
