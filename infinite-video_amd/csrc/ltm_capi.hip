@@ -30,6 +30,11 @@ namespace {
 
 // Timing experiments only (results become garbage): INFV_SKIP bit 0 = no pooling launches, bit 1 = no projection GEMM,
 // bit 2 = no UC launches, bit 3 = no role-S launches.  Shows how much each stream slows the others.
+// INFV_VPROJ_ON_UC (default on): in the sub-batch pipeline only the SCORE half of the new-row projection stays on the
+// side stream (role S waits for it); the V' half, which only the UC kernel reads, is issued on the UC stream right
+// before that kernel -- the side stream stops being the longest of the three.
+bool vproj_on_uc() { static const bool v = [] { const char* e = getenv("INFV_VPROJ_ON_UC"); return !e || atoi(e) != 0; }(); return v; }
+
 int skip_mask() { static const int m = [] { const char* e = getenv("INFV_SKIP"); return e ? atoi(e) : 0; }(); return m; }
 
 struct Operator {
@@ -596,7 +601,8 @@ struct FastPipe {
 // fast-path chunk-parallel stage after the pool: new rows R, then ONE GEMM whose output rows are
 // [ V' projection of the row (L*dm) | its scores under the call's pre-multiplied queries (L*H*Q) ]
 int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T, int Q,
-                        const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad) {
+                        const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad,
+                        bool defer_values = false) {
     const Operator& op = inf ? plan.inf : plan.first;
     const long M = (long)n_chunks * op.rows;
     const int n_out = h->L * h->H * Q;
@@ -641,6 +647,11 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.strideC = 0; g.split_stride = 0;
         g.M = (int)M; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
         HIP_TRY(launch_split_gemm(g, stream, gemm_pad));
+        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+                                      h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
+        *splitk = 1;
+    } else if (defer_values && M >= 1024) {
+        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
                                       h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
         *splitk = 1;
@@ -803,7 +814,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         const int set = b % 3;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
-        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side[set].as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad)) return rc;
+        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side[set].as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
+                                         vproj_on_uc())) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         return INFV_OK;
@@ -848,6 +860,13 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                 if (i == 0 && b + 1 < n_batches)
                     if (int rc = stage_parallel(b + 1)) return rc;
             }
+        }
+        if (vproj_on_uc() && (long)nb * plan->inf.rows >= 1024 && !(skip_mask() & 2)) {
+            // V' half of this sub-batch's projection: needs the new rows (ev_p), feeds only the UC kernel below
+            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_p[set], 0));
+            Timed t_(h->prof, INFV_KERNEL_PROJECT, ucs);
+            HIP_TRY(launch_project_values((int)((long)nb * plan->inf.rows), h->d, h->dm, h->L, pp, h->R_ws[set].as<float>(),
+                                          h->P_ws[set].as<float>(), h->L * h->dm + h->L * h->H * Q, ucs, kGemmPad));
         }
         HIP_TRY(hipEventRecord(h->ev_s[set], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));

@@ -60,6 +60,8 @@ hipError_t launch_project_fast(int M, int d, int dm, int n_layers, int n_out, co
                                const float* R, float* C, int* splitk, hipStream_t stream, int lds_pad = 0);
 hipError_t launch_project_scores(int M, int d, int n_out, const float* qt, const float* R, float* C, int ldc,
                                  hipStream_t stream, int lds_pad = 0);
+hipError_t launch_project_values(int M, int d, int dm, int n_layers, const ProjPtrs& proj, const float* R, float* C,
+                                 int ldc, hipStream_t stream, int lds_pad = 0);
 hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, const ProjPtrs& proj, float* qt, float* cq,
                          hipStream_t stream);
 

@@ -338,6 +338,17 @@ hipError_t launch_project_scores(int M, int d, int n_out, const float* qt, const
     return launch_gemm(R, M, d, s, n_out, C, ldc, 1, 0, stream, lds_pad);
 }
 
+// Value columns only: C[m][l*dm + o] = R[m] . Wv[l][o]   (the V' half of the new rows, consumed by the UC kernel)
+hipError_t launch_project_values(int M, int d, int dm, int n_layers, const ProjPtrs& proj, const float* R, float* C,
+                                 int ldc, hipStream_t stream, int lds_pad) {
+    if (M == 0) return hipSuccess;
+    WSegs s;
+    segs_clear(s);
+    int n = 0;
+    for (int l = 0; l < n_layers; ++l) segs_push(s, n, proj.wv[l], dm);
+    return launch_gemm(R, M, d, s, n_layers * dm, C, ldc, 1, 0, stream, lds_pad);
+}
+
 // qt[(l*H + h)*Q + q][:] = sum_e (q[l][q][h*64+e] / sqrt(dh)) * Wk[l][h*64+e][:]   and   cq[(l*H+h)*Q + q] = q_h . bk_h / sqrt(dh)
 // so that  S'new = (q/sqrt(dh)) . (R Wk^T)_h^T = R . qt^T  without projecting the K half of the new rows.
 __global__ __launch_bounds__(256) void qtilde_kernel(const float* __restrict__ q, int Q, int H, int d, ProjPtrs proj,
