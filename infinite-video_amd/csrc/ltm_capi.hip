@@ -865,8 +865,36 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
             // V' half of this sub-batch's projection: needs the new rows (ev_p), feeds only the UC kernel below
             HIP_TRY(hipStreamWaitEvent(ucs, h->ev_p[set], 0));
             Timed t_(h->prof, INFV_KERNEL_PROJECT, ucs);
-            HIP_TRY(launch_project_values((int)((long)nb * plan->inf.rows), h->d, h->dm, h->L, pp, h->R_ws[set].as<float>(),
-                                          h->P_ws[set].as<float>(), h->L * h->dm + h->L * h->H * Q, ucs, kGemmPad));
+            const long Mv = (long)nb * plan->inf.rows;
+            const int v_cols = h->L * h->dm, p_ld = h->L * h->dm + h->L * h->H * Q;
+            // V' only feeds the read-out (1e-3 budget): split-bf16 contraction (three bf16 MFMA products, ~1e-5
+            // relative) unless INFV_VPROJ_SPLIT=0
+            static const bool v_split = [] { const char* e = getenv("INFV_VPROJ_SPLIT"); return !e || atoi(e) != 0; }();
+            if (v_split && h->d % 64 == 0 && v_cols % 128 == 0) {
+                const size_t szW = (size_t)v_cols * h->d * 2, szR = (size_t)h->maxC * plan->inf.rows * h->d * 2;
+                if (szW > h->wv_hi.bytes || szR > h->R_hi.bytes) {
+                    HIP_TRY(hipDeviceSynchronize());
+                    HIP_TRY(h->wv_hi.reserve(szW)); HIP_TRY(h->wv_lo.reserve(szW));
+                    HIP_TRY(h->R_hi.reserve(szR)); HIP_TRY(h->R_lo.reserve(szR));
+                    h->wv_split_valid = false;
+                }
+                if (!h->wv_split_valid) {
+                    for (int l = 0; l < h->L; ++l)
+                        HIP_TRY(launch_split_rows(pp.wv[l], h->d, h->dm, h->d, h->wv_hi.as<__bf16>() + (size_t)l * h->dm * h->d,
+                                                  h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, ucs));
+                    h->wv_split_valid = true;
+                }
+                HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, ucs));
+                SplitGemm g{};
+                g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
+                g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
+                g.C = h->P_ws[set].as<float>(); g.ldc = p_ld; g.strideC = 0; g.split_stride = 0;
+                g.M = (int)Mv; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
+                HIP_TRY(launch_split_gemm(g, ucs, kGemmPad));
+            } else {
+                HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, h->R_ws[set].as<float>(),
+                                              h->P_ws[set].as<float>(), p_ld, ucs, kGemmPad));
+            }
         }
         HIP_TRY(hipEventRecord(h->ev_s[set], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
