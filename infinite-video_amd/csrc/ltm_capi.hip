@@ -563,7 +563,10 @@ struct FastPipe {
 
     // memory update + read-out of `n` chunks whose role S used ring slots slot0.. ; flips the B / KV ping-pong
     int launch_uc(const Operator& op, bool inf, int n, long slot0, const float* R, const float* Pn, int sk, long ss,
-                  float* ctx, hipStream_t ucs) {
+                  float* ctx, hipStream_t ucs, bool raw_scores = false) {
+        if (raw_scores && !(skip_mask() & 4))                  // the persistent role S left scores in the alpha ring
+            HIP_TRY(launch_alpha_rows(h->alpha_ring.as<float>(), (long)alpha_slot(), h->asum_ring.as<float>(), (long)asum_slot(),
+                                      slot0 % h->ring, h->ring, n, h->L * h->H * Q, h->N, plan.w.as<float>(), plan.w_out, ucs));
         UcArgs u;
         memset(&u, 0, sizeof(u));
         u.N = h->N; u.H = h->H; u.Q = Q; u.L = h->L; u.d = h->d; u.dm = h->dm; u.tabw = op.tabw;
@@ -899,7 +902,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         HIP_TRY(hipEventRecord(h->ev_s[set], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[set].as<float>(), h->P_ws[set].as<float>(),
-                                    sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
+                                    sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs, persistent)) return rc;
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
     }

@@ -230,13 +230,14 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         }
         __syncthreads();
         BSTAMP(4);
-        row_phase_wave(Ssm, sstride, N, valid, lds + m.w, a.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
-                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows,
-                       1ull << kArriveShift);
+        row_phase_wave<false>(Ssm, sstride, N, valid, lds + m.w, a.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
+                              lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, acc_cur, kBRows,
+                              1ull << kArriveShift);
         BSTAMP(5);
         BSTAMP(6);
         // outputs for the UC kernel go out after the arrival, off the other workgroups' critical path:
-        // the resolved gather table (layer's writer) and alpha_i with its row sums
+        // the resolved gather table (layer's writer) and this step's SCORES (alpha_rows_kernel turns them into the
+        // softmax weights and row sums later, off the chain)
         if (writer) {
             int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;
             for (int e = tid; e < N * tabw; e += kBNT) tab_out[e] = tab[e];
@@ -248,7 +249,6 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
                 const int n = lane + 64 * k;
                 if (n < N) al[n] = Ssm[wave * sstride + n];
             }
-            if (lane == 0) a.asum_ring[slot * a.asum_slot + tile + wave] = asum[wave];
         }
         { float* t = Spc; Spc = Spn; Spn = t; }
         BSTAMP(7);
@@ -262,6 +262,58 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         if (sr < valid) *reinterpret_cast<floatx4*>(a.Sp_out + (tile + sr) * N + sc4 * 4) =
                             *reinterpret_cast<const floatx4*>(&Spc[sr * sp + sc4 * 4]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Scores -> softmax weights of `n_steps` ring slots, in place:  alpha[n] = w_n e^{S_n} / (sum_m w_m e^{S_m} + w_out)
+// (LTM.py:247-248,269-282 in closed form) and asum = sum_n alpha[n].  One wave per (step, layer, head, query) row;
+// same arithmetic as row_phase_wave<true>.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void alpha_rows_kernel(float* __restrict__ alpha_ring, long alpha_slot,
+                                                         float* __restrict__ asum_ring, long asum_slot, long slot0, int ring,
+                                                         int n_steps, int rows_per_step, int N, const float* __restrict__ w,
+                                                         float w_out) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)n_steps * rows_per_step) return;
+    const int i = (int)(r / rows_per_step), row = (int)(r - (long)i * rows_per_step);
+    const long slot = (slot0 + i) % ring;
+    float* a = alpha_ring + slot * alpha_slot + (long)row * N;
+    float sv[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = lane + 64 * k;
+        sv[k] = (n < N) ? a[n] : -INFINITY;
+        m = fmaxf(m, sv[k]);
+    }
+    m = wave_max(m);
+    float e[4];
+    float esum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = lane + 64 * k;
+        e[k] = (n < N) ? w[n] * __expf(sv[k] - m) : 0.f;
+        esum += e[k];
+    }
+    esum = wave_sum(esum);
+    const float inv = 1.0f / (esum + w_out * __expf(-m));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = lane + 64 * k;
+        if (n < N) a[n] = e[k] * inv;
+    }
+    if (lane == 0) asum_ring[slot * asum_slot + row] = esum * inv;
+}
+
+hipError_t launch_alpha_rows(float* alpha_ring, long alpha_slot, float* asum_ring, long asum_slot, long slot0, int ring,
+                             int n_steps, int rows_per_step, int N, const float* w, float w_out, hipStream_t stream) {
+    if (n_steps <= 0) return hipSuccess;
+    if (N > 256) return hipErrorInvalidValue;
+    const long rows = (long)n_steps * rows_per_step;
+    hipLaunchKernelGGL(alpha_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, alpha_ring, alpha_slot,
+                       asum_ring, asum_slot, slot0, ring, n_steps, rows_per_step, N, w, w_out);
+    return hipGetLastError();
 }
 
 size_t chain_batch_lds_bytes(int N, int S, int rows, int tabw) { return (size_t)batch_smem(N, S, rows, tabw).total * sizeof(float); }

@@ -270,6 +270,9 @@ __device__ inline void row_phase(float* Ssm, int sstride, int N, int valid_rows,
 // Same row-wise phase with ONE WAVE PER QUERY ROW (1024-thread workgroups: wave w owns row w).
 // Row reductions are wave reductions; the 16 rows proceed in parallel on the CU's 4 SIMDs.
 // --------------------------------------------------------------------------------------
+// ALPHA = false: only the sticky bin masses (the critical path of the persistent role S); the scores stay in Ssm and
+// the softmax weights are computed later by alpha_rows_kernel, off the chain.
+template <bool ALPHA = true>
 __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_rows, const float* w,
                                       float w_out, const int32_t* edge_box, const float* edge_dx, float* Dsm,
                                       float* Msm, float* asum, float* __restrict__ part_out,
@@ -300,6 +303,7 @@ __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_
         const float d2 = expf(s2 - md);                // same value in every lane
         if (lane == 0) Drow[kBins] = d2;
     }
+    if (ALPHA) {
     __syncthreads();                                   // raw-score reads done before alpha overwrites
     // softmax weights feed only the read-out (1e-3 budget): hardware exp2
     float e[NI];
@@ -318,6 +322,10 @@ __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_
         if (n < N) Srow[n] = e[i] * inv;
     }
     if (lane == 0) asum[row] = esum * inv;
+    } else {
+        // Drow was written by this wave only (row == wave): its own LDS operations are ordered, no barrier needed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     const float d0 = Drow[lane], d1 = Drow[lane + 1], d64 = Drow[lane + 64], d65 = Drow[lane + 65];
     const float dx0 = edge_dx[lane], dx1 = edge_dx[lane + 64];
     const float z = wave_sum((d0 + d1) * dx0 + (d64 + d65) * dx1) * 0.5f;

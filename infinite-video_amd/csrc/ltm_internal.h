@@ -154,6 +154,9 @@ struct UcArgs {
     float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks
     long long* dbg;                 // timing experiments: phase stamps of one V' workgroup, or nullptr
 };
+// scores -> softmax weights + row sums of the ring slots the persistent role S filled (in place)
+hipError_t launch_alpha_rows(float* alpha_ring, long alpha_slot, float* asum_ring, long asum_slot, long slot0, int ring,
+                             int n_steps, int rows_per_step, int N, const float* w, float w_out, hipStream_t stream);
 bool uc_supported(int N, int d, int dm, int tabw, int rows_max);
 hipError_t launch_uc(const UcArgs& a, hipStream_t stream);
 
