@@ -75,9 +75,11 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
             attr_set = true;
         }
         static const int max_wgs = [] { const char* e = getenv("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
-        // loads in flight per wave (KiB): the kernel's outstanding bytes set the queueing delay every other kernel's
-        // memory operation (role S's atomics!) sees while the pool runs
-        static const int unroll = [] { const char* e = getenv("INFV_POOL_UNROLL"); return e ? atoi(e) : 16; }();
+        // loads in flight per wave (KiB).  The pool's outstanding bytes set the queueing delay that every other kernel's
+        // memory operation sees while it runs (role S's atomics and stores: all of its phases stretch 1.5-2x during
+        // pooling).  4 KiB per wave (8 MiB chip-wide) keeps ~95 % of the in-situ pooling rate and gives role S back
+        // ~0.5 ms per video; 16 is fastest for the pool alone.
+        static const int unroll = [] { const char* e = getenv("INFV_POOL_UNROLL"); return e ? atoi(e) : 4; }();
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
         if (unroll <= 2)
