@@ -779,13 +779,20 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     const bool persistent = want_persistent &&
         chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
     const int first_c = c;
-    const int n_batches = (n_chunks - first_c + h->maxC - 1) / h->maxC;
+    // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
+    // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 28 so that the
+    // pipeline fills and drains quickly.  INFV_SUB_BATCH overrides.
+    static const int sub_env = [] { const char* e = getenv("INFV_SUB_BATCH"); return e ? atoi(e) : 0; }();
+    int sub = h->maxC;
+    if (sub_env > 0) sub = sub_env < h->maxC ? sub_env : h->maxC;
+    else if (n_chunks < 768 && sub > 28) sub = 28;
+    const int n_batches = (n_chunks - first_c + sub - 1) / sub;
     const size_t rows = plan->inf.rows;
     std::vector<int> sks(n_batches > 0 ? n_batches : 1, 1);
     std::vector<long> sss(n_batches > 0 ? n_batches : 1, 0);
     auto batch_range = [&](int b, int* c0, int* nb) {
-        *c0 = first_c + b * h->maxC;
-        *nb = (n_chunks - *c0 < h->maxC) ? n_chunks - *c0 : h->maxC;
+        *c0 = first_c + b * sub;
+        *nb = (n_chunks - *c0 < sub) ? n_chunks - *c0 : sub;
     };
     // INFV_SPLIT_POOL=1 puts the pooling on its own stream so that the HBM-bound pooling of batch b+2 overlaps the
     // MFMA-bound projection of batch b+1 (pooled frames are triple-buffered either way).  Measured: WORSE (87 k vs
