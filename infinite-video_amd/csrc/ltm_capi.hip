@@ -120,6 +120,8 @@ struct infv_ltm_s {
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
+    hipStream_t aux = nullptr;          // V' projection + softmax weights of a sub-batch (feeds the UC kernel)
+    hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
@@ -140,6 +142,8 @@ struct infv_ltm_s {
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         if (ucs) { (void)hipStreamSynchronize(ucs); (void)hipStreamDestroy(ucs); }
         if (pools) { (void)hipStreamSynchronize(pools); (void)hipStreamDestroy(pools); }
+        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+        for (int i = 0; i < 3; ++i) if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
@@ -561,12 +565,17 @@ struct FastPipe {
         return INFV_OK;
     }
 
+    // the persistent role S leaves SCORES in the alpha ring: turn the `n` slots from slot0 into softmax weights + row sums
+    int launch_alpha(int n, long slot0, hipStream_t s) {
+        if (skip_mask() & 4) return INFV_OK;
+        HIP_TRY(launch_alpha_rows(h->alpha_ring.as<float>(), (long)alpha_slot(), h->asum_ring.as<float>(), (long)asum_slot(),
+                                  slot0 % h->ring, h->ring, n, h->L * h->H * Q, h->N, plan.w.as<float>(), plan.w_out, s));
+        return INFV_OK;
+    }
+
     // memory update + read-out of `n` chunks whose role S used ring slots slot0.. ; flips the B / KV ping-pong
     int launch_uc(const Operator& op, bool inf, int n, long slot0, const float* R, const float* Pn, int sk, long ss,
-                  float* ctx, hipStream_t ucs, bool raw_scores = false) {
-        if (raw_scores && !(skip_mask() & 4))                  // the persistent role S left scores in the alpha ring
-            HIP_TRY(launch_alpha_rows(h->alpha_ring.as<float>(), (long)alpha_slot(), h->asum_ring.as<float>(), (long)asum_slot(),
-                                      slot0 % h->ring, h->ring, n, h->L * h->H * Q, h->N, plan.w.as<float>(), plan.w_out, ucs));
+                  float* ctx, hipStream_t ucs) {
         UcArgs u;
         memset(&u, 0, sizeof(u));
         u.N = h->N; u.H = h->H; u.Q = Q; u.L = h->L; u.d = h->d; u.dm = h->dm; u.tabw = op.tabw;
@@ -689,11 +698,13 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
     }
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
     HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
     HIP_TRY(hipStreamCreateWithPriority(&h->pools, hipStreamNonBlocking, lo));
+    HIP_TRY(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     return INFV_OK;
 }
@@ -871,10 +882,15 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                     if (int rc = stage_parallel(b + 1)) return rc;
             }
         }
+        // What the UC kernel needs besides role S's tables -- the V' half of the projection and the softmax weights --
+        // runs on the UC stream itself.  INFV_AUX_STREAM=1 moves it to a stream of its own: measured much WORSE (23.6 vs
+        // 18.0 ms per video): a fifth concurrent kernel slows role S and the GEMMs more than the shorter chain gains.
+        static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
+        hipStream_t vs = use_aux ? h->aux : ucs;
         if (vproj_on_uc() && (long)nb * plan->inf.rows >= 1024 && !(skip_mask() & 2)) {
             // V' half of this sub-batch's projection: needs the new rows (ev_p), feeds only the UC kernel below
-            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_p[set], 0));
-            Timed t_(h->prof, INFV_KERNEL_PROJECT, ucs);
+            HIP_TRY(hipStreamWaitEvent(vs, h->ev_p[set], 0));
+            Timed t_(h->prof, INFV_KERNEL_PROJECT, vs);
             const long Mv = (long)nb * plan->inf.rows;
             const int v_cols = h->L * h->dm, p_ld = h->L * h->dm + h->L * h->H * Q;
             // V' only feeds the read-out (1e-3 budget): split-bf16 contraction (three bf16 MFMA products, ~1e-5
@@ -891,25 +907,32 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                 if (!h->wv_split_valid) {
                     for (int l = 0; l < h->L; ++l)
                         HIP_TRY(launch_split_rows(pp.wv[l], h->d, h->dm, h->d, h->wv_hi.as<__bf16>() + (size_t)l * h->dm * h->d,
-                                                  h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, ucs));
+                                                  h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, vs));
                     h->wv_split_valid = true;
                 }
-                HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, ucs));
+                HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, vs));
                 SplitGemm g{};
                 g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
                 g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
                 g.C = h->P_ws[set].as<float>(); g.ldc = p_ld; g.strideC = 0; g.split_stride = 0;
                 g.M = (int)Mv; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
-                HIP_TRY(launch_split_gemm(g, ucs, kGemmPad));
+                HIP_TRY(launch_split_gemm(g, vs, kGemmPad));
             } else {
                 HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, h->R_ws[set].as<float>(),
-                                              h->P_ws[set].as<float>(), p_ld, ucs, kGemmPad));
+                                              h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
         HIP_TRY(hipEventRecord(h->ev_s[set], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
+        if (vs != ucs) HIP_TRY(hipStreamWaitEvent(vs, h->ev_s[set], 0));
+        if (persistent)
+            if (int rc = pipe.launch_alpha(nb, slot0, vs)) return rc;
+        if (vs != ucs) {
+            HIP_TRY(hipEventRecord(h->ev_aux[set], vs));
+            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_aux[set], 0));
+        }
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[set].as<float>(), h->P_ws[set].as<float>(),
-                                    sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs, persistent)) return rc;
+                                    sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
     }
