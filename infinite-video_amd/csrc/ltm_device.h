@@ -348,6 +348,64 @@ __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_
 }
 
 // --------------------------------------------------------------------------------------
+// One query row by ONE wave, callable for several rows in turn (no workgroup barrier inside): the per-row part of
+// row_phase_wave<true>.  In: Srow[n] = scores; out: Srow[n] = alpha, *asum_out = sum alpha, Mrow[j] = this row's
+// trapezoid mass of histogram interval j+1 (zero if !valid).  N <= 256.
+// --------------------------------------------------------------------------------------
+__device__ inline void row_phase_row(float* Srow, int N, bool valid, const float* __restrict__ w, float w_out,
+                                     const int32_t* __restrict__ edge_box, const float* __restrict__ edge_dx,
+                                     float* Drow, float* Mrow, float* asum_out) {
+    constexpr int NI = 4;
+    const int lane = threadIdx.x & 63;
+    float sv[NI];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        sv[i] = (n < N) ? Srow[n] : -INFINITY;
+        m = fmaxf(m, sv[i]);
+    }
+    m = wave_max(m);
+    const float md = fmaxf(m, 0.f);
+    {
+        const int eb0 = edge_box[lane], eb1 = edge_box[lane + 64];
+        const int eb2 = edge_box[kBins];
+        const float s0 = (eb0 >= 0) ? Srow[eb0] : 0.f, s1 = (eb1 >= 0) ? Srow[eb1] : 0.f;
+        const float s2 = (eb2 >= 0) ? Srow[eb2] : 0.f;
+        Drow[lane] = expf(s0 - md);
+        Drow[lane + 64] = expf(s1 - md);
+        const float d2 = expf(s2 - md);
+        if (lane == 0) Drow[kBins] = d2;
+    }
+    // the row is private to this wave: its LDS operations are ordered, only the data must have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float e[NI];
+    float esum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        e[i] = (n < N) ? w[n] * __expf(sv[i] - m) : 0.f;
+        esum += e[i];
+    }
+    esum = wave_sum(esum);
+    const float inv = 1.0f / (esum + w_out * __expf(-m));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) Srow[n] = e[i] * inv;
+    }
+    if (lane == 0) *asum_out = esum * inv;
+    const float d0 = Drow[lane], d1 = Drow[lane + 1], d64 = Drow[lane + 64], d65 = Drow[lane + 65];
+    const float dx0 = edge_dx[lane], dx1 = edge_dx[lane + 64];
+    const float z = wave_sum((d0 + d1) * dx0 + (d64 + d65) * dx1) * 0.5f;
+    const float inv_z = 1.0f / z;
+    const float d2 = Drow[lane + 2], d66 = (lane + 66 <= kBins) ? Drow[lane + 66] : 0.f;
+    const float dxa = edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? edge_dx[lane + 65] : 0.f;
+    Mrow[lane] = valid ? ((d1 * inv_z + d2 * inv_z) * dxa) * 0.5f : 0.f;
+    if (lane + 64 < kBins - 1) Mrow[lane + 64] = valid ? ((d65 * inv_z + d66 * inv_z) * dxb) * 0.5f : 0.f;
+}
+
+// --------------------------------------------------------------------------------------
 // Read-out of one (head, 16-row tile): acc[r] = sum_n alpha[4g+r][n] * V'[n][16*wave + c]
 //   Asm: alpha tile in LDS (pitch sstride == 2 mod 32); V' rows read from global at
 //   Vhead + n * row_pitch (64 floats used), staged through Vsm in passes of kVRows rows.

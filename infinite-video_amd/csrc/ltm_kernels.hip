@@ -610,6 +610,156 @@ __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// attend, N <= 256: same result as attend_kernel, restructured around its three latencies (measured 1.0 + 4.0 + 6.8 +
+// 7.6 us for q / scores / row phase / read-out):
+//   * the head's whole V' tile (N x 64) is requested at kernel start and parked in LDS after the scores, so its
+//     round trip hides behind the score MFMAs and the read-out never waits for memory;
+//   * the row phase runs one wave per query row (4 rows per wave in turn, wave reductions, no workgroup barriers).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kAtPitch = 80;                        // LDS pitch of the V' tile: == 16 mod 32 -> conflict-free column reads
+
+__global__ __launch_bounds__(256) void attend_small_kernel(const float* __restrict__ q, int Q, int N, int H,
+                                                           const float* __restrict__ KV, ProjPtrs proj,
+                                                           const float* __restrict__ readout_w, float w_out,
+                                                           StickyView sticky, float* __restrict__ ctx,
+                                                           float* __restrict__ bin_part, float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int sstride = N + 2;
+    float* Ssm = lds;                                   // [16][N+2]
+    float* Vall = lds + ((kQTile * sstride + 3) & ~3);  // [N][80]
+    float* Dsm = Vall + N * kAtPitch;                   // [16][132]
+    float* Msm = Dsm + kQTile * kDPitch;                // [16][128]
+    float* cq = Msm + kQTile * kMPitch;                 // [16]
+    float* asum = cq + 16;                              // [16]
+
+    const int h = blockIdx.x, qt = blockIdx.y, l = blockIdx.z;
+    const int QT = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dm = H * kHeadSize;
+    const int c = lane & 15, g = lane >> 4;
+    const float scale = 1.0f / sqrtf((float)kHeadSize);
+    const float* ql = q + (long)l * Q * dm;
+    const float* KVl = KV + (long)l * N * 2 * dm;
+    const float* bk = proj.bk[l] + h * kHeadSize;
+    const float* bv = proj.bv[l] + h * kHeadSize;
+
+    // ---- V' tile of this head: N rows x 16 float4, 16 per thread (N <= 256), in flight until after the scores ----
+    floatx4 vreg[16];
+    {
+        const float* Vh = KVl + dm + h * kHeadSize;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            const int r = e >> 4, c4 = e & 15;
+            vreg[u] = (r < N) ? *reinterpret_cast<const floatx4*>(Vh + (long)r * 2 * dm + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float qa[16];
+    {
+        const int row = qt * kQTile + c;
+        if (row < Q) {
+            const floatx4* src = reinterpret_cast<const floatx4*>(ql + (long)row * dm + h * kHeadSize + 16 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const floatx4 t = src[v];
+                qa[4 * v + 0] = t.x * scale; qa[4 * v + 1] = t.y * scale;
+                qa[4 * v + 2] = t.z * scale; qa[4 * v + 3] = t.w * scale;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) qa[j] = 0.f;
+        }
+    }
+    // K' rows of this wave's score tiles (n-tiles wave, wave+4, ...): requested together
+    floatx4 kb[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int nt = wave + 4 * u;
+        if (nt < N / 16) {
+            const floatx4* src = reinterpret_cast<const floatx4*>(KVl + (long)(nt * 16 + c) * 2 * dm + h * kHeadSize + 16 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) kb[u][v] = src[v];
+        }
+    }
+    if (wave == 0) {
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part = fmaf(qa[j], bk[16 * g + j], part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (g == 0) cq[c] = part;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int nt = wave + 4 * u;
+        if (nt < N / 16) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[j], kb[u][j >> 2][j & 3], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                const float sv = acc[r] + cq[row];
+                Ssm[row * sstride + nt * 16 + c] = sv;
+                if (scores != nullptr && qt * kQTile + row < Q)
+                    scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = sv;
+            }
+        }
+    }
+    // park the V' tile
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u;
+        const int r = e >> 4, c4 = e & 15;
+        if (r < N) *reinterpret_cast<floatx4*>(&Vall[r * kAtPitch + c4 * 4]) = vreg[u];
+    }
+    __syncthreads();
+    // ---- row phase: wave w takes query rows 4w .. 4w+3 in turn ----
+    const int valid = min(kQTile, Q - qt * kQTile);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * wave + r;
+        row_phase_row(Ssm + row * sstride, N, row < valid, readout_w, w_out, sticky.edge_box, sticky.edge_dx,
+                      Dsm + row * kDPitch, Msm + row * kMPitch, asum + row);
+    }
+    __syncthreads();
+    if (tid < kBins - 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < kQTile; ++r) t += Msm[r * kMPitch + tid];
+        bin_part[(((long)l * H + h) * QT + qt) * kBins + tid] = t;
+    }
+    // ---- read-out: acc[r] = sum_n alpha[4g+r][n] * V'[n][16*wave + c], the whole tile is in LDS ----
+    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < N / 4; t += 2) {
+        const float a0 = Ssm[c * sstride + 4 * t + g];
+        const float b0 = Vall[(4 * t + g) * kAtPitch + 16 * wave + c];
+        const float a1 = Ssm[c * sstride + 4 * (t + 1) + g];
+        const float b1 = Vall[(4 * (t + 1) + g) * kAtPitch + 16 * wave + c];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+    const floatx4 acc = acc0 + acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        const int qrow = qt * kQTile + rr;
+        if (qrow < Q) {
+            const int col = 16 * wave + c;
+            ctx[((long)l * Q + qrow) * dm + h * kHeadSize + col] = acc[r] + asum[rr] * bv[col];
+        }
+    }
+}
+
+size_t attend_small_lds_bytes(int N) {
+    const int sstride = N + 2;
+    size_t floats = ((kQTile * sstride + 3) & ~3) + (size_t)N * kAtPitch + kQTile * kDPitch + kQTile * kMPitch + 64;
+    return floats * sizeof(float);
+}
+
 int attend_parts(int Q, int H) { return H * ((Q + kQTile - 1) / kQTile); }
 
 size_t attend_lds_bytes(int N) {
@@ -629,6 +779,19 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    static const bool want_small = [] { const char* e = getenv("INFV_ATTEND_SMALL"); return !e || atoi(e) != 0; }();
+    if (want_small && N <= 256 && N % 16 == 0) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_small_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(attend_small_kernel, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
+                           KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(attend_kernel, dim3(H, QT, n_layers), dim3(256), lds, stream, q, Q, N, H, KV, proj,
                        readout_w, readout_w_out, sticky, ctx, bin_part, scores);
