@@ -258,3 +258,40 @@ def test_headline_shape_consolidate_in_pieces(dev):
     for c in range(2):
         ref = orc.step(kc[c], qc[0], new_doc=(c == 0), u=uc[c, 0])
         np.testing.assert_allclose(whole[c, 0].cpu().numpy(), ref, rtol=0, atol=CTX_TOL)
+
+
+def test_full_size_properties_of_the_memory_operator(dev):
+    """Size-independent properties at the BASELINE headline shape (T=256, N=256, 2 layers), 40 chunks per call:
+    * with uniform resampling (sticky=False) the consolidated memory is a LINEAR function of the frame tokens:
+      doubling every token doubles B bit for bit (power-of-two scaling commutes with every fp32 rounding on the path);
+    * with sticky resampling: the draw is a probability vector over 127 bins, resampled rows are left bin edges
+      (even boxes at N=256), and every read-out is a sub-convex combination of the projected memory rows."""
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    N, H, dh, d, P, T, Q, L, Cn = 256, 12, 64, 768, 32, 256, 32, 2, 40
+    ws = [synth.layer_projections(l, d, H * dh, seed=911) for l in range(L)]
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    q = torch.from_numpy(np.stack([synth.layer_query(l, Q, H * dh, seed=912) for l in range(L)])).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(913)
+    k = torch.empty(Cn, T * P, d, device=dev).normal_(generator=gen)
+    uni = LTMEngine(N, H, dh, d, P, tau=0.75, sticky=False, n_layers=L, max_q=Q, device=dev)
+    uni.consolidate(k, q, projs, None, new_doc=True)
+    B1 = [uni.export_state(l)[0].clone() for l in range(L)]
+    uni.consolidate(k * 2.0, q, projs, None, new_doc=True)
+    for l in range(L):
+        np.testing.assert_array_equal(uni.export_state(l)[0].cpu().numpy(), (2.0 * B1[l]).cpu().numpy())
+        assert float(B1[l].abs().max()) > 0.01
+
+    u = torch.from_numpy(synth.gibbs_uniforms(Cn, L, seed=914)).to(dev)
+    st = LTMEngine(N, H, dh, d, P, tau=0.75, sticky=True, n_layers=L, max_q=Q, device=dev)
+    ctx = st.consolidate(k, q, projs, u, new_doc=True)
+    assert bool(torch.isfinite(ctx).all())
+    for l in range(L):
+        bins, idx, probs = st.last_draw(l)
+        assert abs(float(probs.astype(np.float64).sum()) - 1.0) < 1e-5 and (probs >= 0).all()
+        assert bins.min() >= 0 and bins.max() <= 126
+        np.testing.assert_array_equal(idx, 2 * bins)                     # left edge of bin b lies in box 2b (N = 2 * 128)
+        wv, bv = projs[l][2], projs[l][3]
+        V = st.export_state(l)[0] @ wv.t() + bv                          # projected memory rows [N, dm]
+        bound = V.abs().max(dim=0).values                                # per output column
+        assert bool((ctx[-1, l].abs() <= bound.unsqueeze(0) * (1 + 1e-5) + 1e-6).all())

@@ -242,3 +242,32 @@ def test_sharded_entry_point_single_rank():
     np.testing.assert_allclose(mean[0].cpu().numpy(), want, atol=ATOL)
     assert len(per_rank) == 1 and len(per_rank[0]) == 2 * case.n_layers
     np.testing.assert_allclose(per_rank[0][0].double().sum(1).cpu().numpy(), g[f"c{Cn - 1}_l0_Bsum"], atol=5e-4)
+
+
+def test_short_attention_rows_sum_to_one_at_headline_size():
+    """Size-independent property at T=256 (8192 tokens): with a zero value projection the short-term context is the
+    value bias exactly (softmax rows sum to one), for both arithmetic modes."""
+    import ctypes as C
+    from infinite_video_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(321)
+    frames = torch.randn(256 * 32, 768, generator=g).to(dev)
+    xq = (torch.randn(32, 768, generator=g) * 3).to(dev)
+    wk = (torch.randn(768, 768, generator=g) * 0.02).to(dev)
+    bk = torch.zeros(768, device=dev)
+    wv = torch.zeros(768, 768, device=dev)
+    bv = torch.randn(768, generator=g).to(dev)
+    lib = _lib.load()
+    for exact in (1, 0):
+        cfg = _lib.VqfConfig(2, 12, 768, 3072, 768, 32, 32, 4096, 512, 1.0, 1e-12)
+        h = C.c_void_p()
+        _lib.check(lib.infv_vqf_create(C.byref(cfg), C.byref(h)))
+        _lib.check(lib.infv_vqf_set_precision(h, exact))
+        key, val = _lib.Linear(wk.data_ptr(), bk.data_ptr()), _lib.Linear(wv.data_ptr(), bv.data_ptr())
+        out = torch.empty(32, 768, device=dev)
+        _lib.check(lib.infv_vqf_short_attention(h, C.c_void_p(frames.data_ptr()), 256 * 32, C.c_void_p(xq.data_ptr()),
+                                                C.byref(key), C.byref(val), C.c_void_p(0), C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), bv.unsqueeze(0).expand(32, -1).cpu().numpy(), atol=1e-6)
+        _lib.check(lib.infv_vqf_destroy(h))
