@@ -56,6 +56,10 @@ CASES = [
     Case("headline", N=256, chunk_T=[256] * 3, seed_base=5000, store_full_B=False),
     Case("headline_ragged", N=256, chunk_T=[256, 255, 100], seed_base=5500, n_layers=1, store_full_B=False),
     Case("vc_shape", variant="VC", Q=96, chunk_T=[16] * 3, seed_base=6000, n_layers=2),
+    # num_basis not a power of two: box edges are fp32 linspace values, membership is NOT floor(t*N) (BASIS.py:248-250).
+    # (For many such values -- 48, 80, 96, 192, ... -- neighbouring fp32 boxes overlap at a sample position, the
+    # reference's G is no longer one-non-zero-per-row and basis_maps.build_plan refuses them; 144 is one that works.)
+    Case("n144", N=144, chunk_T=[12, 12, 9, 12], seed_base=7000, n_layers=1),
 ]
 
 

@@ -110,3 +110,14 @@ def test_memory_file_format_rejects_foreign_files(tmp_path):
     save_file({"a": torch.zeros(2)}, p, metadata={"format": "something-else"})
     with pytest.raises(ValueError):
         load_memory(p, [], "cpu")
+
+
+def test_plan_refuses_num_basis_whose_fp32_boxes_overlap():
+    """For many non-power-of-two num_basis values neighbouring boxes (fp32 mu +/- width/2, BASIS.py:248-250) overlap at a
+    sample position: the reference's ridge operator then has two non-zeros in a row and the sparse closed form does
+    not apply.  The plan builder must refuse them loudly instead of computing something else."""
+    for N in (48, 96, 192):
+        with pytest.raises(basis_maps.UnsupportedBasis):
+            basis_maps.build_plan(256, N, .75)
+    for N in (144, 272):                                   # non-power-of-two values whose boxes do partition the samples
+        basis_maps.build_plan(256, N, .75)
