@@ -126,3 +126,26 @@ def test_memory_state_roundtrip_through_cpu():
     np.testing.assert_allclose(ya.cpu().numpy(), yb.cpu().numpy(), rtol=0, atol=2e-5)
     g = load_golden(case)
     np.testing.assert_allclose(yb[0].cpu().numpy(), g["c3_l0_ctx"], rtol=0, atol=CTX_TOL)
+
+
+def test_half_precision_producer_and_weights():
+    """VideoChat2 feeds the op from an fp16 autocast region (videochat2_it_mistral.py:187): fp16 frame tokens, queries
+    and key/value weights must be accepted, computed in fp32 on the values they hold, and returned in the query's
+    dtype -- compared with the same module fed the identical (fp16-rounded) numbers as fp32."""
+    case = CASES[0]
+    dev = torch.device("cuda:0")
+    ks, qs, ws = case_inputs(case)
+    r16 = lambda a: torch.from_numpy(a).half()                   # the values an fp16 producer would hold
+    ws16 = [tuple(r16(w).float().numpy() for w in ws[l]) for l in range(case.n_layers)]
+    ref = _module(case, ws16, 0, dev)                            # fp32 modules holding the fp16-rounded weights
+    low = _module(case, ws16, 0, dev)
+    low.proj_key.half(); low.proj_value.half()
+    for c in range(3):
+        k16, q16 = r16(ks[c]).unsqueeze(0).to(dev), r16(qs[0]).unsqueeze(0).to(dev)
+        torch.manual_seed(call_seed(case, c, 0))
+        out16 = low(k16, q16, new_doc=(c == 0), layer_n=0)
+        torch.manual_seed(call_seed(case, c, 0))
+        out32 = ref(k16.float(), q16.float(), new_doc=(c == 0), layer_n=0)
+        assert out16.dtype == torch.float16 and out32.dtype == torch.float32
+        np.testing.assert_allclose(out16.float().cpu().numpy(), out32.cpu().numpy(), atol=2e-3, rtol=2e-3)   # fp16 output rounding
+        np.testing.assert_array_equal(low._engine.last_draw(0)[0], ref._engine.last_draw(0)[0])
