@@ -10,3 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is built in-tree by ``__graft_entry__.build()``; (re)build it if it is missing or older than
+    its sources (hipcc cross-compiles without a GPU), so a fresh checkout can run the suite directly."""
+    import __graft_entry__ as entry
+    entry.build()
+    yield
