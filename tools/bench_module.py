@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-call latency of the drop-in LongTermAttention module (the reference's operator API), headline shape."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from infinite_video_amd import synth
+from infinite_video_amd.long_term_attention_gibbs import LongTermAttention
+
+dev = torch.device("cuda:0")
+wk, bk, wv, bv = synth.layer_projections(0, 768, 768)
+pk, pv = torch.nn.Linear(768, 768), torch.nn.Linear(768, 768)
+with torch.no_grad():
+    pk.weight.copy_(torch.from_numpy(wk)); pk.bias.copy_(torch.from_numpy(bk))
+    pv.weight.copy_(torch.from_numpy(wv)); pv.bias.copy_(torch.from_numpy(bv))
+m = LongTermAttention(head_size=64, length=768, target_len=768, attn_func="softmax", attn_num_basis=256, continuous=True,
+                      attn_drop=0.1, infinite_memory=True, n_layers=2, n_heads=12, affines=True, mask=True, mask_type="cnn",
+                      kl_regularizer=False, proj_key=pk.to(dev), proj_value=pv.to(dev), sigma_0=None, mu_0=None,
+                      sticky_memories=True, sigmas=None, tau=0.75, d_model=768)
+ks = [torch.randn(1, 256 * 32, 768, device=dev) for _ in range(8)]
+q = torch.randn(1, 32, 768, device=dev)
+torch.manual_seed(0)
+for c in range(4):
+    m(ks[c % 8], q, new_doc=(c == 0), layer_n=0)
+torch.cuda.synchronize()
+n = 200
+t0 = time.perf_counter()
+for c in range(n):
+    m(ks[c % 8], q, new_doc=False, layer_n=0)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"LongTermAttention.forward, T=256 N=256: host issue {1e6 * (t1 - t0) / n:.1f} us/call, end to end {1e6 * (t2 - t0) / n:.1f} us/call")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for c in range(200):
+        m(ks[c % 8], q, new_doc=False, layer_n=0)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
