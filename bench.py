@@ -10,6 +10,10 @@ in HBM before the timed region.  With N > 1 ranks the video is cut into contiguo
 (strong scaling: total work fixed), each rank consolidates its block as its own document and one
 RCCL all-gather exchanges the consolidated memories (infinite_video_amd.video_memory).
 
+Launch: ``python bench.py --gpus N``.  With N > 1 and no WORLD_SIZE in the environment this
+process only spawns ``python -m torch.distributed.run --nproc-per-node N ... bench.py`` (it never
+touches a GPU itself) and forwards the child's output; under torchrun it is one rank.
+
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
 from __future__ import annotations
@@ -17,16 +21,14 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md), the graded roofline
 T, P, D, N, H, DH, Q, L, TAU, S = 256, 32, 768, 256, 12, 64, 32, 2, 0.75, 512
@@ -40,15 +42,29 @@ BYTES_PER_CHUNK = BYTES_K + L * BYTES_LAYER                        # 39 727 104 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed passes over the video (200 x ~15 ms: a timed region of ~3 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=2048, help="chunks of the synthetic video (whole job)")
     ap.add_argument("--batch-chunks", type=int, default=42,
                     help="largest sub-batch (the library uses 28 for calls shorter than 768 chunks, e.g. multi-GPU shards)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode-video", action="store_true", help="skip the secondary per-chunk Q-former leg")
+    ap.add_argument("--no-selfcheck", action="store_true")
     return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """--gpus N without a torchrun environment: start N ranks as a child job.  Nothing here may initialise the
+    GPU (the children own it; a process that has touched HIP must not exec or fork GPU users on this pool)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def pmc_traffic_per_full_launch():
@@ -61,7 +77,6 @@ def pmc_traffic_per_full_launch():
         return None, None
     d = json.load(open(files[-1]))
     try:
-        # the in-pipeline instantiation: 512-thread workgroups (the unroll factor is a tuning knob)
         fetch = [v for k, v in d["fetch"].items() if "pool_frames_kernel<" in k and ", 512>" in k][0][1]
         write = [v for k, v in d["write"].items() if "pool_frames_kernel<" in k and ", 512>" in k][0][1]
     except (KeyError, IndexError):
@@ -69,11 +84,24 @@ def pmc_traffic_per_full_launch():
     return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
 
 
-def cpu_baseline(budget_s: float):
-    """Reference-shaped CPU port (oracle.DenseOracle) on the host cores: steady-state sticky
-    chunks of the headline shape, 2 LTM layers per chunk sharing one k."""
+# ----------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle on the host cores, 1 thread and the best of a thread sweep
+# ----------------------------------------------------------------------------------------------------------
+def _thread_counts():
+    """Thread counts of the sweep.  All cores is only tried up to 64: on the 256-thread GPU host one chunk of the
+    reference-shaped port took 130 s with 256 ATen threads (0.008 chunks/s, oversubscription) against 0.6 s with 8."""
+    import torch
+    full = max(1, os.cpu_count() or 1, torch.get_num_threads())
+    return sorted({n for n in (8, 16, 32, min(full, 64)) if n <= full} | {min(full, 8)})
+
+
+def _time_dense(threads: int, budget_s: float, max_chunks: int):
+    """Steady-state sticky chunks of the headline shape through oracle.DenseOracle (the reference's ATen sequence,
+    including the four extra compute_probability calls of its density side effect, LTM.py:320-341)."""
+    import torch
     from infinite_video_amd import synth
     from oracle.ltm_oracle import DenseOracle
+    torch.set_num_threads(threads)
     layers = []
     for l in range(L):
         wk, bk, wv, bv = synth.layer_projections(l, D, DM)
@@ -81,7 +109,7 @@ def cpu_baseline(budget_s: float):
         with torch.no_grad():
             pk.weight.copy_(torch.from_numpy(wk)); pk.bias.copy_(torch.from_numpy(bk))
             pv.weight.copy_(torch.from_numpy(wv)); pv.bias.copy_(torch.from_numpy(bv))
-        layers.append(DenseOracle(N, H, DH, TAU, True, pk, pv))
+        layers.append(DenseOracle(N, H, DH, TAU, True, pk, pv, density_side_effect=True))
     qs = [torch.from_numpy(synth.layer_query(l, Q, DM)).unsqueeze(0) for l in range(L)]
     torch.manual_seed(synth.SEED_U)
     done, elapsed, c = 0, 0.0, 0
@@ -96,23 +124,20 @@ def cpu_baseline(budget_s: float):
                 done += 1
                 elapsed += dt
             c += 1
-            if (elapsed >= budget_s and done >= 2) or done >= 64:
+            if (elapsed >= budget_s and done >= 1) or done >= max_chunks:
                 break
-    return {"value": done / elapsed, "unit": "frame-chunks/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{done} steady-state sticky chunks (T=256,N=256,2 layers) after 1 warm-up chunk, "
-                      f"oracle.DenseOracle (reference-shaped ATen sequence), {elapsed:.1f}s"}
+    return done, elapsed
 
 
-def cpu_closed_form(budget_s: float):
-    """The oracle's closed-form CPU restatement (same algebra as the HIP kernels: sparse operator, closed-form
-    read-out) on the host cores -- the honest best-CPU comparison next to the reference-shaped port (SURVEY.md 8d ii)."""
+def _time_closed(threads: int, budget_s: float, max_chunks: int):
+    import torch
     from infinite_video_amd import synth
     from oracle.ltm_oracle import ClosedFormOracle
+    torch.set_num_threads(threads)
     ws = [synth.layer_projections(l, D, DM) for l in range(L)]
     orcs = [ClosedFormOracle(N, H, DH, TAU, True, *ws[l], tokens_per_frame=P) for l in range(L)]
     qs = [synth.layer_query(l, Q, DM) for l in range(L)]
-    u = synth.gibbs_uniforms(64, L)
+    u = synth.gibbs_uniforms(max_chunks + 1, L)
     done, elapsed, c = 0, 0.0, 0
     while True:
         k = synth.frame_tokens(c, T, P, D)
@@ -124,14 +149,99 @@ def cpu_closed_form(budget_s: float):
             done += 1
             elapsed += dt
         c += 1
-        if (elapsed >= budget_s and done >= 2) or done >= 63:
+        if (elapsed >= budget_s and done >= 2) or done >= max_chunks:
             break
-    return {"value": done / elapsed, "unit": "frame-chunks/s", "cores": torch.get_num_threads(), "kind": "port (closed form)",
-            "sample": f"{done} steady-state sticky chunks, oracle.ClosedFormOracle (numpy/torch CPU), {elapsed:.1f}s"}
+    return done, elapsed
+
+
+def cpu_baselines(budget_s: float):
+    """(cpu_baseline, cpu_closed_form): reference-shaped port and closed-form port, each at 1 thread and at the
+    best of {8, 16, 32, all} threads (an oversubscribed all-cores run is not assumed to be the fastest)."""
+    import torch
+    saved = torch.get_num_threads()
+    counts = _thread_counts()
+    share = budget_s * 0.8 / (len(counts) + 2)            # the 1-thread run gets a double share
+    dense = {}
+    n1, t1 = _time_dense(1, 2 * share, 2)
+    dense[1] = (n1, t1)
+    for n in counts:
+        if n != 1:
+            dense[n] = _time_dense(n, share, 4)
+    best = max(dense, key=lambda n: dense[n][0] / dense[n][1])
+    total = sum(t for _, t in dense.values())
+    base = {"value": dense[best][0] / dense[best][1], "unit": "frame-chunks/s", "cores": best, "kind": "port",
+            "one_thread": dense[1][0] / dense[1][1],
+            "threads_tried": {str(n): round(d / t, 4) for n, (d, t) in sorted(dense.items())},
+            "host_cpus": os.cpu_count(),
+            "sample": f"steady-state sticky chunks (T=256,N=256,2 layers sharing k) after 1 new-document chunk, "
+                      f"oracle.DenseOracle = the reference's ATen sequence incl. its density side effect "
+                      f"(LTM.py:320-341), {sum(d for d, _ in dense.values())} chunks over "
+                      f"{len(dense)} thread counts, {total:.1f}s; value = best thread count"}
+    closed = {}
+    cshare = budget_s * 0.2 / (len(counts) + 1)
+    for n in [1] + [n for n in counts if n != 1]:
+        closed[n] = _time_closed(n, cshare, 24)
+    cbest = max(closed, key=lambda n: closed[n][0] / closed[n][1])
+    cf = {"value": closed[cbest][0] / closed[cbest][1], "unit": "frame-chunks/s", "cores": cbest,
+          "kind": "port (closed form)", "one_thread": closed[1][0] / closed[1][1],
+          "threads_tried": {str(n): round(d / t, 3) for n, (d, t) in sorted(closed.items())},
+          "sample": f"steady-state sticky chunks, oracle.ClosedFormOracle (numpy/torch CPU), "
+                    f"{sum(t for _, t in closed.values()):.1f}s"}
+    torch.set_num_threads(saved)
+    return base, cf
+
+
+# ----------------------------------------------------------------------------------------------------------
+def selfcheck(eng_cls, dev, k, q, projs, u, ctx_timed, trace, batch_chunks):
+    """Compare the timed path (one consolidate call over the whole block) with the per-chunk forward chain.
+    (1) first 24 chunks from scratch: forward() per chunk, its draw forced to the timed run's recorded bins so that a
+        uniform within rounding of a cdf edge cannot send the two chains apart; the per-chunk path's own draw is
+        compared bin by bin (flips) and its ctx with the timed run's.
+    (2) last chunk: consolidate the first C-1 chunks on a second engine, then ONE per-chunk forward() for chunk C-1."""
+    import numpy as np
+    import torch
+    bins_all, _ = trace
+    c_local = k.shape[0]
+    n_head = min(24, c_local)
+    out = {"head_chunks": n_head}
+    ref = eng_cls(N, H, DH, D, P, tau=TAU, sticky=True, n_layers=L, max_q=Q, device=dev, max_batch_chunks=batch_chunks)
+    worst, flips = 0.0, 0
+    bins_host = bins_all[:n_head].cpu().numpy()
+    for c in range(n_head):
+        if c > 0:
+            for l in range(L):
+                ref.set_bins(l, bins_host[c, l])
+        y = ref.forward(k[c], q, projs, u[c], new_doc=(c == 0))
+        worst = max(worst, float((y - ctx_timed[c]).abs().max()))
+        if c > 0:
+            for l in range(L):
+                flips += int((ref.last_draw(l)[0] != bins_host[c, l]).sum())
+    out["head_max_abs_err"] = worst
+    out["head_draw_flips"] = flips
+    if c_local >= 2:
+        ref.consolidate(k[:c_local - 1], q, projs, u[:c_local - 1], new_doc=True)
+        last_bins = bins_all[c_local - 1].cpu().numpy()
+        for l in range(L):
+            ref.set_bins(l, last_bins[l])
+        y = ref.forward(k[c_local - 1], q, projs, u[c_local - 1], new_doc=False)
+        ref.sync()
+        out["last_chunk_max_abs_err"] = float((y - ctx_timed[c_local - 1]).abs().max())
+        out["last_chunk_draw_flips"] = int(sum((ref.last_draw(l)[0] != last_bins[l]).sum() for l in range(L)))
+        worst = max(worst, out["last_chunk_max_abs_err"])
+    out["max_abs_err"] = worst
+    del ref
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,6 +296,30 @@ def main():
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(ctx).all()), "non-finite consolidation output"
 
+    # ---- self-check of the code path that was just timed (same engine, same call, plus a draw trace) ----
+    check = None
+    if not args.no_selfcheck:
+        trace = eng.set_trace(c_local)
+        ctx_chk, _ = one_step()
+        eng.set_trace(0)
+        assert torch.equal(ctx_chk, ctx), "the consolidation is not reproducible run to run"
+        check = selfcheck(LTMEngine, dev, k, q, projs, u, ctx_chk, trace, args.batch_chunks)
+        del trace
+
+    # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing ----
+    shard256_ms = None
+    if world == 1 and c_local >= 256:
+        for _ in range(2):
+            consolidate_video(eng, k[:256], q, projs, u[:256])
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t1 = time.perf_counter()
+            consolidate_video(eng, k[:256], q, projs, u[:256])
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        shard256_ms = 1e3 * sorted(ts)[len(ts) // 2]
+
     # ---- the HBM-bound kernel on its own (no other stream running): 5 launches of one sub-batch ----
     nb = min(args.batch_chunks if c_local >= 768 else min(args.batch_chunks, 28), c_local)
     eng.pool(k[:nb])
@@ -211,8 +345,8 @@ def main():
         "kernel": "pool_frames_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "achieved_alone": alone_gbs, "frac_alone": alone_gbs / HBM_PEAK_GBS,
-        "note": "achieved = in situ (512-thread instantiation, 4 KiB in flight per wave, LDS-padded to 1 WG/CU), while the pool shares the chip with the chain and UC streams; "
-                "achieved_alone = same launch size through infv_ltm_pool (256-thread instantiation, no pad), nothing else running",
+        "note": "achieved = in situ, while the pool shares the chip with the chain and update/read-out streams; "
+                "achieved_alone = same launch size through infv_ltm_pool, nothing else running",
         "launches": pool_n, "avg_launch_ms": pool_ms / max(pool_n, 1),
         "bytes_per_full_launch": nb * BYTES_POOL_PER_CHUNK,
         "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
@@ -246,11 +380,13 @@ def main():
 
     if rank == 0:
         value = args.chunks * args.steps / elapsed
+        v_split = os.environ.get("INFV_VPROJ_SPLIT", "0") not in ("", "0")
         out = {
             "metric": "frame-chunks/sec consolidated (max_int=256, num_basis=256, d=768)",
             "value": value, "unit": "frame-chunks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (V' projection bf16x3)" if v_split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.chunks}-chunk synthetic video, max_int=256 frames x 32 tokens x 768, "
                                    "num_basis=256, tau=0.75, sticky, 2 video-Q-former LTM layers, "
                                    "Q=32 queries, LLM/Q-former stubbed (BASELINE configs[1]/[2])",
@@ -258,12 +394,16 @@ def main():
                        "parallelism": f"chunk-block sharding x{world} + 1 all-gather of consolidated memory"},
             "roofline": roofline,
         }
+        if check is not None:
+            out["selfcheck"] = check
+            out["selfcheck_max_abs_err"] = check["max_abs_err"]
+        if shard256_ms is not None:
+            out["shard256_ms"] = shard256_ms
         if encode_video is not None:
             out["encode_video"] = encode_video
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"], out["cpu_closed_form"] = cpu_baselines(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            out["cpu_closed_form"] = cpu_closed_form(min(args.cpu_seconds, 6.0))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -16,8 +16,12 @@
  *     the handle owns only the consolidated memory (coefficients B, their projections,
  *     the sticky histogram) and its workspaces;
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*,
- *     NULL = the null stream); no entry point synchronises except export/get calls that
- *     copy to HOST buffers;
+ *     NULL = the null stream); no entry point synchronises except infv_ltm_sync and the
+ *     get calls that copy to HOST buffers;
+ *   - a failure that only shows on the device (the persistent chain kernel of
+ *     infv_ltm_consolidate timed out waiting for workgroups that never became resident, e.g.
+ *     on a partitioned or shared GPU) is latched in host-visible memory: infv_ltm_sync and
+ *     every later entry point on the handle return INFV_ERR_STATE once, the memory is reset;
  *   - return value: 0 on success, negative infv_status on failure; nothing throws across
  *     the ABI.  infv_ltm_last_error() returns a thread-local description;
  *   - a handle is not re-entrant (the reference module is mutable, single-threaded state);
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define INFV_LTM_ABI_VERSION 1
+#define INFV_LTM_ABI_VERSION 2
 #define INFV_LTM_MAX_LAYERS 8
 
 typedef enum {
@@ -161,6 +165,20 @@ int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* 
 /* Teacher forcing for tests: the next step of `layer` draws from these HOST probs[n_bins-1]
  * instead of the ones derived from its own scores (one-shot). */
 int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs);
+/* Forced draw (one-shot, per-call step/forward only): the next step of `layer` resamples the
+ * rows of these HOST bins[S] (values in [0, n_bins-1)) instead of its own draw.  The step still
+ * derives its own probabilities and draw; infv_ltm_get_draw then returns the step's OWN bins
+ * next to the idx actually used, so a long chain can be compared draw by draw with another path
+ * without the two diverging at the first uniform that falls within rounding of a cdf edge. */
+int infv_ltm_set_bins(infv_ltm_handle h, int32_t layer, const int32_t* bins);
+/* Draw trace of infv_ltm_consolidate: while set, chunk c of a call (c < capacity_chunks) writes
+ * the bins it drew to bins_all[c][L][S] and its probabilities to probs_all[c][L][n_bins]
+ * (DEVICE buffers owned by the caller, either may be NULL; rows of a document's first chunk,
+ * which draws nothing, are left untouched).  capacity_chunks = 0 clears the trace. */
+int infv_ltm_set_trace(infv_ltm_handle h, int32_t* bins_all, float* probs_all, int64_t capacity_chunks);
+
+/* Synchronises `stream`, then reports a latched device-side failure (see Conventions). */
+int infv_ltm_sync(infv_ltm_handle h, void* stream);
 
 /* Measurement (bench.py's roofline leg): while enabled, every kernel launch the handle issues
  * is bracketed by HIP events on the launch stream.  profile_read synchronises, returns the

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinfv_ltm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LAYERS = 8
 
 i32p = C.POINTER(C.c_int32)
@@ -102,6 +102,9 @@ _SIGNATURES = {
     "infv_ltm_reproject": (C.c_int, [C.c_void_p, C.POINTER(Proj), C.c_void_p]),
     "infv_ltm_get_draw": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, f32p, f32p, C.c_void_p]),
     "infv_ltm_set_probs": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
+    "infv_ltm_set_bins": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
+    "infv_ltm_set_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "infv_ltm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "infv_ltm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     # include/infv_vqf.h

@@ -132,7 +132,14 @@ struct infv_ltm_s {
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
-    DeviceBuf sync_words;              // [0..7] arrival counters per layer, [8] error flag of the persistent chain kernel
+    DeviceBuf sync_words;              // [0..7] arrival counters per layer
+    // error word of the persistent chain kernel: pinned host memory mapped into the device, so a time-out is
+    // visible to the host without any synchronisation or copy
+    unsigned int* err_host = nullptr; unsigned int* err_dev = nullptr;
+    bool v_split = false;               // INFV_VPROJ_SPLIT=1 at create: V' half of the sub-batch projection as a split-bf16 contraction
+    int spin_limit = 1 << 22; int expect_extra = 0;     // INFV_CHAIN_FAULT=1 (tests): expect one arrival too many -> every wait times out
+    int32_t* trace_bins = nullptr; float* trace_probs = nullptr; long trace_cap = 0;   // draw trace of consolidate (caller's device buffers)
+    DeviceBuf bins_forced; unsigned forced_mask = 0;    // one-shot forced draw of the per-call path
     DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][128] u64, ring of 3 (read / accumulate / being cleared)
     int sc = 0;
     int n_bins = 128;
@@ -148,6 +155,7 @@ struct infv_ltm_s {
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
+        if (err_host) (void)hipHostFree(err_host);
     }
 };
 
@@ -155,6 +163,20 @@ namespace {
 
 int check_handle(infv_ltm_handle h) {
     if (!h) return fail(INFV_ERR_INVALID, "null handle");
+    return INFV_OK;
+}
+
+// A time-out of the persistent chain kernel leaves garbage in the memory: report it once (at the next entry point
+// that would use or extend the memory, or at infv_ltm_sync) and forget the memory.
+int check_chain_error(infv_ltm_handle h) {
+    if (h->err_host && *reinterpret_cast<volatile unsigned int*>(h->err_host)) {
+        *reinterpret_cast<volatile unsigned int*>(h->err_host) = 0;
+        h->has_memory = false; h->parts = 0; h->k_stale = false;
+        return fail(INFV_ERR_STATE, "the persistent chain kernel of an earlier infv_ltm_consolidate timed out waiting for the "
+                                    "other workgroups of its layer (not all co-resident: partitioned or shared GPU?); "
+                                    "its outputs and the memory are invalid, the memory has been reset "
+                                    "(INFV_PERSISTENT=0 selects one launch per chunk)");
+    }
     return INFV_OK;
 }
 
@@ -220,8 +242,10 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
             Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
             HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(),
                                 h->override_mask, plan.sticky(), u, h->S, h->L,
-                                h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream));
+                                h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream,
+                                h->bins_forced.as<int32_t>(), h->forced_mask));
             h->override_mask = 0;
+            h->forced_mask = 0;
             idx = h->idx.as<int32_t>();
             idx_stride = h->S;
         } else {
@@ -329,6 +353,11 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     }
     if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(h->sync_words.p, 0, 16 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess) { memset(h->err_host, 0, 64); e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->err_dev), h->err_host, 0); }
+    if (e == hipSuccess) e = h->bins_forced.reserve((size_t)h->L * h->S * sizeof(int32_t));
+    if (const char* f = getenv("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
+    if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
     h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
@@ -413,6 +442,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
                   const infv_ltm_proj* proj, const double* u, float* ctx, void* stream_) {
     if (int rc = check_handle(h)) return rc;
     if (!kbar || !q || !proj || !ctx) return fail(INFV_ERR_INVALID, "step: null argument");
+    if (int rc = check_chain_error(h)) return rc;
     if (int rc = check_q(h, Q)) return rc;
     Plan* plan = nullptr;
     if (int rc = find_plan(h, T, &plan)) return rc;
@@ -479,6 +509,10 @@ struct FastPipe {
         s.probs_override = h->probs_override.as<float>(); s.override_mask = h->override_mask;
         s.u = st.u; s.uniform_idx = plan.uniform_idx.as<int32_t>();
         s.probs_out = h->probs.as<float>(); s.bins_out = h->bins.as<int32_t>(); s.idx_out = h->idx.as<int32_t>();
+        if (h->trace_cap > counter) {
+            s.probs_tr = h->trace_probs ? h->trace_probs + (size_t)counter * h->L * h->n_bins : nullptr;
+            s.bins_tr = h->trace_bins ? h->trace_bins + (size_t)counter * h->L * h->S : nullptr;
+        }
         s.tab_out = h->tab_ring.as<int32_t>() + slot * tab_slot();
         s.Sp_prev = h->Sp[h->sc].as<float>(); s.Sp_next = h->Sp[h->sc ^ 1].as<float>();
         s.Snew = st.Snew; s.snew_ld = h->L * h->dm + h->L * h->H * Q; s.snew_splitk = st.sk; s.snew_split_stride = st.ss;
@@ -528,7 +562,13 @@ struct FastPipe {
         b.first_from_parts = (counter == 0) ? 1 : 0;
         b.part_prev = h->bin_part[h->pc].as<float>(); b.parts = h->parts;
         for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
-        b.arrive = h->sync_words.as<unsigned int>(); b.error = h->sync_words.as<unsigned int>() + 8;
+        b.arrive = h->sync_words.as<unsigned int>(); b.error = h->err_dev;
+        b.spin_limit = h->spin_limit; b.expect_extra = h->expect_extra;
+        if (h->trace_cap > counter) {
+            b.trace_steps = (int)((h->trace_cap - counter < n) ? h->trace_cap - counter : n);
+            b.probs_tr = h->trace_probs ? h->trace_probs + (size_t)counter * h->L * h->n_bins : nullptr;
+            b.bins_tr = h->trace_bins ? h->trace_bins + (size_t)counter * h->L * h->S : nullptr;
+        }
         b.probs_override = h->probs_override.as<float>(); b.override_mask = h->override_mask;
         b.u = u; b.uniform_idx = plan.uniform_idx.as<int32_t>();
         b.probs_out = h->probs.as<float>(); b.bins_out = h->bins.as<int32_t>(); b.idx_out = h->idx.as<int32_t>();
@@ -718,6 +758,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
                          void* stream_) {
     if (int rc = check_handle(h)) return rc;
     if (!k || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
+    if (int rc = check_chain_error(h)) return rc;
     if (int rc = check_q(h, Q)) return rc;
     Plan* plan = nullptr;
     if (int rc = find_plan(h, T, &plan)) return rc;
@@ -788,7 +829,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     // INFV_PERSISTENT=0 falls back to one role-S launch per chunk
     static const bool want_persistent = [] { const char* e = getenv("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
     const bool persistent = want_persistent &&
-        chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
+        chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L) &&
+        chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
     const int first_c = c;
     // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
     // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 28 so that the
@@ -893,10 +935,9 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
             Timed t_(h->prof, INFV_KERNEL_PROJECT, vs);
             const long Mv = (long)nb * plan->inf.rows;
             const int v_cols = h->L * h->dm, p_ld = h->L * h->dm + h->L * h->H * Q;
-            // V' only feeds the read-out (1e-3 budget): split-bf16 contraction (three bf16 MFMA products, ~1e-5
-            // relative) unless INFV_VPROJ_SPLIT=0
-            static const bool v_split = [] { const char* e = getenv("INFV_VPROJ_SPLIT"); return !e || atoi(e) != 0; }();
-            if (v_split && h->d % 64 == 0 && v_cols % 128 == 0) {
+            // exact fp32 MFMA by default.  INFV_VPROJ_SPLIT=1: V' only feeds the read-out (1e-3 budget), so it may run as a
+            // split-bf16 contraction (three bf16 MFMA products, ~1e-5 relative); bench.py then labels its dtype accordingly
+            if (h->v_split && h->d % 64 == 0 && v_cols % 128 == 0) {
                 const size_t szW = (size_t)v_cols * h->d * 2, szR = (size_t)h->maxC * plan->inf.rows * h->d * 2;
                 if (szW > h->wv_hi.bytes || szR > h->R_hi.bytes) {
                     HIP_TRY(hipDeviceSynchronize());
@@ -956,6 +997,7 @@ extern "C" {
 int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin_mass, void* stream_) {
     if (int rc = check_handle(h)) return rc;
     if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
+    if (int rc = check_chain_error(h)) return rc;
     if (!h->has_memory) return fail(INFV_ERR_STATE, "no memory to export (B_past is None)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (B) HIP_TRY(hipMemcpyAsync(B, h->B[h->cur].as<float>() + (size_t)layer * h->N * h->d,
@@ -1007,11 +1049,7 @@ int infv_ltm_get_draw(infv_ltm_handle h, int32_t layer, int32_t* bins, int32_t* 
     if (layer < 0 || layer >= h->L) return fail(INFV_ERR_INVALID, "layer out of range");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipStreamSynchronize(stream));
-    {
-        unsigned int err = 0;
-        HIP_TRY(hipMemcpy(&err, h->sync_words.as<unsigned int>() + 8, sizeof(err), hipMemcpyDeviceToHost));
-        if (err) return fail(INFV_ERR_STATE, "a workgroup of the persistent chain kernel timed out waiting for its layer");
-    }
+    if (int rc = check_chain_error(h)) return rc;
     if (bins) HIP_TRY(hipMemcpy(bins, h->bins.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (idx) HIP_TRY(hipMemcpy(idx, h->idx.as<int32_t>() + (size_t)layer * h->S, h->S * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (probs) HIP_TRY(hipMemcpy(probs, h->probs.as<float>() + (size_t)layer * h->n_bins, (h->n_bins - 1) * sizeof(float), hipMemcpyDeviceToHost));
@@ -1038,6 +1076,31 @@ int infv_ltm_set_probs(infv_ltm_handle h, int32_t layer, const float* probs) {
                       (h->n_bins - 1) * sizeof(float), hipMemcpyHostToDevice));
     h->override_mask |= 1u << layer;
     return INFV_OK;
+}
+
+int infv_ltm_set_bins(infv_ltm_handle h, int32_t layer, const int32_t* bins) {
+    if (int rc = check_handle(h)) return rc;
+    if (layer < 0 || layer >= h->L || !bins) return fail(INFV_ERR_INVALID, "set_bins: bad arguments");
+    for (int s = 0; s < h->S; ++s)
+        if (bins[s] < 0 || bins[s] >= h->n_bins - 1) return fail(INFV_ERR_INVALID, "set_bins: bins[%d]=%d outside [0,%d)", s, bins[s], h->n_bins - 1);
+    HIP_TRY(hipMemcpy(h->bins_forced.as<int32_t>() + (size_t)layer * h->S, bins, h->S * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->forced_mask |= 1u << layer;
+    return INFV_OK;
+}
+
+int infv_ltm_set_trace(infv_ltm_handle h, int32_t* bins_all, float* probs_all, int64_t capacity_chunks) {
+    if (int rc = check_handle(h)) return rc;
+    if (capacity_chunks < 0) return fail(INFV_ERR_INVALID, "set_trace: negative capacity");
+    h->trace_bins = capacity_chunks ? bins_all : nullptr;
+    h->trace_probs = capacity_chunks ? probs_all : nullptr;
+    h->trace_cap = (h->trace_bins || h->trace_probs) ? (long)capacity_chunks : 0;
+    return INFV_OK;
+}
+
+int infv_ltm_sync(infv_ltm_handle h, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return check_chain_error(h);
 }
 
 int infv_ltm_profile_enable(infv_ltm_handle h, int32_t on) {

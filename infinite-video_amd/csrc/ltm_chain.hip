@@ -235,7 +235,9 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
                                 a.S, lds + m.cdf, sidx, reinterpret_cast<double*>(lds + m.gsum),
                                 writer ? rs.probs_out + l * kBins : nullptr,
                                 writer ? rs.bins_out + (long)l * a.S : nullptr,
-                                writer ? rs.idx_out + (long)l * a.S : nullptr, (b == 0) ? a.dbg : nullptr);
+                                writer ? rs.idx_out + (long)l * a.S : nullptr, (b == 0) ? a.dbg : nullptr, nullptr,
+                                (writer && rs.probs_tr) ? rs.probs_tr + l * kBins : nullptr,
+                                (writer && rs.bins_tr) ? rs.bins_tr + (long)l * a.S : nullptr);
         if (rs.draw_mode != 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {

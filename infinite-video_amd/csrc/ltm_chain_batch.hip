@@ -154,9 +154,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
             unsigned long long v = coherent_read(acc_prev + tid);
             if (i > 0) {
                 int spins = 0;
-                while ((v >> kArriveShift) < (unsigned long long)blocks_per_layer) {
+                while ((v >> kArriveShift) < (unsigned long long)(blocks_per_layer + a.expect_extra)) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22)) { atomicExch(a.error, 1u); break; }
+                    // give up loudly: the word lives in host-visible memory, every later call on the handle reports it
+                    if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     v = coherent_read(acc_prev + tid);
                 }
             }
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
                                  reinterpret_cast<double*>(lds + m.gsum),
                                  (writer && last) ? a.probs_out + l * kBins : nullptr,
                                  (writer && last) ? a.bins_out + (long)l * a.S : nullptr,
-                                 (writer && last) ? a.idx_out + (long)l * a.S : nullptr);
+                                 (writer && last) ? a.idx_out + (long)l * a.S : nullptr, nullptr, nullptr,
+                                 (writer && a.probs_tr && i < a.trace_steps) ? a.probs_tr + ((long)i * a.L + l) * kBins : nullptr,
+                                 (writer && a.bins_tr && i < a.trace_steps) ? a.bins_tr + ((long)i * a.L + l) * a.S : nullptr);
         } else {
             __syncthreads();
         }
@@ -323,7 +326,7 @@ bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
            n_blocks <= 384 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
 }
 
-hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
+static hipError_t chain_batch_attr() {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch_kernel),
@@ -331,6 +334,25 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    return hipSuccess;
+}
+
+// The persistent kernel spin-waits on its own workgroups: all of them must fit on the device at once, with this
+// kernel's registers and LDS, even if nothing else left room (other kernels may still delay residency; the waits are
+// bounded and report through the error word).  One workgroup per CU less than the API's answer: the occupancy
+// query reads one high for some SGPR counts (MI355X_MICROARCH.md, residency).
+bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks) {
+    if (chain_batch_attr() != hipSuccess) return false;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch_kernel, kBNT, chain_batch_lds_bytes(N, S, rows, tabw)) != hipSuccess) return false;
+    const int safe = per_cu > 1 ? per_cu - 1 : per_cu;
+    return (long)safe * cus >= n_blocks;
+}
+
+hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
+    if (hipError_t e = chain_batch_attr()) return e;
     if (a.n_steps <= 0) return hipSuccess;
     const int blocks = a.H * a.QS * a.L;
     if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, blocks)) return hipErrorInvalidValue;

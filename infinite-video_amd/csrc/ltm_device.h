@@ -137,7 +137,9 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
 template <int NT, int SPT>
 __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, const int32_t* bin_box, int S,
                                    float* cdf, int32_t* sidx, double* gsum /*LDS[(NT/128)*128]*/, float* probs_out,
-                                   int32_t* bins_out, int32_t* idx_out, long long* dbg = nullptr) {
+                                   int32_t* bins_out, int32_t* idx_out, long long* dbg = nullptr,
+                                   const int32_t* __restrict__ forced = nullptr /*[S] bins to resample instead of the draw*/,
+                                   float* __restrict__ probs_tr = nullptr, int32_t* __restrict__ bins_tr = nullptr /*draw trace*/) {
 #define DSTAMP(i) do { if (dbg != nullptr && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
     constexpr int nb = kBins - 1;
     constexpr int G = NT / kBins;
@@ -165,6 +167,7 @@ __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, co
         }
         if (j1 >= nb) p1 = 0.f;
         if (probs_out != nullptr) { probs_out[j0] = p0; if (j1 < nb) probs_out[j1] = p1; }
+        if (probs_tr != nullptr) { probs_tr[j0] = p0; if (j1 < nb) probs_tr[j1] = p1; }
         DSTAMP(13);
         // Sequential fp32 running sum in bin order (torch.multinomial, CPU), as a systolic scan over the
         // lanes: c <- wave_shr:1(c) + p.  After t steps lane i holds the left-to-right sum of its last
@@ -203,9 +206,10 @@ __device__ inline void draw_finish(const DrawRegs<SPT>& r, bool use_override, co
                       ((double)f1.x < us) + ((double)f1.y < us) + ((double)f1.z < us);
             }
             lo = min(lo, nb - 1);
-            const int box = bin_box[lo];
+            const int box = bin_box[(forced != nullptr) ? min(max(forced[s], 0), nb - 1) : lo];
             sidx[s] = box;
             if (bins_out != nullptr) { bins_out[s] = lo; idx_out[s] = box; }
+            if (bins_tr != nullptr) bins_tr[s] = lo;
         }
     }
     __syncthreads();

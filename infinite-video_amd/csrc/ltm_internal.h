@@ -71,7 +71,8 @@ hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, 
 
 hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
-                       int32_t* bins, int32_t* idx, hipStream_t stream);
+                       int32_t* bins, int32_t* idx, hipStream_t stream, const int32_t* bins_forced = nullptr,
+                       unsigned forced_mask = 0);
 
 // next[l][n] = val_n * sum_{slots s of box n} prev[l][idx[l][s]] + new row of box n, for B and [K'|V'].
 hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
@@ -95,6 +96,7 @@ struct ChainRoleS {
     unsigned long long* acc_next; unsigned long long* acc_clear;   // this step's totals; the ring slot to zero for the next
     const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;     // [L][128], [L][S], [L][S]  (diagnostics)
+    float* probs_tr; int32_t* bins_tr;                         // draw trace rows of this chunk ([L][128], [L][S]) or nullptr
     int32_t* tab_out;               // [L][N*tabw] resolved source box of every (box, slot) for role U
     const float* Sp_prev; float* Sp_next; const float* cq; const float* w; float w_out;
     const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // this chunk's new-row scores: row pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
@@ -122,11 +124,14 @@ struct ChainBatchArgs {
     const float* part_prev; int parts;
     unsigned long long* acc[3];     // fixed-point sticky histograms [L][128], ring of 3
     unsigned int* arrive;           // [L] arrival counters, zero at launch
-    unsigned int* error;            // set to 1 if a wait timed out
+    unsigned int* error;            // host-visible word, set to 1 if a wait timed out
+    int spin_limit;                 // polls before a wait gives up
+    int expect_extra;               // fault injection (tests): arrivals expected beyond the launch's workgroups
     const float* probs_override; unsigned override_mask;     // teacher forcing of step 0
     const double* u;                // [n_steps][L][S]
     const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;    // diagnostics of the last step
+    float* probs_tr; int32_t* bins_tr; int trace_steps;       // draw trace of steps [0, trace_steps): [.][L][128], [.][L][S] (either may be null)
     int32_t* tab_ring; long tab_slot;
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
@@ -135,6 +140,7 @@ struct ChainBatchArgs {
     long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
 };
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
+bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks);   // all workgroups fit on the device at once
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
 
 // ---- state update + read-out of a sub-batch in one launch (ltm_uc.hip) ----

@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin
                                                    unsigned override_mask, StickyView sticky,
                                                    const double* __restrict__ u, int S,
                                                    float* __restrict__ probs_out, int32_t* __restrict__ bins_out,
-                                                   int32_t* __restrict__ idx_out) {
+                                                   int32_t* __restrict__ idx_out,
+                                                   const int32_t* __restrict__ bins_forced, unsigned forced_mask) {
     __shared__ float cdf[kBins];
     __shared__ double gsum[256];
     __shared__ int32_t sidx[1024];
@@ -410,15 +411,15 @@ __global__ __launch_bounds__(256) void draw_kernel(const float* __restrict__ bin
     const DrawRegs<4> r = draw_load<256, 4>(bin_part + (long)l * parts * kBins, parts, nullptr, probs_override + l * kBins,
                                             ovr, u + (long)l * S, S);
     draw_finish<256, 4>(r, ovr, sticky.bin_box, S, cdf, sidx, gsum, probs_out + l * kBins, bins_out + (long)l * S,
-                        idx_out + (long)l * S);
+                        idx_out + (long)l * S, nullptr, ((forced_mask >> l) & 1u) ? bins_forced + (long)l * S : nullptr);
 }
 
 hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
-                       int32_t* bins, int32_t* idx, hipStream_t stream) {
+                       int32_t* bins, int32_t* idx, hipStream_t stream, const int32_t* bins_forced, unsigned forced_mask) {
     if (S > 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(draw_kernel, dim3(n_layers), dim3(256), 0, stream, bin_part, parts, probs_override,
-                       override_mask, sticky, u, S, probs, bins, idx);
+                       override_mask, sticky, u, S, probs, bins, idx, bins_forced, forced_mask);
     return hipGetLastError();
 }
 

@@ -252,6 +252,33 @@ class LTMEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_set_probs(self._h, layer, p.ctypes.data_as(_lib.f32p)))
 
+    def set_bins(self, layer: int, bins: np.ndarray):
+        """Forced draw of the next per-call step of ``layer`` (see infv_ltm_set_bins)."""
+        b = _np_i32(bins)
+        if b.size != self.S:
+            raise ValueError(f"bins must have {self.S} entries")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_set_bins(self._h, layer, b.ctypes.data_as(_lib.i32p)))
+
+    def set_trace(self, n_chunks: int):
+        """Record the draw of every chunk of the following consolidate() calls: returns device tensors
+        (bins [n_chunks, L, S] int32 initialised to -1, probs [n_chunks, L, 128] fp32); ``n_chunks = 0`` stops tracing."""
+        if n_chunks <= 0:
+            self._trace = None
+            _lib.check(self.lib.infv_ltm_set_trace(self._h, None, None, 0))
+            return None
+        bins = torch.full((n_chunks, self.L, self.S), -1, device=self.device, dtype=torch.int32)
+        probs = torch.zeros(n_chunks, self.L, NB_BINS, device=self.device, dtype=torch.float32)
+        self._trace = (bins, probs)                       # keep the buffers alive while the library writes them
+        _lib.check(self.lib.infv_ltm_set_trace(self._h, _ptr(bins), _ptr(probs), n_chunks))
+        return bins, probs
+
+    def sync(self):
+        """Wait for the engine's work on the current stream and raise if a device-side failure was latched
+        (the persistent chain kernel of consolidate() timed out: its outputs are invalid)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_sync(self._h, _stream(self.device)))
+
     # ------------------------------------------------------------------ measurement
     def profile(self, on: bool):
         """Bracket every kernel launch of this engine with HIP events (bench.py's roofline leg)."""

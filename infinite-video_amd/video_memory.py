@@ -80,11 +80,17 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
 
     k_local [C_local, T*P, d]; q [L, Q, dm]; u_local [C_local, L, S] (rows keyed by global chunk id).
     Returns (per-chunk outputs of this rank [C_local, L, Q, dm], gathered ConsolidatedMemory).
-    Works without an initialised process group (world = 1, no collective)."""
+    Works without an initialised process group (world = 1, no collective); with an initialised group the
+    all-gather is issued whatever its size (a world of one still goes through RCCL).
+
+    This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
+    raises if the persistent chain kernel reported a failure instead of passing an invalid memory on."""
     ctx = engine.consolidate(k_local, q, projs, u_local, new_doc=True)
+    engine.sync()
     payload = pack_local_memory(engine, ctx)
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    if world > 1:
+    have_group = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if have_group else 1
+    if have_group:
         gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=payload.dtype)
         dist.all_gather_into_tensor(gathered, payload, group=group)
     else:

@@ -3,6 +3,7 @@ reference goldens, and that the C-ABI library loads and exports every declared s
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -121,3 +122,30 @@ def test_plan_refuses_num_basis_whose_fp32_boxes_overlap():
             basis_maps.build_plan(256, N, .75)
     for N in (144, 272):                                   # non-power-of-two values whose boxes do partition the samples
         basis_maps.build_plan(256, N, .75)
+
+
+def test_bench_gpus_flag_spawns_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment must start N ranks as a child job
+    (torch.distributed.run, 127.0.0.1 rendezvous) and leave the GPU to them."""
+    import subprocess
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

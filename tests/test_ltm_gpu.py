@@ -129,13 +129,17 @@ def test_draw_kernel_equals_torch_multinomial_on_skewed_probs(dev):
         np.testing.assert_array_equal(bins, expect)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[5], CASES[7]], ids=lambda c: c.name)
+@pytest.mark.parametrize("case", [c for c in CASES if c.name in ("cfg1_sticky", "cfg1_uniform", "peaked", "tau09", "headline",
+                                                                  "vc_shape", "n144")], ids=lambda c: c.name)
 def test_consolidate_equals_per_chunk_forward(dev, case):
-    """The batched whole-video entry point must reproduce the per-chunk chain."""
+    """The batched whole-video entry point must reproduce the per-chunk chain (every golden case of one document with a
+    fixed chunk length, including the peaked, tau = 0.9 and N = 144 ones, where the fixed-point histogram of the fast
+    path and the fp32 partial sums of the per-call path are most likely to disagree by an index)."""
     ks, qs, ws = case_inputs(case)
     projs = [tuple(_to(dev, *w)) for w in ws]
     q = torch.from_numpy(np.stack(qs)).to(dev)
-    Cn = len(case.chunk_T)
+    Cn = next((i for i, t in enumerate(case.chunk_T) if t != case.chunk_T[0]), len(case.chunk_T))   # leading chunks of one length
+    ks = ks[:Cn]
     u = np.stack([np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)]) for c in range(Cn)])
     ud = torch.from_numpy(u).to(dev)
     a = _engine(case, dev)

@@ -33,6 +33,9 @@ class OracleEngine:
                 out[c, l] = self.layers[l].step(k[c].numpy(), q[l].numpy(), new_doc=(new_doc and c == 0), u=u[c, l].numpy())
         return torch.from_numpy(out)
 
+    def sync(self):
+        pass
+
     def export_state(self, l):
         o = self.layers[l]
         return torch.from_numpy(o.B_past), torch.from_numpy(o.sticky_p_raw(o.S_prev).astype(np.float32))

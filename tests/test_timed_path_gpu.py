@@ -1,0 +1,199 @@
+"""Parity of the code path ``bench.py`` times: ``infv_ltm_consolidate`` at the BASELINE headline shape
+(T=256, P=32, d=768, N=256, 2 layers, Q=32) with the default sub-batches (42 chunks for calls of >= 768 chunks,
+28 below), the large-M projection GEMMs and the persistent chain kernel -- against the per-chunk ``forward``
+chain (the per-stage kernels, which the golden tests pin to the reference) and, for its first chunks, against
+the reference goldens.  Needs a real MI355X: run with ``-m gpu``.
+
+The two paths compute the sticky probabilities with different (equally valid) fp32 association, so over
+millions of draws a uniform eventually lands within rounding of a cdf edge and the free-running chains would
+part there ("bit-exact index draw").  The comparison is therefore made draw by draw: the
+consolidate call records every chunk's probabilities and bins (``infv_ltm_set_trace``), the per-chunk chain
+resamples the SAME bins (``infv_ltm_set_bins``) while still deriving its own probabilities and its own draw;
+those must agree to rounding and in all but a counted handful of draws.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltm_oracle as O
+from tests.golden.cases import CASES, call_uniforms, case_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CTX_TOL = 1e-4
+B_TOL = 2e-5
+N, H, DH, D, P, T, Q, L, S = 256, 12, 64, 768, 32, 256, 32, 2, 512
+DM = H * DH
+HEADLINE = next(c for c in CASES if c.name == "headline")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _engine(dev, **kw):
+    from infinite_video_amd.engine import LTMEngine
+    return LTMEngine(N, H, DH, D, P, tau=0.75, sticky=True, n_layers=L, max_q=Q, device=dev, **kw)
+
+
+def _video(dev, n_chunks):
+    """Chunks 0-2 are the inputs of the ``headline`` golden case (same tokens, weights, queries, Gibbs uniforms);
+    the rest is generated on the device."""
+    from infinite_video_amd import synth
+    ks, qs, ws = case_inputs(HEADLINE)
+    projs = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in w) for w in ws]
+    q = torch.from_numpy(np.stack(qs)).to(dev)
+    k = torch.empty(n_chunks, T * P, D, device=dev, dtype=torch.float32)
+    gen = torch.Generator(device=dev).manual_seed(20260)
+    for i in range(0, n_chunks, 64):
+        k[i:i + 64].normal_(generator=gen)
+    u = synth.gibbs_uniforms(n_chunks, L, seed=20261)
+    for c in range(min(3, n_chunks)):
+        k[c] = torch.from_numpy(ks[c]).to(dev)
+        for l in range(L):
+            u[c, l] = call_uniforms(HEADLINE, c, l)
+    return k, q, projs, torch.from_numpy(u).to(dev), ws, qs
+
+
+def _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, flip_budget):
+    """Per-chunk forward chain with the consolidate call's bins forced; returns (reference engine, flips)."""
+    Cn = k.shape[0]
+    ref = _engine(dev)
+    bins_host = bins_all.cpu().numpy()
+    probs_host = probs_all.cpu().numpy()
+    worst = torch.zeros((), device=dev)
+    flips = 0
+    worst_p = 0.0
+    for c in range(Cn):
+        if c > 0:
+            for l in range(L):
+                ref.set_bins(l, bins_host[c, l])
+        y = ref.forward(k[c], q, projs, u[c], new_doc=(c == 0))
+        worst = torch.maximum(worst, (y - ctx[c]).abs().max())
+        if c > 0:
+            for l in range(L):
+                own_bins, idx, own_probs = ref.last_draw(l)
+                np.testing.assert_array_equal(idx, 2 * bins_host[c, l])     # left edge of bin b lies in box 2b (N = 256)
+                d = own_bins != bins_host[c, l]
+                flips += int(d.sum())
+                assert np.abs(own_bins[d] - bins_host[c, l][d]).max(initial=0) <= 1, "a differing draw is not an adjacent bin"
+                worst_p = max(worst_p, float(np.abs(own_probs / probs_host[c, l, :127] - 1).max()))
+    assert float(worst) <= CTX_TOL, f"max |ctx(consolidate) - ctx(per-chunk chain)| = {float(worst):.3e}"
+    assert worst_p <= 2e-5, f"sticky probabilities of the two paths differ by {worst_p:.2e} relative"
+    assert flips <= flip_budget, f"{flips} of {(Cn - 1) * L * S} draws differ between the two paths"
+    for l in range(L):
+        np.testing.assert_allclose(fast.export_state(l)[0].cpu().numpy(), ref.export_state(l)[0].cpu().numpy(),
+                                   rtol=0, atol=B_TOL)
+        # the per-chunk path's last own draw against the consolidate call's diagnostics of its last step
+        np.testing.assert_array_equal(fast.last_draw(l)[0], bins_host[Cn - 1, l])
+        np.testing.assert_allclose(fast.last_scores(l, Q), ref.last_scores(l, Q), rtol=1e-4, atol=2e-5)
+    return ref, flips
+
+
+@pytest.mark.parametrize("n_chunks", [64, 256, 2048])
+def test_bench_call_matches_per_chunk_chain(dev, n_chunks):
+    """64 chunks: two 28-chunk sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
+    shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call."""
+    k, q, projs, u, ws, qs = _video(dev, n_chunks)
+    fast = _engine(dev, max_batch_chunks=42)
+    bins_all, probs_all = fast.set_trace(n_chunks)
+    ctx = fast.consolidate(k, q, projs, u, new_doc=True)
+    fast.sync()
+    fast.set_trace(0)
+    assert bool(torch.isfinite(ctx).all())
+    assert int((bins_all[1:] < 0).sum()) == 0 and int((bins_all[0] >= 0).sum()) == 0   # every chunk but the first drew
+    # reproducible run to run (fixed-point histogram: no order dependence)
+    again = fast.consolidate(k, q, projs, u, new_doc=True)
+    assert torch.equal(again, ctx)
+    # chunks 0-2 are the reference's own run of the headline golden case
+    g = load_golden(HEADLINE)
+    for c in range(3):
+        for l in range(L):
+            np.testing.assert_allclose(ctx[c, l].cpu().numpy(), g[f"c{c}_l{l}_ctx"], rtol=0, atol=CTX_TOL)
+            if c > 0:
+                np.testing.assert_array_equal(bins_all[c, l].cpu().numpy(), g[f"c{c}_l{l}_bins"])
+                np.testing.assert_allclose(probs_all[c, l, :127].cpu().numpy(), g[f"c{c}_l{l}_probs"], rtol=2e-5, atol=1e-9)
+    budget = max(4, int(4e-5 * n_chunks * L * S))
+    ref, flips = _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, budget)
+    print(f"[timed path] {n_chunks} chunks: {flips} of {(n_chunks - 1) * L * S} draws differ between consolidate and the per-chunk chain")
+    # oracle on chunk 1 of layer 0 (one CPU step at this shape costs ~1 s)
+    orc = O.ClosedFormOracle(N, H, DH, 0.75, True, *ws[0], tokens_per_frame=P)
+    kc, uc = k[:2].cpu().numpy(), u[:2].cpu().numpy()
+    for c in range(2):
+        out = orc.step(kc[c], qs[0], new_doc=(c == 0), u=uc[c, 0])
+        np.testing.assert_allclose(ctx[c, 0].cpu().numpy(), out, rtol=0, atol=CTX_TOL)
+
+
+def test_split_bf16_value_projection_stays_inside_tolerance(dev, monkeypatch):
+    """INFV_VPROJ_SPLIT=1 (off by default): the V' half of a sub-batch's projection as three bf16 MFMA products.
+    Same draws (the score half stays exact fp32), read-out within the 1e-4 gate of the exact-fp32 run."""
+    k, q, projs, u, _, _ = _video(dev, 64)
+    exact = _engine(dev, max_batch_chunks=42)
+    be, _ = exact.set_trace(64)
+    ctx_e = exact.consolidate(k, q, projs, u, new_doc=True)
+    monkeypatch.setenv("INFV_VPROJ_SPLIT", "1")
+    split = _engine(dev, max_batch_chunks=42)
+    monkeypatch.delenv("INFV_VPROJ_SPLIT")
+    bs, _ = split.set_trace(64)
+    ctx_s = split.consolidate(k, q, projs, u, new_doc=True)
+    split.sync()
+    assert torch.equal(be, bs)
+    err = float((ctx_e - ctx_s).abs().max())
+    assert 0.0 < err <= CTX_TOL, err            # > 0: the split path really ran
+    for l in range(L):
+        np.testing.assert_array_equal(exact.export_state(l)[0].cpu().numpy(), split.export_state(l)[0].cpu().numpy())
+
+
+def test_chain_timeout_is_reported_not_swallowed(dev, monkeypatch):
+    """Fault injection: the persistent chain kernel is told to expect one arrival more than its workgroups can deliver,
+    so every wait times out.  The failure must surface as INFV_ERR_STATE at sync() (and at the next entry point),
+    once, and a fresh engine must be unaffected."""
+    from infinite_video_amd import _lib
+    k, q, projs, u, _, _ = _video(dev, 8)
+    monkeypatch.setenv("INFV_CHAIN_FAULT", "1")
+    bad = _engine(dev, max_batch_chunks=4)
+    monkeypatch.delenv("INFV_CHAIN_FAULT")
+    bad.consolidate(k, q, projs, u, new_doc=True)
+    with pytest.raises(_lib.LTMError) as ei:
+        bad.sync()
+    assert ei.value.code == -4 and "timed out" in str(ei.value)
+    assert not bad.has_memory                                   # the invalid memory was dropped
+    bad.sync()                                                  # reported once
+    bad.consolidate(k, q, projs, u, new_doc=True)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.LTMError):                          # ... and caught by whatever entry point comes next
+        bad.export_state(0)
+    good = _engine(dev, max_batch_chunks=4)
+    ctx = good.consolidate(k, q, projs, u, new_doc=True)
+    good.sync()
+    assert bool(torch.isfinite(ctx).all())
+
+
+def test_consolidate_video_through_rccl_world_of_one(dev):
+    """The multi-GPU entry point with an initialised "nccl" (= RCCL) group of one rank: the all-gather branch runs on
+    the device and returns this rank's own memory."""
+    import socket
+    import torch.distributed as dist
+    from infinite_video_amd.video_memory import consolidate_video
+    k, q, projs, u, _, _ = _video(dev, 6)
+    eng = _engine(dev, max_batch_chunks=4)
+    ctx0, mem0 = consolidate_video(eng, k, q, projs, u)         # no group: no collective
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        ctx1, mem1 = consolidate_video(eng, k, q, projs, u)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(ctx0, ctx1)
+    assert mem1.B.shape == (1, L, N, D) and float(mem1.count[0]) == 6.0
+    assert torch.equal(mem0.B, mem1.B) and torch.equal(mem0.bin_mass, mem1.bin_mass)
+    torch.testing.assert_close(mem1.mean_embedding(), ctx1.mean(0), rtol=1e-5, atol=1e-6)
