@@ -64,8 +64,10 @@ struct Plan {
     DeviceBuf w, edge_box, edge_dx, bin_box, uniform_idx;
     float w_out = 0.f;
     int n_bins = 0;
+    bool points_ok = false;            // the histogram edges are the bins' left edges (what chain_batch2_kernel assumes)
     StickyView sticky() const {
         StickyView s;
+        s.points_ok = points_ok ? 1 : 0;
         s.n_bins = n_bins;
         s.edge_box = edge_box.as<int32_t>();
         s.edge_dx = edge_dx.as<float>();
@@ -129,6 +131,7 @@ struct infv_ltm_s {
     DeviceBuf Sp[2], cqbuf;
     DeviceBuf qt_buf;                  // fast path: pre-multiplied queries qt[(l*H+h)*Q+q][d] of the current call
     DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
+    DeviceBuf crit_ring, tabb_ring;              // chain_batch2_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
@@ -348,7 +351,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
     }
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
+        e = h->mass_acc[i].reserve((size_t)h->L * 128 * kAccStride * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
     if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
@@ -400,6 +403,11 @@ int infv_ltm_set_plan(infv_ltm_handle h, const infv_ltm_plan* p) {
         if (p->uniform_idx[s] < -1 || p->uniform_idx[s] >= h->N) { delete plan; return fail(INFV_ERR_INVALID, "plan: uniform_idx out of range"); }
     plan->w_out = p->readout_w_out;
     plan->n_bins = p->n_bins;
+    plan->points_ok = p->edge_box[0] == -1 && p->edge_box[p->n_bins] == -1;
+    for (int j = 0; j < p->n_bins; ++j) {
+        if (p->bin_box[j] < 0) plan->points_ok = false;
+        if (j > 0 && p->edge_box[j] != p->bin_box[j]) plan->points_ok = false;
+    }
     hipError_t e = upload(plan->w, p->readout_w, h->N);
     if (e == hipSuccess) e = upload(plan->edge_box, p->edge_box, p->n_bins + 1);
     if (e == hipSuccess) e = upload(plan->edge_dx, p->edge_dx, p->n_bins);
@@ -484,6 +492,9 @@ struct FastPipe {
     size_t alpha_slot() const { return (size_t)h->L * h->H * Q * h->N; }
     size_t asum_slot() const { return (size_t)h->L * h->H * Q; }
     size_t tab_slot() const { return (size_t)h->L * h->N * 16; }
+    size_t crit_slot() const { return (size_t)h->L * h->H * Q * 128; }
+    bool last_v2 = false;            // the last persistent launch ran chain_batch2_kernel (scores rebuilt by alpha_rows2)
+    const float* last_snew = nullptr; int last_sk = 1; long last_ss = 0; float* last_sp_out = nullptr; int batch_launches = 0;
 
     int launch_s(const StepS& st) {
         ChainArgs a;
@@ -564,6 +575,7 @@ struct FastPipe {
         for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
         b.arrive = h->sync_words.as<unsigned int>(); b.error = h->err_dev;
         b.spin_limit = h->spin_limit; b.expect_extra = h->expect_extra;
+        { static const int fl = [] { const char* e = getenv("INFV_S_FLAGS"); return e ? atoi(e) : 0; }(); b.exp_flags = fl; }
         if (h->trace_cap > counter) {
             b.trace_steps = (int)((h->trace_cap - counter < n) ? h->trace_cap - counter : n);
             b.probs_tr = h->trace_probs ? h->trace_probs + (size_t)counter * h->L * h->n_bins : nullptr;
@@ -573,6 +585,9 @@ struct FastPipe {
         b.u = u; b.uniform_idx = plan.uniform_idx.as<int32_t>();
         b.probs_out = h->probs.as<float>(); b.bins_out = h->bins.as<int32_t>(); b.idx_out = h->idx.as<int32_t>();
         b.tab_ring = h->tab_ring.as<int32_t>(); b.tab_slot = (long)tab_slot();
+        b.tabb_ring = h->tabb_ring.as<int32_t>();
+        b.crit_ring = h->crit_ring.as<float>(); b.crit_slot = (long)crit_slot();
+        b.publish_init = (batch_launches == 0) ? 1 : 0;
         b.alpha_ring = h->alpha_ring.as<float>(); b.alpha_slot = (long)alpha_slot();
         b.asum_ring = h->asum_ring.as<float>(); b.asum_slot = (long)asum_slot();
         b.Sp_in = h->Sp[h->sc].as<float>(); b.Sp_out = h->Sp[h->sc ^ 1].as<float>();
@@ -597,6 +612,9 @@ struct FastPipe {
             Timed t_(h->prof, INFV_KERNEL_CHAIN, stream);
             if (!(skip_mask() & 8)) HIP_TRY(launch_chain_batch(b, stream));
         }
+        last_v2 = chain_batch2_applies(b);
+        last_snew = Snew; last_sk = sk; last_ss = ss; last_sp_out = b.Sp_out;
+        ++batch_launches;
         if (b.draw_mode == 1) h->override_mask = 0;
         h->sc ^= 1;
         h->lastQ = Q;
@@ -606,8 +624,25 @@ struct FastPipe {
     }
 
     // the persistent role S leaves SCORES in the alpha ring: turn the `n` slots from slot0 into softmax weights + row sums
-    int launch_alpha(int n, long slot0, hipStream_t s) {
+    int launch_alpha(int n, long slot0, hipStream_t s, bool last_batch) {
         if (skip_mask() & 4) return INFV_OK;
+        if (last_v2) {
+            // chain_batch2_kernel published point scores + drawn bins: rebuild the full score rows, then the weights
+            AlphaRows2Args r;
+            memset(&r, 0, sizeof(r));
+            r.N = h->N; r.H = h->H; r.Q = Q; r.L = h->L; r.rows = plan.inf.rows; r.tabw = plan.inf.tabw; r.n_steps = n;
+            r.slot0 = slot0 % h->ring; r.ring = h->ring;
+            r.crit_ring = h->crit_ring.as<float>(); r.crit_slot = (long)crit_slot();
+            r.tabb_ring = h->tabb_ring.as<int32_t>(); r.tab_slot = (long)tab_slot();
+            r.Snew = last_snew; r.snew_ld = h->L * h->dm + h->L * h->H * Q; r.snew_splitk = last_sk; r.snew_split_stride = last_ss;
+            r.cq = h->cqbuf.as<float>(); r.w = plan.w.as<float>(); r.w_out = plan.w_out;
+            r.box_val = plan.inf.box_val.as<float>(); r.box_row = plan.inf.box_row.as<int32_t>();
+            r.alpha_ring = h->alpha_ring.as<float>(); r.alpha_slot = (long)alpha_slot();
+            r.asum_ring = h->asum_ring.as<float>(); r.asum_slot = (long)asum_slot();
+            r.Sp_out = last_batch ? last_sp_out : nullptr;
+            HIP_TRY(launch_alpha_rows2(r, s));
+            return INFV_OK;
+        }
         HIP_TRY(launch_alpha_rows(h->alpha_ring.as<float>(), (long)alpha_slot(), h->asum_ring.as<float>(), (long)asum_slot(),
                                   slot0 % h->ring, h->ring, n, h->L * h->H * Q, h->N, plan.w.as<float>(), plan.w_out, s));
         return INFV_OK;
@@ -779,10 +814,12 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         return INFV_OK;
     }
     if (int rc = ensure_side_stream(h)) return rc;
-    // Padding LDS caps the side-stream kernels' occupancy: ONE 512-thread pool workgroup (88 KB) or ONE GEMM
-    // workgroup (36 + 90 KB) per CU, so a role-S workgroup always finds LDS and wave slots.
+    // Padding LDS caps the pooling kernel's occupancy at ONE 512-thread workgroup (88 KB) per CU, so a role-S workgroup
+    // always finds LDS and wave slots and the pool's bytes in flight stay bounded.  The GEMMs carry no padding any more
+    // (INFV_GEMM_PAD): their workgroups (36 KB, one wave per SIMD) co-reside with a pooling workgroup -- MFMA work beside
+    // memory work -- instead of taking the CU away from it.
     static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
-    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 90 * 1024; }();
+    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
@@ -793,6 +830,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
             HIP_TRY(h->alpha_ring.reserve(need_a));
             HIP_TRY(h->asum_ring.reserve((size_t)h->ring * pipe.asum_slot() * sizeof(float)));
             HIP_TRY(h->tab_ring.reserve((size_t)h->ring * pipe.tab_slot() * sizeof(int32_t)));
+            HIP_TRY(h->tabb_ring.reserve((size_t)h->ring * pipe.tab_slot() * sizeof(int32_t)));
+            HIP_TRY(h->crit_ring.reserve((size_t)h->ring * pipe.crit_slot() * sizeof(float)));
         }
     }
     hipStream_t side = h->side, ucs = h->ucs;
@@ -847,10 +886,11 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         *c0 = first_c + b * sub;
         *nb = (n_chunks - *c0 < sub) ? n_chunks - *c0 : sub;
     };
-    // INFV_SPLIT_POOL=1 puts the pooling on its own stream so that the HBM-bound pooling of batch b+2 overlaps the
-    // MFMA-bound projection of batch b+1 (pooled frames are triple-buffered either way).  Measured: WORSE (87 k vs
-    // 95 k chunks/s) -- four concurrent kernels slow each other and role S more than the overlap gains; default off.
-    static const bool split_pool = [] { const char* e = getenv("INFV_SPLIT_POOL"); return e && atoi(e) != 0; }();
+    // The pooling has its own stream so that the HBM-bound pooling of batch b+2 overlaps the MFMA-bound projection of
+    // batch b+1 (pooled frames are triple-buffered either way); INFV_SPLIT_POOL=0 puts it back on the side stream.
+    // (Round 1 measured this worse, 87 k vs 95 k chunks/s, because role S was then sensitive to every concurrent
+    // kernel; with chain_batch2_kernel and no padding LDS on the GEMMs it is better: 112 k vs 102 k.)
+    static const bool split_pool = [] { const char* e = getenv("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
     {
@@ -967,7 +1007,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
         if (vs != ucs) HIP_TRY(hipStreamWaitEvent(vs, h->ev_s[set], 0));
         if (persistent)
-            if (int rc = pipe.launch_alpha(nb, slot0, vs)) return rc;
+            if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
         if (vs != ucs) {
             HIP_TRY(hipEventRecord(h->ev_aux[set], vs));
             HIP_TRY(hipStreamWaitEvent(ucs, h->ev_aux[set], 0));

@@ -135,9 +135,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     const int ring_n = (int)a.ring;
     for (int i = 0; i < a.n_steps; ++i) {
         BSTAMP(0);
-        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;      // (g + 2) % 3
-        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
-        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;      // (g + 1) % 3
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;      // (g + 2) % 3
+        unsigned long long* acc_cur = a.acc[g3] + l * kBins * kAccStride;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins * kAccStride;      // (g + 1) % 3
         const long slot = slot_run;
         if (++g3 == 3) g3 = 0;
         if (++slot_run == ring_n) slot_run = 0;
@@ -151,20 +151,20 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         double mass_prev = 0.0;
         const bool steady = a.draw_mode == 1 && !((i == 0) && (((a.override_mask >> l) & 1u) || a.first_from_parts));
         if (steady && tid < kBins - 1) {
-            unsigned long long v = coherent_read(acc_prev + tid);
+            unsigned long long v = coherent_read(acc_prev + tid * kAccStride);
             if (i > 0) {
                 int spins = 0;
                 while ((v >> kArriveShift) < (unsigned long long)(blocks_per_layer + a.expect_extra)) {
                     __builtin_amdgcn_s_sleep(1);
                     // give up loudly: the word lives in host-visible memory, every later call on the handle reports it
                     if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                    v = coherent_read(acc_prev + tid);
+                    v = coherent_read(acc_prev + tid * kAccStride);
                 }
             }
             mass_prev = mass_of(v);
         }
         BSTAMP(1);
-        if (writer && tid < kBins) atomicExch(acc_clr + tid, 0ull);      // slot of the NEXT step: idle until then
+        if (writer && tid < kBins) atomicExch(acc_clr + tid * kAccStride, 0ull);      // slot of the NEXT step: idle until then
         // ---- draw ----
         if (a.draw_mode == 1) {
             const bool ovr = (i == 0) && ((a.override_mask >> l) & 1u);
@@ -267,6 +267,511 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     }
 }
 
+// ======================================================================================================
+// chain_batch2_kernel: the same role S with only the truly sequential work on the chain.
+//
+// A step's draw needs the bin masses of the previous step, which need the scores at the 127 interior edges
+// of the sticky histogram, which are the scores of the boxes holding the bins' left edges -- the same boxes the
+// resampling reads (LTM.py:207-208: ts = bins[b]).  So the recurrence only ever feeds back through the 128
+// "points" j = 0..127 (left edge of bin j, box pb[j] = bin_box[j]); every other box is a pure output, rebuilt
+// later, chunk-parallel, by alpha_rows2_kernel from what this kernel publishes per step: the point scores and the
+// table of drawn bins.  Eight waves, wave r owns query row r.  Per step:
+//   wave 0      poll the previous totals (the poll is issued right behind this workgroup's own deposit, one step
+//               earlier), normalise, sequential fp32 cdf (systolic DPP scan)                      -> barrier 1
+//   all waves   one lower-bound search per thread (fp32 compares against the round-up of the f64 uniform:
+//               equivalent to the f64 compare), result written straight into the gather table;
+//               wave 7 also parks the NEXT step's inputs (new-row scores, uniforms), loaded two steps ago -> barrier 2
+//   wave = row  recurrence of the row's 128 point scores (2 per lane, state private to the wave), edge densities,
+//               trapezoid masses: all in registers, neighbours through DPP shifts                    -> barrier 3
+//   tid < 127   8-row sum, fixed-point deposit (+ arrival count); wave 0 re-arms its poll and goes round
+//   waves 1-6   publish the step (point scores of all 8 rows; the layer's writer: drawn-bin table, source-box table)
+//   wave 7      requests the inputs of step i+3.
+// vmcnt counts loads, stores and atomics in issue order, so a wave that waits for a load also waits for the
+// acknowledgement of every store it issued before -- hence the split: the poller issues no store between arming and
+// reading its poll, the storing waves load nothing, the loading wave stores nothing.  While a streaming kernel shares
+// the CU every vector-memory INSTRUCTION also queues ~0.2 us at issue: each role issues a handful per step.
+// Requires the plan's edges to be the bins' left edges (StickyView.points_ok), the sticky draw (mode 1), rows <= 128.
+// ======================================================================================================
+constexpr int kB2Ld = 4;                  // float4 pieces of the new-row score tile the loader holds per lane (2 * rows <= 64 * kB2Ld)
+struct Batch2Smem { int cdf, coarse, pos, tabb, box_val, box_row, pb, sc0, sc1, Snew, uf, Msm, total; };
+constexpr int kScPitch = kBins + 4;
+
+__host__ __device__ inline Batch2Smem batch2_smem(int N, int S, int rows, int tabw) {
+    Batch2Smem m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.cdf = take(kBins);
+    m.coarse = take(16);
+    m.pos = take(S);
+    m.tabb = take(N * tabw);
+    m.box_val = take(N);
+    m.box_row = take(N);
+    m.pb = take(kBins);
+    m.sc0 = take(kBRows * kScPitch);
+    m.sc1 = take(kBRows * kScPitch);
+    m.Snew = take(2 * kBRows * (rows + 1));
+    m.uf = take(2 * S);
+    m.Msm = take(kBRows * kMPitch);
+    m.total = o;
+    return m;
+}
+
+// lane i <- lane i+1; lane 63 <- fill
+__device__ inline float wave_shl1(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (!(a.exp_flags & 1)) __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
+    const int rows = a.op.rows, tabw = a.op.tabw;
+    const Batch2Smem m = batch2_smem(N, a.S, rows, tabw);
+    const int b = blockIdx.x;
+    const int h = b % H, qs = (b / H) % QS, l = b / (H * QS);
+    const int blocks_per_layer = H * QS;
+    const int sn = rows + 1, sn_tile = kBRows * sn;
+    float* cdf = lds + m.cdf;
+    float* coarse = lds + m.coarse;
+    int32_t* tabb = reinterpret_cast<int32_t*>(lds + m.tabb);          // bin of the k-th resampled slot of box n, -1 = none
+    int32_t* pb = reinterpret_cast<int32_t*>(lds + m.pb);
+    const float* box_val = lds + m.box_val;
+    const int32_t* box_row = reinterpret_cast<const int32_t*>(lds + m.box_row);
+    float* Msm = lds + m.Msm;
+    const long tile = (((long)l * H + h) * Q + qs * kBRows);
+    const int valid = min(kBRows, Q - qs * kBRows);
+    const bool writer = (h == 0 && qs == 0);
+    const bool loader = wave == kBRows - 1;
+    const long tile_snew = (long)rows * a.snew_ld;
+
+    // ---- one-time set-up ----
+    {
+        int32_t* pos = reinterpret_cast<int32_t*>(lds + m.pos);
+        if (tid < N) {
+            (lds + m.box_val)[tid] = a.op.box_val[tid];
+            reinterpret_cast<int32_t*>(lds + m.box_row)[tid] = a.op.box_row[tid];
+        }
+        if (tid < kBins) pb[tid] = a.st.bin_box[tid];
+        if (tid < a.S) pos[tid] = -1;
+        __syncthreads();
+        for (int e = tid; e < N * tabw; e += kBNT) {
+            const int sl = a.op.slot_tab[e];
+            tabb[e] = -1;
+            if (sl >= 0) pos[sl] = e;
+        }
+        __syncthreads();
+    }
+    const int my_pos = (tid < a.S) ? reinterpret_cast<const int32_t*>(lds + m.pos)[tid] : -1;
+    const bool row_ok = wave < valid;
+    float* scc = lds + m.sc0 + wave * kScPitch;                        // this wave's row of point scores (bias-free), current
+    float* scn = lds + m.sc1 + wave * kScPitch;                        // ... and next
+    // the two points of this lane: boxes, operator entries, edge validity and spacings (static)
+    const int n0 = pb[lane], n1 = pb[lane + 64];
+    const float val0 = box_val[n0], val1 = box_val[n1];
+    const int br0 = box_row[n0], br1 = box_row[n1];
+    const bool e0ok = a.st.edge_box[lane] >= 0, e1ok = a.st.edge_box[lane + 64] >= 0;     // edge 0 lies left of every box
+    const float dx0 = a.st.edge_dx[lane], dx1 = a.st.edge_dx[lane + 64];
+    const float dxa = a.st.edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? a.st.edge_dx[lane + 65] : 0.f;
+    const float cqr = row_ok ? a.cq[tile + wave] : 0.f;
+    {
+        const float i0 = row_ok ? a.Sp_in[(tile + wave) * N + n0] : 0.f;
+        const float i1 = row_ok ? a.Sp_in[(tile + wave) * N + n1] : 0.f;
+        scc[lane] = i0;
+        scc[lane + 64] = i1;
+        if (a.publish_init && row_ok) {
+            // first launch of a call: the state before its first step, for the rows alpha_rows2_kernel rebuilds of that step
+            const long prev = (a.step0 % a.ring == 0) ? a.ring - 1 : a.step0 % a.ring - 1;
+            float* cr = a.crit_ring + prev * a.crit_slot + (tile + wave) * kBins;
+            cr[lane] = i0;
+            cr[lane + 64] = i1;
+        }
+    }
+
+    // ---- loader (wave 7): the S'new tile and the uniforms of a step in registers, two sets (steps in flight: i+1, i+2).
+    // Wide loads only.   S'new tile: new row nr holds this tile's 8 scores contiguously -> float4 e4 = lane + 64 k:
+    // row e4 >> 1, half e4 & 1;   uniforms: S float64 -> double2 per lane
+    struct LdSet { floatx4 sn[kB2Ld]; double2 u[4]; };
+    LdSet ldA, ldB;
+    auto ld_request = [&](int i, LdSet& r) {
+        const float* sb = a.Snew + (long)i * tile_snew + tile;
+#pragma unroll
+        for (int k = 0; k < kB2Ld; ++k) {
+            const int e4 = lane + 64 * k;
+            const int nr = e4 >> 1, hf = e4 & 1;
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nr < rows && 4 * hf < valid) {
+                const float* src = sb + (long)nr * a.snew_ld + 4 * hf;
+                v = *reinterpret_cast<const floatx4*>(src);
+                for (int x = 1; x < a.snew_splitk; ++x) v += *reinterpret_cast<const floatx4*>(src + x * a.snew_split_stride);
+            }
+            r.sn[k] = v;
+        }
+        const double2* ub = reinterpret_cast<const double2*>(a.u + ((long)i * a.L + l) * a.S);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s2 = lane + 64 * k;
+            r.u[k] = (2 * s2 < a.S) ? ub[s2] : make_double2(2.0, 2.0);
+        }
+    };
+    auto round_up = [](double u) {
+        // (double)c < u  <=>  c < uf for every float c, with uf = the smallest float >= u
+        float f = (float)u;
+        if ((double)f < u) f = __int_as_float(__float_as_int(f) + 1);
+        return f;
+    };
+    auto ld_park = [&](int i, const LdSet& r) {                         // into the tiles of parity i & 1
+        float* st = lds + m.Snew + (i & 1) * sn_tile;
+        float* uf = lds + m.uf + (i & 1) * a.S;
+#pragma unroll
+        for (int k = 0; k < kB2Ld; ++k) {
+            const int e4 = lane + 64 * k;
+            const int nr = e4 >> 1, hf = e4 & 1;
+            if (nr < rows) {
+                st[(4 * hf + 0) * sn + nr] = r.sn[k].x; st[(4 * hf + 1) * sn + nr] = r.sn[k].y;
+                st[(4 * hf + 2) * sn + nr] = r.sn[k].z; st[(4 * hf + 3) * sn + nr] = r.sn[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s2 = lane + 64 * k;
+            if (2 * s2 < a.S) { uf[2 * s2] = round_up(r.u[k].x); uf[2 * s2 + 1] = round_up(r.u[k].y); }
+        }
+    };
+    if (loader) {
+        ld_request(0, ldA);
+        ld_park(0, ldA);
+        if (a.n_steps > 1) ld_request(1, ldB);                         // odd steps live in set B, even steps in set A
+        if (a.n_steps > 2) ld_request(2, ldA);
+    }
+
+    int g3 = (int)(a.step0 % 3), slot_run = (int)(a.step0 % a.ring);
+    const int ring_n = (int)a.ring;
+    const unsigned long long need_full = (unsigned long long)(blocks_per_layer + a.expect_extra);
+    // wave 0: totals of the previous step, polled one step ahead (lane j: bins j and j+64)
+    unsigned long long pv0 = 0ull, pv1 = 0ull;
+    const bool ovr0 = ((a.override_mask >> l) & 1u) != 0;
+    const bool special0 = ovr0 || a.first_from_parts;                 // step 0 takes its probabilities from elsewhere
+    if (wave == 0 && !special0) {
+        unsigned long long* ap = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;
+        pv0 = coherent_read(ap + lane * kAccStride);
+        pv1 = (lane + 64 < kBins - 1) ? coherent_read(ap + (lane + 64) * kAccStride) : 0ull;
+    }
+    __syncthreads();
+
+#define B2STAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
+    for (int i = 0; i < a.n_steps; ++i) {
+        B2STAMP(0);
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;
+        unsigned long long* acc_cur = a.acc[g3] + l * kBins * kAccStride;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins * kAccStride;
+        const long slot = slot_run;
+        if (++g3 == 3) g3 = 0;
+        if (++slot_run == ring_n) slot_run = 0;
+        const bool last = (i == a.n_steps - 1);
+        const float* Snew = lds + m.Snew + (i & 1) * sn_tile;
+        // ---- wave 0: probabilities -> cdf ----
+        if (wave == 0) {
+            constexpr int nb = kBins - 1;
+            const int j1 = lane + 64;
+            float p0, p1;
+            if (i == 0 && ovr0) {
+                p0 = a.probs_override[l * kBins + lane];
+                p1 = (j1 < nb) ? a.probs_override[l * kBins + j1] : 0.f;
+            } else {
+                double a0 = 0.0, a1 = 0.0;
+                if (i == 0 && a.first_from_parts) {
+                    for (int p = 0; p < a.parts; ++p) {
+                        a0 += (double)a.part_prev[((long)l * a.parts + p) * kBins + lane];
+                        if (j1 < nb) a1 += (double)a.part_prev[((long)l * a.parts + p) * kBins + j1];
+                    }
+                } else {
+                    // the poll was issued one step ago; step 0 reads totals completed by an earlier launch (no count)
+                    const unsigned long long need = (i > 0 && !(a.exp_flags & 16)) ? need_full : 0ull;
+                    int spins = 0;
+                    while ((pv0 >> kArriveShift) < need || (j1 < nb && (pv1 >> kArriveShift) < need)) {
+                        if (a.exp_flags & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        pv0 = coherent_read(acc_prev + lane * kAccStride);
+                        if (j1 < nb) pv1 = coherent_read(acc_prev + j1 * kAccStride);
+                    }
+                    a0 = mass_of(pv0);
+                    a1 = (j1 < nb) ? mass_of(pv1) : 0.0;
+                }
+                const float raw0 = (float)a0;
+                const float raw1 = (j1 < nb) ? (float)a1 : 0.f;
+                const float tot1 = (float)wave_sum_f64((double)raw0 + (double)raw1);
+                const float q0 = raw0 / tot1, q1 = raw1 / tot1;                       // LTM.py:203
+                const float tot2 = (float)wave_sum_f64((double)q0 + (double)q1);
+                p0 = q0 / tot2; p1 = q1 / tot2;                                       // Categorical's own normalisation
+            }
+            if (j1 >= nb) p1 = 0.f;
+            B2STAMP(1);
+            if (writer) {
+                if (last) { a.probs_out[l * kBins + lane] = p0; if (j1 < nb) a.probs_out[l * kBins + j1] = p1; }
+                if (a.probs_tr != nullptr && i < a.trace_steps) {
+                    float* pt = a.probs_tr + ((long)i * a.L + l) * kBins;
+                    pt[lane] = p0; if (j1 < nb) pt[j1] = p1;
+                }
+            }
+            // sequential fp32 running sum in bin order (torch.multinomial, CPU) as a systolic scan over the lanes
+            float c0 = p0;
+#pragma unroll
+            for (int t = 0; t < 63; ++t) c0 = dpp_f32<0x138>(c0) + p0;          // bins 0..63
+            const float carry = readlane_f32(c0, 63);
+            const float q1s = (lane == 0) ? carry + p1 : p1;                    // bin 64 continues the chain
+            float c1 = q1s;
+#pragma unroll
+            for (int t = 0; t < 62; ++t) c1 = dpp_f32<0x138>(c1) + q1s;         // bins 64..126 (lane 63: padding)
+            const float run = readlane_f32(c1, 62);
+            const float f0 = c0 / run;
+            const float f1 = (j1 < nb) ? ((j1 == nb - 1) ? 1.f : c1 / run) : 2.f;   // last bucket forced to 1; pad never below a uniform
+            cdf[lane] = f0;
+            cdf[j1] = f1;
+            if ((lane & 7) == 7) { coarse[lane >> 3] = f0; coarse[8 + (lane >> 3)] = f1; }
+        }
+        __syncthreads();                                                         // barrier 1
+        B2STAMP(2);
+        if (tid < a.S) {
+            // ---- lower bound of this thread's uniform in the cdf == number of entries below it ----
+            const float my_uf = (lds + m.uf + (i & 1) * a.S)[tid];
+            const floatx4* c4 = reinterpret_cast<const floatx4*>(coarse);
+            int grp = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const floatx4 f = c4[v];
+                grp += (f.x < my_uf) + (f.y < my_uf) + (f.z < my_uf) + (f.w < my_uf);
+            }
+            int lo = 8 * grp;
+            if (grp < 16) {
+                const floatx4 f0 = *reinterpret_cast<const floatx4*>(&cdf[8 * grp]);
+                const floatx4 f1 = *reinterpret_cast<const floatx4*>(&cdf[8 * grp + 4]);
+                lo += (f0.x < my_uf) + (f0.y < my_uf) + (f0.z < my_uf) + (f0.w < my_uf) +
+                      (f1.x < my_uf) + (f1.y < my_uf) + (f1.z < my_uf);
+            }
+            lo = min(lo, kBins - 2);
+            if (my_pos >= 0) tabb[my_pos] = lo;
+            if (writer && !loader) {
+                if (last) { a.bins_out[(long)l * a.S + tid] = lo; a.idx_out[(long)l * a.S + tid] = pb[lo]; }
+                if (a.bins_tr != nullptr && i < a.trace_steps) a.bins_tr[((long)i * a.L + l) * a.S + tid] = lo;
+            }
+            if (writer && loader) (lds + m.pos)[tid] = __int_as_float(lo);       // wave 7 stores nothing: wave 6 writes its 64 bins out
+        }
+        // the next step's inputs were requested two steps ago: park them (tiles of the other parity: their last readers,
+        // recurrence and search of step i-1, are behind barrier 3 of that step)
+        if (loader && !last) { if ((i + 1) & 1) ld_park(i + 1, ldB); else ld_park(i + 1, ldA); }
+        __syncthreads();                                                         // barrier 2
+        B2STAMP(3);
+        // ---- wave = row: recurrence of the 128 point scores, edge densities, bin masses (registers + DPP) ----
+        float acc0 = 0.f, acc1 = 0.f;
+        {
+            for (int k0 = 0; k0 < tabw; k0 += 4) {
+                const int4 s0 = *reinterpret_cast<const int4*>(&tabb[n0 * tabw + k0]);
+                const int4 s1 = *reinterpret_cast<const int4*>(&tabb[n1 * tabw + k0]);
+                const float v0 = scc[max(s0.x, 0)], v1 = scc[max(s0.y, 0)], v2 = scc[max(s0.z, 0)], v3 = scc[max(s0.w, 0)];
+                const float w0 = scc[max(s1.x, 0)], w1 = scc[max(s1.y, 0)], w2 = scc[max(s1.z, 0)], w3 = scc[max(s1.w, 0)];
+                if (s0.x >= 0) acc0 = fmaf(val0, v0, acc0);
+                if (s0.y >= 0) acc0 = fmaf(val0, v1, acc0);
+                if (s0.z >= 0) acc0 = fmaf(val0, v2, acc0);
+                if (s0.w >= 0) acc0 = fmaf(val0, v3, acc0);
+                if (s1.x >= 0) acc1 = fmaf(val1, w0, acc1);
+                if (s1.y >= 0) acc1 = fmaf(val1, w1, acc1);
+                if (s1.z >= 0) acc1 = fmaf(val1, w2, acc1);
+                if (s1.w >= 0) acc1 = fmaf(val1, w3, acc1);
+            }
+            if (br0 >= 0) acc0 += Snew[wave * sn + br0];
+            if (br1 >= 0) acc1 += Snew[wave * sn + br1];
+            scn[lane] = acc0;
+            scn[lane + 64] = acc1;
+            // densities at the 129 edges: edge j (1..127) sits in the box of point j, edges 0 and 128 in none (score 0)
+            const float s0 = e0ok ? acc0 + cqr : 0.f, s1 = e1ok ? acc1 + cqr : 0.f;
+            const float md = fmaxf(wave_max(fmaxf(e0ok ? s0 : -INFINITY, e1ok ? s1 : -INFINITY)), 0.f);
+            const float d0 = expf(s0 - md), d1 = expf(s1 - md);
+            const float d128 = expf(0.f - md);
+            const float d0n = wave_shl1(d0, readlane_f32(d1, 0));               // D[lane + 1]
+            const float d1n = wave_shl1(d1, d128);                              // D[lane + 65]
+            const float d0nn = wave_shl1(d0n, readlane_f32(d1, 1));             // D[lane + 2]
+            const float d1nn = wave_shl1(d1n, 0.f);                             // D[lane + 66]  (lane 63: unused)
+            const float z = wave_sum((d0 + d0n) * dx0 + (d1 + d1n) * dx1) * 0.5f;
+            const float inv_z = 1.0f / z;
+            // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
+            Msm[wave * kMPitch + lane] = row_ok ? ((d0n * inv_z + d0nn * inv_z) * dxa) * 0.5f : 0.f;
+            if (lane + 64 < kBins - 1) Msm[wave * kMPitch + lane + 64] = row_ok ? ((d1n * inv_z + d1nn * inv_z) * dxb) * 0.5f : 0.f;
+        }
+        __syncthreads();                                                         // barrier 3
+        B2STAMP(4);
+        if (tid < kBins - 1) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < kBRows; ++r) t += Msm[r * kMPitch + tid];
+            if (!(a.exp_flags & 16)) atomicAdd(&acc_cur[tid * kAccStride], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
+        }
+        if (loader) {
+            // request the inputs of step i+3 (set of its parity: parked during this step) in the shadow of wave 0's poll
+            if (i + 3 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 3) & 1) ld_request(i + 3, ldB); else ld_request(i + 3, ldA); }
+        } else if (wave == 0) {
+            // re-arm the poll right behind the deposit and go round: this wave issues nothing else until it has read it
+            if (!last && !(a.exp_flags & 16)) {
+                pv0 = coherent_read(acc_cur + lane * kAccStride);
+                pv1 = (lane + 64 < kBins - 1) ? coherent_read(acc_cur + (lane + 64) * kAccStride) : 0ull;
+            }
+            B2STAMP(5);
+        } else {
+            // ---- waves 1-6, stores only: publish the step for alpha_rows2_kernel / the UC kernel ----
+            if (writer) {
+                if (tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + (tid - 128) * kAccStride, 0ull);   // slot of the NEXT step: idle until then
+                int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;          // source BOX of every slot (UC kernel)
+                int32_t* tabb_out = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;        // drawn BIN of every slot
+                for (int e = tid - 64; e < N * tabw; e += kBNT - 128) {
+                    const int bb = tabb[e];
+                    tabb_out[e] = bb;
+                    tab_out[e] = (bb >= 0) ? pb[bb] : -1;
+                }
+                if (wave == 6 && a.S > 448) {                                                    // wave 7's share of the draw diagnostics
+                    const int s7 = 448 + lane;
+                    const int lo = __float_as_int((lds + m.pos)[s7]);
+                    if (s7 < a.S) {
+                        if (last) { a.bins_out[(long)l * a.S + s7] = lo; a.idx_out[(long)l * a.S + s7] = pb[lo]; }
+                        if (a.bins_tr != nullptr && i < a.trace_steps) a.bins_tr[((long)i * a.L + l) * a.S + s7] = lo;
+                    }
+                }
+            }
+            // point scores after this step: own row from registers; wave 1 also row 0, wave 6 also row 7 (from LDS)
+            float* cr = a.crit_ring + slot * a.crit_slot + tile * kBins;
+            if (row_ok && !(a.exp_flags & 4)) { cr[wave * kBins + lane] = acc0; cr[wave * kBins + lane + 64] = acc1; }
+            const int extra = (wave == 1) ? 0 : ((wave == 6) ? kBRows - 1 : -1);
+            if (extra >= 0 && extra < valid) {
+                const float* sx = lds + ((i & 1) ? m.sc0 : m.sc1) + extra * kScPitch;            // that row's NEXT buffer
+                cr[extra * kBins + lane] = sx[lane];
+                cr[extra * kBins + lane + 64] = sx[lane + 64];
+            }
+        }
+        { float* t = scc; scc = scn; scn = t; }
+        B2STAMP(6);
+        B2STAMP(7);
+        // LDS reuse: cdf / coarse are rewritten by wave 0 after barrier 3, i.e. after every search of this step; the
+        // S'new / uniform tiles of parity i are rewritten by wave 7 behind barrier 1 of step i+1; tabb and the bins parked in
+        // `pos` behind barrier 1 as well (their readers, the publishing waves, reach that barrier after their stores were
+        // issued); Msm behind barrier 2; the rows read by waves 1 and 6 are rewritten behind barrier 2 of step i+1.
+    }
+    // ---- hand the point scores to the next launch (its set-up reads them back through pb) ----
+    if (row_ok) {
+        a.Sp_out[(tile + wave) * N + n0] = scc[lane];
+        a.Sp_out[(tile + wave) * N + n1] = scc[lane + 64];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// alpha_rows2_kernel: the chunk-parallel other half of chain_batch2_kernel.  For every step of a sub-batch and every
+// (layer, head, query) row it rebuilds the full score row from the point scores of the PREVIOUS step and the step's
+// drawn-bin table -- S'_c[n] = val_n * sum_k S'_{c-1}[point tabb_c[n][k]] + S'new_c[row(n)], the same fma chain in
+// the same order as the chain kernel's, so the two agree bit for bit on the boxes both compute -- then the
+// count-weighted softmax alpha[n] = w_n e^{S_n} / (sum_m w_m e^{S_m} + w_out)  (LTM.py:247-248,269-282 in closed
+// form) and asum = sum_n alpha[n].  One workgroup per (step, layer, head), a wave per query row in turn.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kA2NT = 256;
+constexpr int kA2Q = 32;                  // query rows staged per pass
+
+__global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
+    const int i = blockIdx.x, lh = blockIdx.y, l = lh / H;
+    const int snp = kA2Q + 1;
+    int32_t* tabb = reinterpret_cast<int32_t*>(lds);                       // [N * tabw]
+    float* prev = lds + ((N * tabw + 3) & ~3);                             // [kA2Q][kScPitch]
+    float* snew = prev + kA2Q * kScPitch;                                  // [rows][kA2Q + 1]
+    const long slot = (a.slot0 + i) % a.ring;
+    const long pslot = (a.slot0 + i + a.ring - 1) % a.ring;
+    const int32_t* tb = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;
+    for (int e = tid; e < N * tabw / 4; e += kA2NT) reinterpret_cast<int4*>(tabb)[e] = reinterpret_cast<const int4*>(tb)[e];
+    // static operator entries of this lane's boxes
+    float val[4]; int brow[4]; float wn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = lane + 64 * k;
+        val[k] = (n < N) ? a.box_val[n] : 0.f;
+        brow[k] = (n < N) ? a.box_row[n] : -1;
+        wn[k] = (n < N) ? a.w[n] : 0.f;
+    }
+    const bool write_sp = a.Sp_out != nullptr && i == a.n_steps - 1;
+    for (int q0 = 0; q0 < Q; q0 += kA2Q) {
+        const int qn = min(kA2Q, Q - q0);
+        const long row0 = (long)lh * Q + q0;                               // first row of the pass in [L][H][Q] order
+        __syncthreads();
+        // previous point scores of the pass's rows (contiguous in the ring) and the S'new tile [rows][qn]
+        const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
+        for (int e = tid; e < qn * (kBins / 4); e += kA2NT) {
+            const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
+            *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = reinterpret_cast<const floatx4*>(cp)[e];
+        }
+        const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
+        for (int e = tid; e < rows * kA2Q; e += kA2NT) {
+            const int r = e / kA2Q, qq = e - r * kA2Q;
+            float v = 0.f;
+            if (qq < qn) {
+                v = sb[(long)r * a.snew_ld + qq];
+                for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+            }
+            snew[r * snp + qq] = v;
+        }
+        __syncthreads();
+        for (int qq = wave; qq < qn; qq += kA2NT / 64) {
+            const float* pr = prev + qq * kScPitch;
+            const float cqv = a.cq[row0 + qq];
+            float sv[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = lane + 64 * k;
+                sv[k] = -INFINITY;
+                if (n < N) {
+                    float acc = 0.f;
+                    for (int k0 = 0; k0 < tabw; k0 += 4) {
+                        const int4 src = *reinterpret_cast<const int4*>(&tabb[n * tabw + k0]);
+                        const float v0 = pr[max(src.x, 0)], v1 = pr[max(src.y, 0)];
+                        const float v2 = pr[max(src.z, 0)], v3 = pr[max(src.w, 0)];
+                        if (src.x >= 0) acc = fmaf(val[k], v0, acc);
+                        if (src.y >= 0) acc = fmaf(val[k], v1, acc);
+                        if (src.z >= 0) acc = fmaf(val[k], v2, acc);
+                        if (src.w >= 0) acc = fmaf(val[k], v3, acc);
+                    }
+                    if (brow[k] >= 0) acc += snew[brow[k] * snp + qq];
+                    if (write_sp) a.Sp_out[(row0 + qq) * N + n] = acc;     // bias-free scores of the call's last step (diagnostics)
+                    sv[k] = acc + cqv;
+                }
+                mx = fmaxf(mx, sv[k]);
+            }
+            mx = wave_max(mx);
+            float e[4];
+            float esum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = lane + 64 * k;
+                e[k] = (n < N) ? wn[k] * __expf(sv[k] - mx) : 0.f;
+                esum += e[k];
+            }
+            esum = wave_sum(esum);
+            const float inv = 1.0f / (esum + a.w_out * __expf(-mx));
+            float* al = a.alpha_ring + slot * a.alpha_slot + (row0 + qq) * N;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = lane + 64 * k;
+                if (n < N) al[n] = e[k] * inv;
+            }
+            if (lane == 0) a.asum_ring[slot * a.asum_slot + row0 + qq] = esum * inv;
+        }
+    }
+}
+
+hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream) {
+    if (a.n_steps <= 0) return hipSuccess;
+    if (a.N > 256 || (a.N * a.tabw) % 4) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + a.rows * (kA2Q + 1)) * sizeof(float);
+    hipLaunchKernelGGL(alpha_rows2_kernel, dim3(a.n_steps, a.L * a.H), dim3(kA2NT), lds, stream, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Scores -> softmax weights of `n_steps` ring slots, in place:  alpha[n] = w_n e^{S_n} / (sum_m w_m e^{S_m} + w_out)
 // (LTM.py:247-248,269-282 in closed form) and asum = sum_n alpha[n].  One wave per (step, layer, head, query) row;
@@ -331,6 +836,8 @@ static hipError_t chain_batch_attr() {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -341,6 +848,12 @@ static hipError_t chain_batch_attr() {
 // kernel's registers and LDS, even if nothing else left room (other kernels may still delay residency; the waits are
 // bounded and report through the error word).  One workgroup per CU less than the API's answer: the occupancy
 // query reads one high for some SGPR counts (MI355X_MICROARCH.md, residency).
+bool chain_batch2_applies(const ChainBatchArgs& a) {
+    static const bool want_v2 = [] { const char* e = getenv("INFV_CHAIN_V1"); return !e || atoi(e) == 0; }();
+    return want_v2 && a.draw_mode == 1 && a.st.points_ok && 2 * a.op.rows <= 64 * kB2Ld && a.S <= 512 && a.S % 2 == 0 && a.Q % 4 == 0 &&
+           a.crit_ring != nullptr;
+}
+
 bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks) {
     if (chain_batch_attr() != hipSuccess) return false;
     int dev = 0, cus = 0, per_cu = 0;
@@ -356,6 +869,14 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
     if (a.n_steps <= 0) return hipSuccess;
     const int blocks = a.H * a.QS * a.L;
     if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, blocks)) return hipErrorInvalidValue;
+    if (chain_batch2_applies(a)) {
+        // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
+        static const int pad = [] { const char* e = getenv("INFV_S_LDS"); return e ? atoi(e) : 0; }();
+        size_t lds = (size_t)batch2_smem(a.N, a.S, a.op.rows, a.op.tabw).total * sizeof(float);
+        if ((size_t)pad > lds) lds = pad;
+        hipLaunchKernelGGL(chain_batch2_kernel, dim3(blocks), dim3(kBNT), lds, stream, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(chain_batch_kernel, dim3(blocks), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
                        stream, a);
     return hipGetLastError();

@@ -8,6 +8,13 @@ namespace infv {
 constexpr int kMaxLayers = 8;
 constexpr int kHeadSize = 64;      // dh the attend kernel is written for
 constexpr int kQTile = 16;         // query rows per attend workgroup (one MFMA row tile)
+// Spacing (in 8-byte words) of the fixed-point sticky bin-mass accumulators: word j of layer l lives at
+// (l * 128 + j) * kAccStride.  The memory-side atomics of all workgroups of a layer serialise per word; packed
+// words share a few memory channels with each other (and with every streaming load interleaved onto them).
+#ifndef INFV_ACC_STRIDE
+#define INFV_ACC_STRIDE 1
+#endif
+constexpr int kAccStride = INFV_ACC_STRIDE;
 
 // Device-side view of one ridge operator (first-chunk or infinite-memory) of a plan.
 struct OperatorView {
@@ -28,6 +35,7 @@ struct StickyView {
     const int32_t* edge_box;      // [n_bins+1]
     const float* edge_dx;         // [n_bins]
     const int32_t* bin_box;       // [n_bins]
+    int32_t points_ok;            // edges 1..n_bins-1 lie in the box of the bin's left edge, edges 0 and n_bins in none
 };
 
 struct ProjPtrs {
@@ -126,6 +134,7 @@ struct ChainBatchArgs {
     unsigned int* arrive;           // [L] arrival counters, zero at launch
     unsigned int* error;            // host-visible word, set to 1 if a wait timed out
     int spin_limit;                 // polls before a wait gives up
+    int exp_flags;                  // INFV_S_FLAGS (timing experiments): 1 no s_setprio, 2 long sleep between polls, 4 no point-score stores, 8 no loader requests, 16 no exchange (deposit / poll)
     int expect_extra;               // fault injection (tests): arrivals expected beyond the launch's workgroups
     const float* probs_override; unsigned override_mask;     // teacher forcing of step 0
     const double* u;                // [n_steps][L][S]
@@ -133,6 +142,9 @@ struct ChainBatchArgs {
     float* probs_out; int32_t* bins_out; int32_t* idx_out;    // diagnostics of the last step
     float* probs_tr; int32_t* bins_tr; int trace_steps;       // draw trace of steps [0, trace_steps): [.][L][128], [.][L][S] (either may be null)
     int32_t* tab_ring; long tab_slot;
+    int32_t* tabb_ring;             // chain_batch2_kernel: drawn bin of every (box, slot), same slot layout as tab_ring
+    float* crit_ring; long crit_slot;   // chain_batch2_kernel: point scores after every step, [ring][L][H][Q][128]
+    int publish_init;               // chain_batch2_kernel: also write the state BEFORE step 0 to the slot before slot0's
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
     const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // [n_steps][rows] rows of pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
@@ -140,6 +152,20 @@ struct ChainBatchArgs {
     long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
 };
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
+bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch2_kernel (scores rebuilt by alpha_rows2)
+// the chunk-parallel half of chain_batch2_kernel: full score rows from the published point scores + drawn bins, then alpha
+struct AlphaRows2Args {
+    int N, H, Q, L, rows, tabw, n_steps;
+    long slot0; int ring;
+    const float* crit_ring; long crit_slot;
+    const int32_t* tabb_ring; long tab_slot;
+    const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;
+    const float* cq; const float* w; float w_out;
+    const float* box_val; const int32_t* box_row;
+    float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
+    float* Sp_out;                  // full bias-free score rows of the LAST step [L][H][Q][N], or nullptr
+};
+hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
 bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks);   // all workgroups fit on the device at once
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
 

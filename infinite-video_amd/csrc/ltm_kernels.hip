@@ -161,22 +161,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         b_src[i] = segs.base[seg] + (long)(o - segs.start[seg]) * K + kbeg + c4 * 4;
     }
 
-    floatx4 a_reg[AR], b_reg[BR];
-    auto load_tile = [&](int t) {
+    // Two tiles in flight (the tile staged into LDS at step t was requested at step t-2).  It buys no time by itself --
+    // the kernel is MFMA-paced -- but the 92 extra VGPRs make a workgroup of this kernel too large to share a SIMD with
+    // the two resident waves of role S (chain_batch2_kernel): the GEMMs co-reside with the pooling kernel only, never with
+    // the latency-critical chain (measured: 112 k chunks/s against 102 k with the one-tile version).
+    floatx4 a_reg[2][AR], b_reg[2][BR];
+    auto load_tile = [&](int t, floatx4 (&ar)[AR], floatx4 (&br)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            a_reg[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + t * kBK)
-                                : floatx4{0.f, 0.f, 0.f, 0.f};
+            ar[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + t * kBK)
+                             : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < BR; ++i) b_reg[i] = *reinterpret_cast<const floatx4*>(b_src[i] + t * kBK);
+        for (int i = 0; i < BR; ++i) br[i] = *reinterpret_cast<const floatx4*>(b_src[i] + t * kBK);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const floatx4 (&ar)[AR], const floatx4 (&br)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<floatx4*>(&As[(row0 + 32 * i) * kLdsStride + c4 * 4]) = a_reg[i];
+            *reinterpret_cast<floatx4*>(&As[(row0 + 32 * i) * kLdsStride + c4 * 4]) = ar[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<floatx4*>(&Bs[(row0 + 32 * i) * kLdsStride + c4 * 4]) = b_reg[i];
+            *reinterpret_cast<floatx4*>(&Bs[(row0 + 32 * i) * kLdsStride + c4 * 4]) = br[i];
     };
 
     floatx16 acc[TM][TN];
@@ -188,11 +192,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int li = lane & 31, kk = lane >> 5;     // MFMA 32x32x2: row/col = lane&31, k = lane>>5
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
+    auto compute_tile = [&]() {
         // lane half kk consumes k = 16*kk + s at MFMA step s (any bijection of k works as long
         // as A and B agree): 4 x ds_read_b128 per operand tile.
         floatx4 af[TM][4], bf[TN][4];
@@ -216,7 +216,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j][s >> 2][s & 3],
                                                                      acc[i][j], 0, 0, 0);
+    };
+    load_tile(0, a_reg[0], b_reg[0]);
+    if (ntiles > 1) load_tile(1, a_reg[1], b_reg[1]);
+    for (int t = 0; t < ntiles; t += 2) {
+        store_tile(a_reg[0], b_reg[0]);
         __syncthreads();
+        if (t + 2 < ntiles) load_tile(t + 2, a_reg[0], b_reg[0]);
+        compute_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            store_tile(a_reg[1], b_reg[1]);
+            __syncthreads();
+            if (t + 3 < ntiles) load_tile(t + 3, a_reg[1], b_reg[1]);
+            compute_tile();
+            __syncthreads();
+        }
     }
     // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -263,7 +278,21 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (M >= 1024) {
+    if (M >= 1024 && ((M + 127) / 128) * (n_cols / 128) <= 160 && ((M + 63) / 64) * (n_cols / 128) <= 256) {
+        // few column tiles (the score half of the fast path: 126 tiles of 128 x 128 would leave half the CUs idle):
+        // 64-row tiles double the workgroups of the one round
+        const int gx = (M + 63) / 64, gy = n_cols / 128;
+        static bool attr64 = false;
+        if (lds_pad > 0 && !attr64) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<64, 128>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr64 = true;
+        }
+        dim3 grid(gx, gy, splitk);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
+                           C, ldc, split_stride, k_per_split, 0);
+    } else if (M >= 1024) {
         const int gx = (M + 127) / 128, gy = n_cols / 128;
         if (lds_pad > 0) {
             // overlapped mode: one workgroup per CU (padding LDS) and never more workgroups than CUs in a
