@@ -92,12 +92,17 @@ class LongTermAttention(nn.Module):
     def _get_engine(self, device: torch.device, Q: int) -> LTMEngine:
         eng = self._engine
         if eng is None or eng.device != device or eng.max_q < Q:
+            carried = None
             if eng is not None and eng.has_memory:
-                raise RuntimeError("LongTermAttention moved device or grew its query length mid-document")
+                if eng.device != device:
+                    raise RuntimeError("LongTermAttention moved device mid-document")
+                carried = eng.export_state(0)             # a longer query mid-document: carry the memory into a larger engine
             self._engine = eng = LTMEngine(
                 self.attn_num_basis, self.n_head, self.head_size, self.encoder_width, self.tokens_per_frame,
                 tau=self.tau, sticky=bool(self.sticky_memories), n_layers=1, max_q=max(Q, 32), device=device,
                 nb_samples=self.nb_samples)
+            if carried is not None:
+                eng.import_state(0, carried[0].contiguous(), carried[1].contiguous(), self._proj(device))
         return eng
 
     def _proj(self, device):
@@ -140,17 +145,24 @@ class LongTermAttention(nn.Module):
         return {"B_past": B.cpu(), "bin_mass": mass.cpu(), "num_basis": self.attn_num_basis, "tau": self.tau,
                 "sticky": bool(self.sticky_memories), "version": 1}
 
-    def load_memory_state(self, state: Optional[dict], device) -> None:
+    def load_memory_state(self, state: Optional[dict], device, max_q: Optional[int] = None) -> None:
         """Inverse of :meth:`memory_state` (``None`` clears the memory).  The projected memory is rebuilt
-        from ``B_past`` with the current key/value weights."""
+        from ``B_past`` with the current key/value weights.  A memory only continues correctly under the knobs it was
+        consolidated with: ``num_basis``, ``tau`` and ``sticky_memories`` must match this module's."""
         device = torch.device(device)
         if state is None:
             if self._engine is not None:
                 self._engine.reset()
             return
         if state.get("version") != 1 or state["num_basis"] != self.attn_num_basis:
-            raise ValueError("memory state does not match this LongTermAttention")
-        eng = self._get_engine(device, 32)
+            raise ValueError("memory state does not match this LongTermAttention (version / num_basis)")
+        if abs(float(state["tau"]) - float(self.tau)) > 1e-12 or bool(state["sticky"]) != bool(self.sticky_memories):
+            raise ValueError(f"memory was consolidated with tau={state['tau']}, sticky={bool(state['sticky'])}; this module has "
+                             f"tau={self.tau}, sticky={bool(self.sticky_memories)}")
+        if tuple(state["B_past"].shape) != (self.attn_num_basis, self.encoder_width) or state["bin_mass"].numel() != 127:
+            raise ValueError("memory state tensors have the wrong shape")
+        want_q = max_q if max_q is not None else (self._engine.max_q if self._engine is not None else 32)
+        eng = self._get_engine(device, want_q)
         eng.reset()
         eng.import_state(0, state["B_past"].to(device=device, dtype=torch.float32).contiguous(),
                          state["bin_mass"].to(device=device, dtype=torch.float32).contiguous(), self._proj(device))
