@@ -26,7 +26,7 @@
  *     the ABI.  infv_ltm_last_error() returns a thread-local description;
  *   - a handle is not re-entrant (the reference module is mutable, single-threaded state);
  *   - all floating-point data is fp32, row-major, batch size 1 (reference
- *     long_term_attention_gibbs.py:208,346).
+ *     long_term_attention_gibbs.py:208,346); only the frame tokens may be bf16 (infv_ltm_set_token_dtype).
  */
 #ifndef INFV_LTM_H
 #define INFV_LTM_H
@@ -123,8 +123,16 @@ int infv_ltm_has_plan(infv_ltm_handle h, int32_t T);          /* 1 / 0 */
 int infv_ltm_reset(infv_ltm_handle h);
 int infv_ltm_has_memory(infv_ltm_handle h);                    /* 1 / 0 */
 
-/* Frame mean-pool, long_term_attention_gibbs.py:304:  k [n_frames, P, d] -> kbar [n_frames, d]. */
-int infv_ltm_pool(infv_ltm_handle h, const float* k, int64_t n_frames, float* kbar, void* stream);
+/* Element type of the frame tokens `k` handed to pool / forward / consolidate.  The reference's tokens are fp32
+ * (infinityqa.py:317-322 concatenates the image Q-former's fp32 outputs).  A producer that stores them as bf16
+ * halves the bytes of the only HBM-heavy stream of the path; the pooled frames and everything after stay fp32,
+ * so results differ from the fp32-token run only by the rounding of the tokens themselves (2^-9 relative each,
+ * averaged over P tokens).  Default fp32; set before the first call that takes `k`. */
+typedef enum { INFV_TOKENS_F32 = 0, INFV_TOKENS_BF16 = 1 } infv_token_dtype;
+int infv_ltm_set_token_dtype(infv_ltm_handle h, int32_t dtype);
+
+/* Frame mean-pool, long_term_attention_gibbs.py:304:  k [n_frames, P, d] -> kbar [n_frames, d] (fp32). */
+int infv_ltm_pool(infv_ltm_handle h, const void* k, int64_t n_frames, float* kbar, void* stream);
 
 /* One consolidation step of all n_layers instances on one chunk, from pooled frames:
  * update_inf + proj_key/proj_value + expected_value (long_term_attention_gibbs.py:194-222,
@@ -135,7 +143,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
 
 /* LongTermAttention.forward (long_term_attention_gibbs.py:288-346) for all layers of the
  * handle on one chunk: reset if new_doc, pool, step.  k [T*P, d]. */
-int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
+int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q, int32_t Q,
                      const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
                      void* stream);
 
@@ -143,7 +151,7 @@ int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* 
  * with the LLM/Q-former stubbed: n_chunks chunks of T frames, k [C, T*P, d], the same
  * q [L,Q,dm] for every chunk, u [C,L,S], ctx [C,L,Q,dm].  new_doc applies to chunk 0.
  * Pooling and new-row projections are batched over chunks; the memory chain is sequential. */
-int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T,
+int infv_ltm_consolidate(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T,
                          const float* q, int32_t Q, const infv_ltm_proj* proj, const double* u,
                          int32_t new_doc, float* ctx, void* stream);
 

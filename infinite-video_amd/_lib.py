@@ -90,6 +90,7 @@ _SIGNATURES = {
     "infv_ltm_has_plan": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_reset": (C.c_int, [C.c_void_p]),
     "infv_ltm_has_memory": (C.c_int, [C.c_void_p]),
+    "infv_ltm_set_token_dtype": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "infv_ltm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),

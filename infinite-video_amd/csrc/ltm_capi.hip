@@ -139,6 +139,7 @@ struct infv_ltm_s {
     // error word of the persistent chain kernel: pinned host memory mapped into the device, so a time-out is
     // visible to the host without any synchronisation or copy
     unsigned int* err_host = nullptr; unsigned int* err_dev = nullptr;
+    int k_bf16 = 0;                     // frame tokens arrive as bf16 (infv_ltm_set_token_dtype)
     bool v_split = false;               // INFV_VPROJ_SPLIT=1 at create: V' half of the sub-batch projection as a split-bf16 contraction
     int spin_limit = 1 << 22; int expect_extra = 0;     // INFV_CHAIN_FAULT=1 (tests): expect one arrival too many -> every wait times out
     int32_t* trace_bins = nullptr; float* trace_probs = nullptr; long trace_cap = 0;   // draw trace of consolidate (caller's device buffers)
@@ -438,11 +439,18 @@ int infv_ltm_has_memory(infv_ltm_handle h) {
     return h->has_memory ? 1 : 0;
 }
 
-int infv_ltm_pool(infv_ltm_handle h, const float* k, int64_t n_frames, float* kbar, void* stream) {
+int infv_ltm_set_token_dtype(infv_ltm_handle h, int32_t dtype) {
+    if (int rc = check_handle(h)) return rc;
+    if (dtype != INFV_TOKENS_F32 && dtype != INFV_TOKENS_BF16) return fail(INFV_ERR_INVALID, "set_token_dtype: unknown dtype %d", dtype);
+    h->k_bf16 = dtype == INFV_TOKENS_BF16;
+    return INFV_OK;
+}
+
+int infv_ltm_pool(infv_ltm_handle h, const void* k, int64_t n_frames, float* kbar, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!k || !kbar || n_frames < 0) return fail(INFV_ERR_INVALID, "pool: bad arguments");
     Timed t_(h->prof, INFV_KERNEL_POOL, static_cast<hipStream_t>(stream));
-    HIP_TRY(launch_pool(k, kbar, n_frames, h->P, h->d, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_pool(k, h->k_bf16, kbar, n_frames, h->P, h->d, static_cast<hipStream_t>(stream)));
     return INFV_OK;
 }
 
@@ -463,7 +471,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     return chain_step(h, *plan, h->R_ws[0].as<float>(), h->P_ws[0].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
 }
 
-int infv_ltm_forward(infv_ltm_handle h, const float* k, int32_t T, const float* q, int32_t Q,
+int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q, int32_t Q,
                      const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!k) return fail(INFV_ERR_INVALID, "forward: null k");
@@ -788,10 +796,11 @@ int ensure_side_stream(infv_ltm_handle h) {
 
 extern "C" {
 
-int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, int32_t T, const float* q,
+int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, int32_t T, const float* q,
                          int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
                          void* stream_) {
     if (int rc = check_handle(h)) return rc;
+    const char* k = static_cast<const char*>(k_);               // byte addressing: the token element size depends on the handle
     if (!k || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
     if (int rc = check_chain_error(h)) return rc;
     if (int rc = check_q(h, Q)) return rc;
@@ -799,7 +808,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
     if (int rc = find_plan(h, T, &plan)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const ProjPtrs pp = make_proj(proj, h->L);
-    const size_t chunk_k = (size_t)T * h->P * h->d;          // floats of one chunk's tokens
+    const size_t chunk_k = (size_t)T * h->P * h->d * (h->k_bf16 ? 2 : 4);   // bytes of one chunk's tokens
     const size_t chunk_ctx = (size_t)h->L * Q * h->dm;
     const size_t chunk_u = (size_t)h->L * h->S;
     if (new_doc) infv_ltm_reset(h);
@@ -907,7 +916,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const float* k, int32_t n_chunks, in
         if (split_pool && p_pending[set]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_p[set], 0));
         if (!(skip_mask() & 1)) {
             Timed t_(h->prof, INFV_KERNEL_POOL, pools);
-            HIP_TRY(launch_pool(k + c0 * chunk_k, h->kbar_side[set].as<float>(), (int64_t)nb * T, h->P, h->d, pools, kPoolPad));
+            HIP_TRY(launch_pool(k + c0 * chunk_k, h->k_bf16, h->kbar_side[set].as<float>(), (int64_t)nb * T, h->P, h->d, pools, kPoolPad));
         }
         if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
         return INFV_OK;

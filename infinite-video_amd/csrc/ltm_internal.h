@@ -53,7 +53,7 @@ struct WSegs {
 };
 
 // ---- launchers (all asynchronous on `stream`) -------------------------------------------
-hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad = 0);
+hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad = 0);
 
 // R[c][r][:] = val * sum of the frames of row r of chunk c;  Pnew[sk][c][r][l][kv][dm] = split-K
 // partials of R . W[l][kv]^T  (sk = project_splitk(n_chunks*rows, d) slabs of n_chunks*rows*L*2*dm floats).

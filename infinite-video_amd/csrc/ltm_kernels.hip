@@ -26,27 +26,45 @@ namespace infv {
 //    1 KiB contiguous; P loads per lane are independent, so the whole 32 KiB of a unit is in
 //    flight at once.  This is the only HBM-heavy stage of the path (25.2 MB per chunk).
 // ======================================================================================
-template <int UNROLL, int NT>
-__global__ __launch_bounds__(NT) void pool_frames_kernel(const float* __restrict__ k,
+// Tokens as the producer stores them: fp32 (the reference's layout) or bf16 (half the HBM bytes of the only heavy
+// stream of the path; every bf16 value is exact in fp32, the sum runs in fp32 in the same order).
+struct TokF32 {
+    typedef floatx4 vec;                               // 4 columns per lane
+    static __device__ inline floatx4 widen(floatx4 v) { return v; }
+};
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
+struct TokBF16 {
+    typedef uintx2 vec;                                // 4 bf16 columns per lane (8 bytes)
+    static __device__ inline floatx4 widen(uintx2 v) {
+        floatx4 r;
+        r.x = __uint_as_float(v.x << 16); r.y = __uint_as_float(v.x & 0xffff0000u);
+        r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xffff0000u);
+        return r;
+    }
+};
+
+template <int UNROLL, int NT, class Tok = TokF32>
+__global__ __launch_bounds__(NT) void pool_frames_kernel(const void* __restrict__ k_,
                                                           float* __restrict__ kbar,
                                                           long n_units, int P, int d4, int slices) {
+    typedef typename Tok::vec tvec;
     const int lane = threadIdx.x & 63;
     // grid-stride over units: with a full grid every wave takes exactly one unit; a smaller grid throttles the kernel
     for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
         const long frame = unit / slices;
         const int c4 = (int)(unit - frame * slices) * 64 + lane;
         if (c4 >= d4) continue;
-        const floatx4* src = reinterpret_cast<const floatx4*>(k) + frame * (long)P * d4 + c4;
+        const tvec* src = reinterpret_cast<const tvec*>(k_) + frame * (long)P * d4 + c4;
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         int p = 0;
         for (; p + UNROLL <= P; p += UNROLL) {
-            floatx4 v[UNROLL];
+            tvec v[UNROLL];
 #pragma unroll
             for (int i = 0; i < UNROLL; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
 #pragma unroll
-            for (int i = 0; i < UNROLL; ++i) acc += v[i];
+            for (int i = 0; i < UNROLL; ++i) acc += Tok::widen(v[i]);
         }
-        for (; p < P; ++p) acc += __builtin_nontemporal_load(src + (long)p * d4);
+        for (; p < P; ++p) acc += Tok::widen(__builtin_nontemporal_load(src + (long)p * d4));
         const float fp = (float)P;
         acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does
         // streaming store: leave no dirty lines in L2 (every kernel boundary of the concurrent chain writes L2 back)
@@ -56,7 +74,16 @@ __global__ __launch_bounds__(NT) void pool_frames_kernel(const float* __restrict
 
 // `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
 // latency-critical kernel on another stream always finds wave slots and LDS (see consolidate()).
-hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad) {
+template <class Tok>
+static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad);
+
+hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad) {
+    return k_bf16 ? launch_pool_t<TokBF16>(k, kbar, n_frames, P, d, stream, lds_pad)
+                  : launch_pool_t<TokF32>(k, kbar, n_frames, P, d, stream, lds_pad);
+}
+
+template <class Tok>
+static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, int P, int d, hipStream_t stream, int lds_pad) {
     const int d4 = d / 4;
     const int slices = (d4 + 63) / 64;
     const long n_units = (long)n_frames * slices;
@@ -66,11 +93,11 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
         // (8 waves x 32 KiB in flight still cover the HBM latency), so the chain kernel always finds room
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 512>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 512, Tok>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
@@ -83,15 +110,15 @@ hipError_t launch_pool(const float* k, float* kbar, int64_t n_frames, int P, int
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
         if (unroll <= 2)
-            hipLaunchKernelGGL((pool_frames_kernel<2, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            hipLaunchKernelGGL((pool_frames_kernel<2, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
         else if (unroll <= 4)
-            hipLaunchKernelGGL((pool_frames_kernel<4, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            hipLaunchKernelGGL((pool_frames_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
         else if (unroll <= 8)
-            hipLaunchKernelGGL((pool_frames_kernel<8, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            hipLaunchKernelGGL((pool_frames_kernel<8, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
         else
-            hipLaunchKernelGGL((pool_frames_kernel<16, 512>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            hipLaunchKernelGGL((pool_frames_kernel<16, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
     } else {
-        hipLaunchKernelGGL((pool_frames_kernel<16, 256>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
+        hipLaunchKernelGGL((pool_frames_kernel<16, 256, Tok>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
                            n_units, P, d4, slices);
     }
     return hipGetLastError();

@@ -36,11 +36,19 @@ namespace {
 int check_cfg(const infv_vqf_config& c) {
     if (c.n_layers < 1 || c.n_layers > INFV_VQF_MAX_LAYERS) return fail(INFV_ERR_INVALID, "n_layers must be 1..%d", INFV_VQF_MAX_LAYERS);
     if (c.n_heads < 1 || c.hidden != c.n_heads * 64) return fail(INFV_ERR_UNSUPPORTED, "hidden must be n_heads * 64");
-    if (c.n_query < 1 || c.n_query > 32) return fail(INFV_ERR_UNSUPPORTED, "n_query must be 1..32");
+    // (the whole-layer entry points need n_query <= 32 and tokens_per_frame % 32 == 0 and check it themselves;
+    //  infv_vqf_short_attention alone also serves the VideoChat2 shape: 96 query tokens, 196 tokens per frame)
+    if (c.n_query < 1 || c.n_query > 256) return fail(INFV_ERR_UNSUPPORTED, "n_query must be 1..256");
     if (c.hidden % 64 || c.inter % 64 || c.enc_width % 32 || (c.proj_out % 64)) return fail(INFV_ERR_UNSUPPORTED, "widths must be multiples of 64 (enc_width: 32)");
     if (c.hidden > 4096 || c.inter > 4096 || c.proj_out > 4096 || 3 * c.hidden > 4096) return fail(INFV_ERR_UNSUPPORTED, "row widths above 4096 are not supported");
     if (c.nb_samples < 1) return fail(INFV_ERR_INVALID, "nb_samples must be >= 1");
-    if (c.tokens_per_frame < 1 || c.tokens_per_frame % 32) return fail(INFV_ERR_UNSUPPORTED, "tokens_per_frame must be a multiple of 32");
+    if (c.tokens_per_frame < 1) return fail(INFV_ERR_INVALID, "tokens_per_frame must be positive");
+    return INFV_OK;
+}
+
+int check_layer_cfg(const infv_vqf_config& c) {       // what the fused per-layer kernels of encode_chunk / encode_video are built for
+    if (c.n_query > 32) return fail(INFV_ERR_UNSUPPORTED, "encode_chunk / encode_video need n_query <= 32 (this handle: %d)", c.n_query);
+    if (c.tokens_per_frame % 32) return fail(INFV_ERR_UNSUPPORTED, "encode_chunk / encode_video need tokens_per_frame %% 32 == 0");
     return INFV_OK;
 }
 
@@ -255,6 +263,7 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                           float* hidden_out, float* llama_out, void* stream_) {
     if (!h || !frames || !w) return fail(INFV_ERR_INVALID, "null argument");
     const infv_vqf_config& c = h->cfg;
+    if (int rc = check_layer_cfg(c)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const bool use_ltm = c.alpha != 1.0f;                      // Qformer.py:220-223
     if (use_ltm && !ltm) return fail(INFV_ERR_INVALID, "alpha != 1 needs the per-layer LTM handles");
@@ -349,6 +358,7 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                           float* hidden_out, float* llama_out, float* llama_mean, void* stream_) {
     if (!h || !frames || !w || n_chunks < 1) return fail(INFV_ERR_INVALID, "bad argument");
     const infv_vqf_config& c = h->cfg;
+    if (int rc = check_layer_cfg(c)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const bool use_ltm = c.alpha != 1.0f;
     if (use_ltm && !ltm) return fail(INFV_ERR_INVALID, "alpha != 1 needs the per-layer LTM handles");

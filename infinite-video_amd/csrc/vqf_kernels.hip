@@ -355,11 +355,13 @@ hipError_t launch_qf_self_attention(const float* qkv, int nb, int Q, int H, floa
 __global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict__ xq, int Q, int H, int d,
                                                         const float* __restrict__ wk, float* __restrict__ qt) {
     __shared__ __attribute__((aligned(16))) float qs[32 * 64];
-    const int h = blockIdx.x, b = blockIdx.z, tid = threadIdx.x;
+    const int QT = (Q + 31) / 32;                                // query rows in tiles of 32 (VideoChat2: Q = 96)
+    const int h = blockIdx.x, b = blockIdx.z / QT, q0 = (blockIdx.z - b * QT) * 32, tid = threadIdx.x;
     const int hidden = H * 64;
+    const int qn = min(32, Q - q0);
     for (int e = tid; e < 32 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
-        qs[e] = (r < Q) ? xq[((long)b * Q + r) * hidden + h * 64 + c] * 0.125f : 0.f;
+        qs[e] = (r < qn) ? xq[((long)b * Q + q0 + r) * hidden + h * 64 + c] * 0.125f : 0.f;
     }
     __syncthreads();
     const int j = blockIdx.y * 256 + tid;
@@ -367,8 +369,8 @@ __global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict_
     float w[64];
 #pragma unroll
     for (int e = 0; e < 64; ++e) w[e] = wk[(long)(h * 64 + e) * d + j];
-    float* out = qt + ((long)b * H * Q + (long)h * Q) * d + j;
-    for (int r = 0; r < Q; ++r) {
+    float* out = qt + ((long)b * H * Q + (long)h * Q + q0) * d + j;
+    for (int r = 0; r < qn; ++r) {
         float a = 0.f;
 #pragma unroll
         for (int e4 = 0; e4 < 16; ++e4) {
@@ -384,8 +386,7 @@ __global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict_
 
 hipError_t launch_qf_qtilde(const float* xq, int nb, int Q, int H, int d, const float* wk, float* qt,
                             hipStream_t stream) {
-    if (Q > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qf_qtilde_kernel, dim3(H, (d + 255) / 256, nb), dim3(256), 0, stream, xq, Q, H, d, wk, qt);
+    hipLaunchKernelGGL(qf_qtilde_kernel, dim3(H, (d + 255) / 256, nb * ((Q + 31) / 32)), dim3(256), 0, stream, xq, Q, H, d, wk, qt);
     return hipGetLastError();
 }
 

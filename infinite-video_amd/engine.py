@@ -33,6 +33,9 @@ def _np_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+TOKEN_DTYPES = {torch.float32: 0, torch.bfloat16: 1}      # infv_token_dtype
+
+
 def _check_dev(t: torch.Tensor, device: torch.device, name: str, dtype=torch.float32):
     if t.device != device:
         raise ValueError(f"{name} is on {t.device}, engine is on {device}")
@@ -66,6 +69,7 @@ class LTMEngine:
             _lib.check(self.lib.infv_ltm_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
         self._plans = {}
+        self._token_dtype = torch.float32
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -139,10 +143,20 @@ class LTMEngine:
     def reset(self):
         _lib.check(self.lib.infv_ltm_reset(self._h))
 
+    def _tokens(self, k: torch.Tensor):
+        """Frame tokens may be fp32 (the reference's layout) or bf16 (a producer that halves the HBM stream): tell the
+        handle which one this call passes."""
+        if k.dtype not in TOKEN_DTYPES:
+            raise TypeError(f"frame tokens must be float32 or bfloat16, got {k.dtype}")
+        _check_dev(k, self.device, "k", k.dtype)
+        if k.dtype != self._token_dtype:
+            _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, TOKEN_DTYPES[k.dtype]))
+            self._token_dtype = k.dtype
+
     # ------------------------------------------------------------------ operators
     def pool(self, k: torch.Tensor) -> torch.Tensor:
-        """k [..., T*P, d] -> frame means [..., T, d]   (reference :304)."""
-        _check_dev(k, self.device, "k")
+        """k [..., T*P, d] (fp32 or bf16) -> frame means [..., T, d] fp32   (reference :304)."""
+        self._tokens(k)
         if k.shape[-1] != self.d or k.shape[-2] % self.P:
             raise ValueError(f"k must be [..., T*{self.P}, {self.d}], got {tuple(k.shape)}")
         n_frames = k.numel() // (self.P * self.d)
@@ -168,7 +182,7 @@ class LTMEngine:
     def forward(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
                 u: Optional[torch.Tensor] = None, new_doc: bool = False) -> torch.Tensor:
         """LongTermAttention.forward for all layers: k [T*P, d], q [L, Q, dm] -> ctx [L, Q, dm]."""
-        _check_dev(k, self.device, "k")
+        self._tokens(k)
         if k.dim() != 2 or k.shape[1] != self.d or k.shape[0] % self.P:
             raise ValueError(f"k must be [T*{self.P}, {self.d}], got {tuple(k.shape)}")
         T = k.shape[0] // self.P
@@ -184,8 +198,8 @@ class LTMEngine:
     def consolidate(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
                     u: Optional[torch.Tensor] = None, new_doc: bool = True,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Whole-video loop: k [C, T*P, d], q [L, Q, dm], u [C, L, S] -> ctx [C, L, Q, dm]."""
-        _check_dev(k, self.device, "k")
+        """Whole-video loop: k [C, T*P, d] (fp32 or bf16), q [L, Q, dm], u [C, L, S] -> ctx [C, L, Q, dm]."""
+        self._tokens(k)
         if k.dim() != 3 or k.shape[2] != self.d or k.shape[1] % self.P:
             raise ValueError(f"k must be [C, T*{self.P}, {self.d}], got {tuple(k.shape)}")
         Cn, T = int(k.shape[0]), k.shape[1] // self.P

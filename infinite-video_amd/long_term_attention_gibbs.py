@@ -188,8 +188,10 @@ class LongTermAttention(nn.Module):
         if new_doc or not self.infinite_memory:
             eng.reset()                                   # :300-302 (and the non-infinite branch :310)
         kf = k[0]
-        if kf.dtype != torch.float32 or not kf.is_contiguous():
-            kf = kf.float().contiguous()
+        if kf.dtype not in (torch.float32, torch.bfloat16):       # bf16 tokens are pooled as they are (engine._tokens)
+            kf = kf.float()
+        if not kf.is_contiguous():
+            kf = kf.contiguous()
         ref = _pool_cache["ref"]
         if ref is not None and ref() is k and _pool_cache["version"] == k._version:
             kbar = _pool_cache["kbar"]

@@ -107,3 +107,48 @@ def video_qformer_weights(n_layers: int = 2, hidden: int = 768, inter: int = 307
         lnorm(p + "output_query.LayerNorm", hidden)
     linear("llama_proj", proj_out, hidden)
     return out
+
+
+SEED_VC = 888
+
+
+def videochat2_qformer_weights(n_layers: int = 12, hidden: int = 768, inter: int = 3072, enc_width: int = 1024,
+                               cross_freq: int = 2, n_query: int = 96, proj_out: int = 4096, seed: int = SEED_VC) -> dict:
+    """Random-init weights of the VideoChat2 Q-former encoder + ``mistral_proj`` under the reference's state-dict names
+    (infty-VideoChat2/models/blip2/Qformer.py:419-441: every layer has self-attention, the query FFN
+    ``intermediate_query``/``output_query`` and the text FFN ``intermediate``/``output``; layers with
+    ``l % cross_freq == 0`` also a cross-attention whose key/value read the ``enc_width``-wide frame tokens), plus
+    ``query_tokens`` [1, n_query, hidden] (query + extra query tokens, videochat2_it_mistral.py:199-203).
+    Same value conventions as :func:`video_qformer_weights`."""
+    out, idx = {}, [0]
+
+    def nrm(shape, scale, shift=0.0):
+        a = _normal(seed, idx[0], shape, scale)
+        idx[0] += 1
+        return a + np.float32(shift) if shift else a
+
+    def linear(name, n_out, n_in):
+        out[name + ".weight"] = nrm((n_out, n_in), 0.02)
+        out[name + ".bias"] = nrm((n_out,), 0.02)
+
+    def lnorm(name, n):
+        out[name + ".weight"] = nrm((n,), 0.1, 1.0)
+        out[name + ".bias"] = nrm((n,), 0.1)
+
+    out["query_tokens"] = nrm((1, n_query, hidden), 0.02)
+    for l in range(n_layers):
+        p = f"bert.encoder.layer.{l}."
+        atts = [("attention", hidden)] + ([("crossattention", enc_width)] if l % cross_freq == 0 else [])
+        for att, kv_in in atts:
+            linear(p + att + ".self.query", hidden, hidden)
+            linear(p + att + ".self.key", hidden, kv_in)
+            linear(p + att + ".self.value", hidden, kv_in)
+            linear(p + att + ".output.dense", hidden, hidden)
+            lnorm(p + att + ".output.LayerNorm", hidden)
+        for ffn in ("intermediate", "intermediate_query"):
+            linear(p + ffn + ".dense", inter, hidden)
+        for ffn in ("output", "output_query"):
+            linear(p + ffn + ".dense", hidden, inter)
+            lnorm(p + ffn + ".LayerNorm", hidden)
+    linear("mistral_proj", proj_out, hidden)
+    return out

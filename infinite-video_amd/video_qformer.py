@@ -143,6 +143,59 @@ def init_video_Qformer(num_query_token: int, vision_width: int, num_hidden_layer
     return qformer, query_tokens
 
 
+class ShortMemoryBuffer:
+    """Producer side of ``encode_video``: the frame tokens of the current video fragment, kept in the layout the
+    frame mean-pool reads -- one contiguous ``[T, P, d]`` block -- instead of the reference's Python list of per-frame
+    tensors that ``encode_video`` unsqueezes, concatenates and rearranges on every call (infinityqa.py:251-278 fills the
+    list, :285,306-323 rebuilds the tensor).
+
+    * ``replace(q_hidden_state, n_frame)`` is ``encode_short_memory_frame``'s epilogue (:270-278): the buffer is
+      emptied and the frames ``cur_frame <= n_frame`` of the image Q-former's output ``[F, P, d]`` are kept
+      (so at most ``n_frame + 1`` of them, as in the reference).
+    * ``frames()`` applies ``encode_video``'s cap (:286-288,306-307): with ``n_position = min(32, ceil(sqrt(T)))``
+      only the newest ``n_position**2`` frames survive; it returns them as ``[1, T*P, d]`` without copying.
+
+    ``dtype=torch.bfloat16`` stores the tokens at half the bytes: ``infv_ltm_pool`` / ``infv_ltm_consolidate`` read them
+    directly (``infv_ltm_set_token_dtype``); the result then differs from the fp32-token run by the rounding of the
+    tokens (off by default, never used for the headline number)."""
+
+    def __init__(self, tokens_per_frame: int, width: int, capacity_frames: int = 2049, dtype=torch.float32,
+                 device=None):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("ShortMemoryBuffer holds float32 or bfloat16 tokens")
+        self.P, self.d = int(tokens_per_frame), int(width)
+        self.store = torch.empty(int(capacity_frames), self.P, self.d, dtype=dtype, device=device)
+        self.n = 0
+
+    def __len__(self) -> int:
+        return self.n
+
+    def clear(self):
+        self.n = 0
+
+    def replace(self, q_hidden_state: torch.Tensor, n_frame: int = 2048):
+        if q_hidden_state.dim() != 3 or tuple(q_hidden_state.shape[1:]) != (self.P, self.d):
+            raise ValueError(f"q_hidden_state must be [F, {self.P}, {self.d}]")
+        keep = min(q_hidden_state.size(0), int(n_frame) + 1)            # frames with cur_frame <= n_frame (:275)
+        if keep > self.store.size(0):
+            raise ValueError(f"{keep} frames exceed the buffer's capacity of {self.store.size(0)}")
+        self.store[:keep].copy_(q_hidden_state[:keep])                   # cast + layout in one copy, no list, no cat
+        self.n = keep
+        return self
+
+    @staticmethod
+    def frame_cap(n_frames: int):
+        """(n_position, frames kept) of encode_video for a buffer of ``n_frames`` frames (:286-288,306-307)."""
+        n_position = min(32, math.ceil(math.sqrt(n_frames)))
+        return n_position, min(n_frames, n_position * n_position)
+
+    def frames(self) -> torch.Tensor:
+        if self.n == 0:
+            raise RuntimeError("short_memory_buffer is empty")
+        _, kept = self.frame_cap(self.n)
+        return self.store[self.n - kept:self.n].reshape(1, kept * self.P, self.d)     # the oldest frames are dropped
+
+
 def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     t = t.detach()
     if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
@@ -417,6 +470,15 @@ class InfVideoEncoder(nn.Module):
 
     # ------------------------------------------------------------------ encode_video (infinityqa.py:280-344)
     def encode_video(self, new_video: bool = True):
+        if isinstance(self.short_memory_buffer, ShortMemoryBuffer):
+            # tokens already in the pooling layout: no per-frame unsqueeze / cat / rearrange (:285,317-323)
+            frame_hidden_state = self.short_memory_buffer.frames()
+            self.n_position, _ = ShortMemoryBuffer.frame_cap(len(self.short_memory_buffer))
+            if not frame_hidden_state.is_cuda:
+                raise RuntimeError("the video Q-former path runs on the HIP device only (no CPU fallback)")
+            _, inputs_llama = self.encode_frames(frame_hidden_state, new_video)
+            atts_llama = torch.ones(inputs_llama.size()[:-1], dtype=torch.long, device=frame_hidden_state.device)
+            return inputs_llama, atts_llama
         if not self.short_memory_buffer:
             raise RuntimeError("short_memory_buffer is empty")
         buf = [f if f.dim() == 3 else f.unsqueeze(0) for f in self.short_memory_buffer]   # :285

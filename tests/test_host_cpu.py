@@ -149,3 +149,33 @@ def test_bench_gpus_flag_spawns_ranks_without_touching_the_gpu(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_short_memory_buffer_keeps_the_reference_frames():
+    """Producer layout (infinityqa.py:251-278,285-307): frames with cur_frame <= n_frame are kept, encode_video then
+    drops the oldest beyond n_position**2, n_position = min(32, ceil(sqrt(T)))."""
+    import math
+    import torch
+    from infinite_video_amd.video_qformer import ShortMemoryBuffer
+    P, d = 4, 8
+    frames = torch.arange(1100 * P * d, dtype=torch.float32).reshape(1100, P, d)
+    buf = ShortMemoryBuffer(P, d, capacity_frames=1101)
+    for F, n_frame in ((5, 2048), (8, 2048), (300, 256), (1100, 2048), (10, 3)):
+        buf.replace(frames[:F], n_frame)
+        # the reference: a list of the frames with index <= n_frame ...
+        ref = [frames[i] for i in range(F) if i <= n_frame]
+        assert len(buf) == len(ref)
+        # ... of which encode_video keeps the newest n_position^2
+        n_position = min(32, math.ceil(math.sqrt(len(ref))))
+        while len(ref) > n_position * n_position:
+            ref.pop(0)
+        want = torch.cat([f.unsqueeze(0) for f in ref], 0).reshape(1, -1, d)
+        got = buf.frames()
+        assert got.data_ptr() >= buf.store.data_ptr() and torch.equal(got, want)          # a view, same numbers
+        assert ShortMemoryBuffer.frame_cap(len(buf)) == (n_position, len(ref))
+    half = ShortMemoryBuffer(P, d, capacity_frames=16, dtype=torch.bfloat16).replace(frames[:9] / 1000.0)
+    assert half.frames().dtype == torch.bfloat16 and half.frames().shape == (1, 9 * P, d)
+    with pytest.raises(ValueError):
+        buf.replace(frames[:3, :2])
+    with pytest.raises(RuntimeError):
+        ShortMemoryBuffer(P, d, 4).frames()

@@ -299,3 +299,30 @@ def test_full_size_properties_of_the_memory_operator(dev):
         V = st.export_state(l)[0] @ wv.t() + bv                          # projected memory rows [N, dm]
         bound = V.abs().max(dim=0).values                                # per output column
         assert bool((ctx[-1, l].abs() <= bound.unsqueeze(0) * (1 + 1e-5) + 1e-6).all())
+
+
+def test_bf16_frame_tokens_pool_and_consolidate(dev):
+    """f4 producer option: tokens stored as bf16 (half the HBM bytes of the only heavy stream).  Every bf16 value is exact
+    in fp32 and the sum runs in fp32 in the same order, so pooling bf16 tokens equals pooling their fp32 copies bit for
+    bit, and so does everything downstream."""
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    N, H, dh, d, P, T, Q, L, Cn = 64, 12, 64, 768, 32, 8, 32, 2, 7
+    k16 = torch.from_numpy(np.stack([synth.frame_tokens(c, T, P, d, seed=990) for c in range(Cn)])).to(dev).to(torch.bfloat16)
+    k32 = k16.float()
+    eng = LTMEngine(N, H, dh, d, P, tau=.75, sticky=True, n_layers=L, max_q=Q, device=dev, max_batch_chunks=3)
+    pooled16 = eng.pool(k16)
+    pooled32 = eng.pool(k32)
+    assert pooled16.dtype == torch.float32 and torch.equal(pooled16, pooled32)
+    np.testing.assert_allclose(pooled16[0].cpu().numpy(), O.ClosedFormOracle.pool(k32[0].cpu().numpy(), P), rtol=0, atol=2e-6)
+    projs = [tuple(_to(dev, *synth.layer_projections(l, d, H * dh, seed=991))) for l in range(L)]
+    q = torch.from_numpy(np.stack([synth.layer_query(l, Q, H * dh, seed=992) for l in range(L)])).to(dev)
+    u = torch.from_numpy(synth.gibbs_uniforms(Cn, L, seed=993)).to(dev)
+    a = eng.consolidate(k16, q, projs, u, new_doc=True).clone()
+    b = eng.consolidate(k32, q, projs, u, new_doc=True)
+    assert torch.equal(a, b)
+    f16 = eng.forward(k16[0], q, projs, None, new_doc=True).clone()
+    f32 = eng.forward(k32[0], q, projs, None, new_doc=True)
+    assert torch.equal(f16, f32)
+    with pytest.raises(TypeError):
+        eng.pool(k32.half())

@@ -271,3 +271,25 @@ def test_short_attention_rows_sum_to_one_at_headline_size():
         torch.cuda.synchronize()
         np.testing.assert_allclose(out.cpu().numpy(), bv.unsqueeze(0).expand(32, -1).cpu().numpy(), atol=1e-6)
         _lib.check(lib.infv_vqf_destroy(h))
+
+
+def test_encode_video_from_the_producer_layout_equals_the_list_path():
+    """ShortMemoryBuffer (tokens kept as one [T, P, d] block, infinityqa.py:251-278 counterpart) feeds encode_video the
+    same frames as the reference's list of per-frame tensors, including the frame cap."""
+    from infinite_video_amd.video_qformer import ShortMemoryBuffer
+    case = QF_CASES[0]
+    dev = torch.device("cuda:0")
+    frames, weights = qf_inputs(case)
+    a, b = make_model(case, weights, dev), make_model(case, weights, dev)
+    P, d = 32, 768
+    buf = ShortMemoryBuffer(P, d, capacity_frames=64, device=dev)
+    for c, fr in enumerate(frames[:3]):
+        tok = torch.from_numpy(fr).to(dev).reshape(-1, P, d)
+        torch.manual_seed(chunk_seed(case, c))
+        a.short_memory_buffer = list(tok)
+        ya, _ = a.encode_video(new_video=(c == 0))
+        torch.manual_seed(chunk_seed(case, c))
+        b.short_memory_buffer = buf.replace(tok)
+        yb, _ = b.encode_video(new_video=(c == 0))
+        assert torch.equal(ya, yb)
+        assert b.n_position == a.n_position
