@@ -141,6 +141,20 @@ int infv_ltm_pool(infv_ltm_handle h, const void* k, int64_t n_frames, float* kba
 int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* q, int32_t Q,
                   const infv_ltm_proj* proj, const double* u, float* ctx, void* stream);
 
+/* `n_chunks` consecutive consolidation steps with a DIFFERENT query per chunk (what a cross-attention layer
+ * after the first sees: its query is self.query(hidden_states), Qformer.py:211, and hidden_states depend on the
+ * chunk).  kbar [C,T,d]; q [C,L,Q,dm]; u [C,L,S] (rows of chunks that resample nothing are ignored; may be NULL
+ * when not sticky); ctx [C,L,Q,dm].  The new-row projections of all chunks are batched into one GEMM; the
+ * memory chain (draw, update, attend per chunk) stays sequential.  Equals C calls of infv_ltm_step. */
+int infv_ltm_steps(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T, const float* q, int32_t Q,
+                   const infv_ltm_proj* proj, const double* u, float* ctx, void* stream);
+
+/* The per-chunk loop with per-chunk queries: infv_ltm_consolidate's arguments except q [C,L,Q,dm].
+ * reset if new_doc, pool every chunk (batched), infv_ltm_steps. */
+int infv_ltm_consolidate_q(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T, const float* q,
+                           int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                           void* stream);
+
 /* LongTermAttention.forward (long_term_attention_gibbs.py:288-346) for all layers of the
  * handle on one chunk: reset if new_doc, pool, step.  k [T*P, d]. */
 int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q, int32_t Q,

@@ -94,6 +94,10 @@ _SIGNATURES = {
     "infv_ltm_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "infv_ltm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "infv_ltm_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                 C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "infv_ltm_consolidate_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_consolidate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

@@ -118,6 +118,7 @@ struct infv_ltm_s {
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
     DeviceBuf kbar_ws, kbar_side[3], R_ws[3], P_ws[3], Snew_ws[3];
+    DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
     hipStream_t side = nullptr;
@@ -469,6 +470,56 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     int sk = 1; long ss = 0;
     if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, 0, &sk, &ss, stream)) return rc;
     return chain_step(h, *plan, h->R_ws[0].as<float>(), h->P_ws[0].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
+}
+
+int infv_ltm_steps(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T, const float* q, int32_t Q,
+                   const infv_ltm_proj* proj, const double* u, float* ctx, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!kbar || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "steps: bad arguments");
+    if (int rc = check_chain_error(h)) return rc;
+    if (int rc = check_q(h, Q)) return rc;
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, T, &plan)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const ProjPtrs pp = make_proj(proj, h->L);
+    const size_t chunk_kbar = (size_t)T * h->d, chunk_q = (size_t)h->L * Q * h->dm, chunk_u = (size_t)h->L * h->S;
+    int c = 0;
+    if (!h->has_memory && n_chunks > 0) {                     // first chunk of a document: its own operator
+        if (int rc = infv_ltm_step(h, kbar, T, q, Q, proj, u, ctx, stream_)) return rc;
+        c = 1;
+    }
+    if (c < n_chunks && h->k_stale)
+        if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
+    const size_t rows = plan->inf.rows;
+    const long n_cols = (long)h->L * 2 * h->dm;
+    // sub-batches of at least 16 chunks: 1024 new rows take the large-tile GEMM without split-K
+    const int sub = h->maxC > 16 ? h->maxC : 16;
+    while (c < n_chunks) {
+        const int nb = n_chunks - c < sub ? n_chunks - c : sub;
+        int sk = 1; long ss = 0;
+        // workspace set 0 is reused by every sub-batch: its readers (the update kernels of the previous one) are earlier on
+        // this same stream
+        if (int rc = project_chunks(h, *plan, true, kbar + c * chunk_kbar, nb, T, pp, 0, &sk, &ss, stream)) return rc;
+        for (int i = 0; i < nb; ++i)
+            if (int rc = chain_step(h, *plan, h->R_ws[0].as<float>() + (size_t)i * rows * h->d,
+                                    h->P_ws[0].as<float>() + (size_t)i * rows * n_cols, sk, ss, q + (c + i) * chunk_q, Q, pp,
+                                    u ? u + (c + i) * chunk_u : nullptr, ctx + (c + i) * chunk_q, stream)) return rc;
+        c += nb;
+    }
+    return INFV_OK;
+}
+
+int infv_ltm_consolidate_q(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T, const float* q,
+                           int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                           void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!k || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate_q: bad arguments");
+    if (new_doc) infv_ltm_reset(h);
+    if (n_chunks == 0) return INFV_OK;
+    const size_t need = (size_t)n_chunks * T * h->d * sizeof(float);
+    if (need > h->kbar_all.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->kbar_all.reserve(need)); }
+    if (int rc = infv_ltm_pool(h, k, (int64_t)n_chunks * T, h->kbar_all.as<float>(), stream)) return rc;
+    return infv_ltm_steps(h, h->kbar_all.as<float>(), n_chunks, T, q, Q, proj, u, ctx, stream);
 }
 
 int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q, int32_t Q,

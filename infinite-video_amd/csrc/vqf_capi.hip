@@ -479,9 +479,9 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                 if (new_video)
                     if (int rc = infv_ltm_reset(ltm[l])) return rc;
                 if (int rc = infv_ltm_pool(ltm[l], frames, (int64_t)C * T, h->vkbar.as<float>(), h->side)) return rc;
-                for (int ch = 0; ch < C; ++ch)
-                    if (int rc = infv_ltm_step(ltm[l], h->vkbar.as<float>() + (long)ch * T * c.enc_width, T, vxq + (long)ch * Q * Hd, Q, &pr,
-                                               u ? h->vu.as<double>() + (size_t)ch * S : nullptr, valong + (long)ch * Q * Hd, h->side)) return rc;
+                // per-chunk queries: new-row projections of all chunks in one GEMM, then the chain chunk by chunk
+                if (int rc = infv_ltm_steps(ltm[l], h->vkbar.as<float>(), C, T, vxq, Q, &pr, u ? h->vu.as<double>() : nullptr,
+                                            valong, h->side)) return rc;
                 HIP_TRY(hipEventRecord(h->ev_side, h->side));
             }
             for (int c0 = 0; c0 < C; c0 += NB) {

@@ -215,6 +215,27 @@ class LTMEngine:
                                                       _ptr(u), int(new_doc), _ptr(out), _stream(self.device)))
         return out
 
+    def consolidate_q(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
+                      u: Optional[torch.Tensor] = None, new_doc: bool = True) -> torch.Tensor:
+        """Whole-video loop with a DIFFERENT query per chunk (a cross-attention layer after the first, Qformer.py:211):
+        k [C, T*P, d], q [C, L, Q, dm], u [C, L, S] -> ctx [C, L, Q, dm].  Pooling and new-row projections are batched,
+        the memory chain runs chunk by chunk; equals C calls of forward()."""
+        self._tokens(k)
+        if k.dim() != 3 or k.shape[2] != self.d or k.shape[1] % self.P:
+            raise ValueError(f"k must be [C, T*{self.P}, {self.d}], got {tuple(k.shape)}")
+        Cn, T = int(k.shape[0]), k.shape[1] // self.P
+        _check_dev(q, self.device, "q")
+        if q.dim() != 4 or q.shape[0] != Cn or q.shape[1] != self.L or q.shape[3] != self.dm or q.shape[2] > self.max_q:
+            raise ValueError(f"q must be [{Cn}, {self.L}, Q <= {self.max_q}, {self.dm}], got {tuple(q.shape)}")
+        Q = int(q.shape[2])
+        self._check_u(u, (Cn,))
+        self.ensure_plan(T)
+        out = torch.empty(Cn, self.L, Q, self.dm, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_consolidate_q(self._h, _ptr(k), Cn, T, _ptr(q), Q, self._proj_array(projs),
+                                                        _ptr(u), int(new_doc), _ptr(out), _stream(self.device)))
+        return out
+
     # ------------------------------------------------------------------ state
     def export_state(self, layer: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(B_past [N, d], unnormalised sticky bin masses [127]) of one layer."""

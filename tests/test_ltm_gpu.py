@@ -326,3 +326,32 @@ def test_bf16_frame_tokens_pool_and_consolidate(dev):
     assert torch.equal(f16, f32)
     with pytest.raises(TypeError):
         eng.pool(k32.half())
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c.name in ("cfg1_sticky", "headline", "vc_shape")], ids=lambda c: c.name)
+def test_consolidate_with_per_chunk_queries_equals_forward_chain(dev, case):
+    """infv_ltm_consolidate_q: a different query per chunk (cross-attention layers after the first, Qformer.py:211).
+    Batched pooling + one projection GEMM for all chunks, sequential chain: must equal the per-chunk forward() calls."""
+    from infinite_video_amd import synth
+    ks, qs, ws = case_inputs(case)
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    Cn = next((i for i, t in enumerate(case.chunk_T) if t != case.chunk_T[0]), len(case.chunk_T))
+    ks = ks[:Cn]
+    q = np.stack([np.stack([synth.layer_query(10 * c + l, case.Q, case.dm, seed=4242) for l in range(case.n_layers)])
+                  for c in range(Cn)])                                             # [C, L, Q, dm], different per chunk
+    u = np.stack([np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)]) for c in range(Cn)])
+    qd, ud = torch.from_numpy(q).to(dev), torch.from_numpy(u).to(dev)
+    a = _engine(case, dev)
+    per_chunk = torch.stack([a.forward(torch.from_numpy(ks[c]).to(dev), qd[c], projs, ud[c], new_doc=(c == 0))
+                             for c in range(Cn)])
+    b = _engine(case, dev)
+    batched = b.consolidate_q(torch.from_numpy(np.stack(ks)).to(dev), qd, projs, ud, new_doc=True)
+    np.testing.assert_allclose(batched.cpu().numpy(), per_chunk.cpu().numpy(), rtol=0, atol=2e-5)
+    for l in range(case.n_layers):
+        np.testing.assert_array_equal(b.last_draw(l)[0], a.last_draw(l)[0])
+        np.testing.assert_allclose(b.export_state(l)[0].cpu().numpy(), a.export_state(l)[0].cpu().numpy(), rtol=0, atol=1e-5)
+    # oracle on the last chunk of layer 0 via a fresh per-chunk oracle chain
+    orc = _oracles(case, ws)[0]
+    for c in range(Cn):
+        ref = orc.step(ks[c], q[c, 0], new_doc=(c == 0), u=u[c, 0])
+    np.testing.assert_allclose(batched[-1, 0].cpu().numpy(), ref, rtol=0, atol=CTX_TOL)

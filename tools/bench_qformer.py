@@ -32,16 +32,19 @@ def main():
         Cn = args.batched
         frames = torch.randn(Cn, args.T * 32, 768, device=dev)
         u = torch.from_numpy(synth.gibbs_uniforms(Cn, 2)).to(dev)
-        m.encode_frames_batch(frames[:min(Cn, 32)], new_video=True, u=u[:min(Cn, 32)])
+        m.encode_frames_batch(frames, new_video=True, u=u)             # full-size warm-up: workspaces grow here
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        m.encode_frames_batch(frames, new_video=True, u=u)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            m.encode_frames_batch(frames, new_video=True, u=u)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]
         flops = 2 * 2 * (2 * 384 * 768 * args.T * 32)
-        print(json.dumps({"what": "encode_video counterpart, layer-major whole video", "T": args.T, "alpha": args.alpha,
-                          "chunks": Cn, "ms_per_chunk": 1e3 * dt / Cn, "chunks_per_s": Cn / dt,
-                          "short_attention_tflops": flops * Cn / dt / 1e12}))
+        print(json.dumps({"what": "encode_video counterpart, layer-major whole video (median of 5 calls)", "T": args.T,
+                          "alpha": args.alpha, "chunks": Cn, "ms_per_chunk": 1e3 * dt / Cn, "chunks_per_s": Cn / dt,
+                          "best_ms_per_chunk": 1e3 * min(ts) / Cn, "short_attention_tflops": flops * Cn / dt / 1e12}))
         return
     ks = [torch.randn(1, args.T * 32, 768, device=dev) for _ in range(args.distinct)]
     u = torch.from_numpy(synth.gibbs_uniforms(args.chunks + 4, 2)).to(dev)
