@@ -77,8 +77,9 @@ def pmc_traffic_per_full_launch():
         return None, None
     d = json.load(open(files[-1]))
     try:
-        fetch = [v for k, v in d["fetch"].items() if "pool_frames_kernel<" in k and ", 512>" in k][0][1]
-        write = [v for k, v in d["write"].items() if "pool_frames_kernel<" in k and ", 512>" in k][0][1]
+        # the in-pipeline instantiation (512- or 1024-thread workgroups; the unroll factor is a tuning knob)
+        pick = lambda t: [v for k, v in d[t].items() if "pool_frames_kernel<" in k and (", 512" in k or ", 1024" in k)][0][1]
+        fetch, write = pick("fetch"), pick("write")
     except (KeyError, IndexError):
         return None, None
     return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])

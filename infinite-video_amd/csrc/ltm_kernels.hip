@@ -107,6 +107,26 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
         // pooling).  4 KiB per wave (8 MiB chip-wide) keeps ~95 % of the in-situ pooling rate and gives role S back
         // ~0.5 ms per video; 16 is fastest for the pool alone.
         static const int unroll = [] { const char* e = getenv("INFV_POOL_UNROLL"); return e ? atoi(e) : 4; }();
+        // INFV_POOL_NT=1024: sixteen waves per workgroup (still one workgroup per CU by the padding LDS): the pooling rate
+        // follows the number of resident pooling waves, and other kernels hold part of the CUs
+        static const int nt1024 = [] { const char* e = getenv("INFV_POOL_NT"); return e && atoi(e) == 1024; }();
+        if (nt1024) {
+            static bool attr_big = false;
+            if (!attr_big) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 1024, Tok>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 1024, Tok>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_big = true;
+            }
+            const unsigned g16 = (unsigned)((n_units + 15) / 16);
+            if (unroll <= 2)
+                hipLaunchKernelGGL((pool_frames_kernel<2, 1024, Tok>), dim3(g16), dim3(1024), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            else
+                hipLaunchKernelGGL((pool_frames_kernel<4, 1024, Tok>), dim3(g16), dim3(1024), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            return hipGetLastError();
+        }
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
         if (unroll <= 2)

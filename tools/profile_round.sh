@@ -1,12 +1,13 @@
 #!/bin/bash
 # rocprofv3 passes of the headline bench: kernel-trace stats, then PMC passes (each on its own, as gpurun requires)
+# usage (GPU box): tools/profile_round.sh <tag>    -> gpurun_out/prof_<tag>/ (copy the summaries to profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-encode-video > $out/bench_trace.json 2> $out/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encode-video > $out/bench_trace.json 2> $out/trace.err
 export INFV_SUB_BATCH=42   # the PMC passes run a 252-chunk video: force the 42-chunk launches of the full-length run (6 full launches)
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video > $out/bench_fetch.json 2> $out/fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video > $out/bench_write.json 2> $out/write.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck > $out/bench_fetch.json 2> $out/fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck > $out/bench_write.json 2> $out/write.err
 unset INFV_SUB_BATCH
 python3 - <<PY
 import csv,glob,collections,json
@@ -23,7 +24,7 @@ for name in ("fetch","write"):
     if not fs: print("no pmc file for",name); continue
     agg=collections.defaultdict(lambda:[0,0.0])
     for r in csv.DictReader(open(fs[0])):
-        k=r["Kernel_Name"][:40]
+        k=r["Kernel_Name"][:60]
         agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
     res[name]={k:(n,v/n) for k,(n,v) in agg.items()}
 json.dump(res,open(out+"/pmc_summary.json","w"),indent=1)
