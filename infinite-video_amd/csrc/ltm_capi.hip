@@ -133,6 +133,7 @@ struct infv_ltm_s {
     DeviceBuf qt_buf;                  // fast path: pre-multiplied queries qt[(l*H+h)*Q+q][d] of the current call
     DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
     DeviceBuf crit_ring, tabb_ring;              // chain_batch2_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
+    DeviceBuf wc_flags;                          // whole-call chain kernel: gemm_ready / uc_done / progress counters (u64 x 8)
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
@@ -356,6 +357,8 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->mass_acc[i].reserve((size_t)h->L * 128 * kAccStride * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
+    if (e == hipSuccess) e = h->wc_flags.reserve(8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->wc_flags.p, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(h->sync_words.p, 0, 16 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocMapped);
@@ -615,10 +618,19 @@ struct FastPipe {
         return INFV_OK;
     }
 
+    // whole-call mode of launch_s_batch (wc.sub > 0): one launch for every sub-batch of the call, see ChainBatchArgs
+    struct WholeCall { int sub = 0, n_sub = 0; const float* snew[3] = {nullptr, nullptr, nullptr}; int last_sk = 1; long last_ss = 0; };
+
     // role S of `n` consecutive infinite-memory chunks in one persistent launch
-    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u) {
+    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u, const WholeCall* wc = nullptr) {
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
+        if (wc != nullptr) {
+            b.wc_sub = wc->sub; b.wc_n_sub = wc->n_sub; b.wc_set0 = 0;
+            for (int i = 0; i < 3; ++i) b.wc_snew[i] = wc->snew[i];
+            b.wc_last_splitk = wc->last_sk; b.wc_last_split_stride = wc->last_ss;
+            b.wc_flags = h->wc_flags.as<unsigned long long>();
+        }
         const int QS = chain_s_tiles(Q);
         b.N = h->N; b.H = h->H; b.Q = Q; b.QS = QS; b.L = h->L; b.S = h->S;
         b.st = plan.sticky();
@@ -946,6 +958,33 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         *c0 = first_c + b * sub;
         *nb = (n_chunks - *c0 < sub) ? n_chunks - *c0 : sub;
     };
+    // Whole-call chain (INFV_WHOLE_CALL=1, off by default): ONE launch of chain_batch2_kernel runs every sub-batch.  It
+    // gates itself on the score GEMMs (counter bumped on the side stream) and on the consumption of its ring slots (counter
+    // bumped on the UC stream); the consumers of sub-batch b are gated on its progress counter.  The chain then never
+    // waits to become resident again and its launch gaps disappear.  Measured (headline video): 21.2 ms against 18.3 ms
+    // with one launch per sub-batch -- the permanently resident chain costs the co-resident pooling workgroups more
+    // (pool stream 19.7 ms instead of 15.8) than the launch gaps were worth, the three other streams being the longer
+    // ones either way.  Kept as an option (parity-tested) for configurations where role S is the longest stream.
+    static const bool want_wc = [] { const char* e = getenv("INFV_WHOLE_CALL"); return e && atoi(e) != 0; }();
+    const int s_blocks = h->H * chain_s_tiles(Q) * h->L;
+    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && vproj_on_uc() && !(skip_mask() & 8) &&
+                    chain_batch2_shape_ok(h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S, Q);
+    if (wc) {
+        // the kernel holds the addresses of all three workspace sets: size them before it is launched
+        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
+        const size_t M = (size_t)sub * rows;
+        int c0l_, nbl_; batch_range(n_batches - 1, &c0l_, &nbl_);
+        const size_t Ml = (size_t)nbl_ * rows;                     // the final sub-batch may be short enough for split-K slabs
+        const size_t needP_reg = M * ld * (M < 1024 ? 8 : 1), needP_last = Ml * ld * (Ml < 1024 ? 8 : 1);
+        const size_t needR = M * h->d * sizeof(float), needP = (needP_reg > needP_last ? needP_reg : needP_last) * sizeof(float);
+        bool grow = false;
+        for (int i = 0; i < 3; ++i) grow = grow || needR > h->R_ws[i].bytes || needP > h->P_ws[i].bytes;
+        if (grow) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) { HIP_TRY(h->R_ws[i].reserve(needR)); HIP_TRY(h->P_ws[i].reserve(needP)); }
+        }
+        HIP_TRY(hipMemsetAsync(h->wc_flags.p, 0, 8 * sizeof(unsigned long long), stream));
+    }
     // The pooling has its own stream so that the HBM-bound pooling of batch b+2 overlaps the MFMA-bound projection of
     // batch b+1 (pooled frames are triple-buffered either way); INFV_SPLIT_POOL=0 puts it back on the side stream.
     // (Round 1 measured this worse, 87 k vs 95 k chunks/s, because role S was then sensitive to every concurrent
@@ -979,6 +1018,9 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
         if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side[set].as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
                                          vproj_on_uc())) return rc;
+        // gemm_ready: the chain may enter batch b.  Before the event, so that whoever waits for this batch's projection
+        // (the UC stream, and through it the join of the call) also waits for the counter update: the next call resets it
+        if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 0, side));
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         return INFV_OK;
@@ -987,6 +1029,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
         HIP_TRY(hipStreamWaitEvent(side, h->ev_in, 0));
         if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_in, 0));
+        if (wc) HIP_TRY(hipStreamWaitEvent(ucs, h->ev_in, 0));   // its gate kernels must not read the counters before their reset
         if (int rc = stage_pool(0)) return rc;
         if (n_batches > 1)
             if (int rc = stage_pool(1)) return rc;
@@ -997,16 +1040,35 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
             if (int rc = stage_pool(b + 1)) return rc;
         return stage_project(b);
     };
+    const long wc_slot_base = pipe.counter;                   // ring slot of the call's first sub-batch step
+    if (wc) {
+        FastPipe::WholeCall w;
+        w.sub = sub; w.n_sub = n_batches;
+        for (int i = 0; i < 3; ++i) w.snew[i] = h->P_ws[i].as<float>() + (size_t)h->L * h->dm;
+        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
+        int c0l, nbl; batch_range(n_batches - 1, &c0l, &nbl);
+        const long M_reg = (long)sub * rows, M_last = (long)nbl * rows;
+        w.last_sk = M_last >= 1024 ? 1 : project_splitk((int)M_last, h->d);
+        w.last_ss = M_last * ld;
+        if (int rc = pipe.launch_s_batch(n_chunks - first_c, nullptr, M_reg >= 1024 ? 1 : project_splitk((int)M_reg, h->d), M_reg * ld,
+                                         u ? u + (size_t)first_c * chunk_u : nullptr, &w)) return rc;
+    }
     for (int b = 0; b < n_batches; ++b) {
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % 3;
-        HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
-        // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
-        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
-        const long slot0 = pipe.counter;
+        if (!wc) {
+            HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
+            // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
+            if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
+        }
+        const long slot0 = wc ? wc_slot_base + (long)b * sub : pipe.counter;
         static const bool serial = getenv("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
-        if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
-        if (persistent) {
+        if (serial && !wc) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
+        if (wc) {
+            if (b + 1 < n_batches)
+                if (int rc = stage_parallel(b + 1)) return rc;
+            pipe.last_snew = h->P_ws[set].as<float>() + (size_t)h->L * h->dm; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
+        } else if (persistent) {
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
@@ -1063,9 +1125,15 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
-        HIP_TRY(hipEventRecord(h->ev_s[set], stream));
-        HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
-        if (vs != ucs) HIP_TRY(hipStreamWaitEvent(vs, h->ev_s[set], 0));
+        if (wc) {
+            // consumers of batch b's ring slots: every workgroup of the chain has published and counted the batch
+            HIP_TRY(launch_gate(h->wc_flags.as<unsigned long long>() + 2, (unsigned long long)(b + 1) * s_blocks, h->err_dev, vs));
+            if (vs != ucs) { HIP_TRY(hipEventRecord(h->ev_s[set], vs)); HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0)); }
+        } else {
+            HIP_TRY(hipEventRecord(h->ev_s[set], stream));
+            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
+            if (vs != ucs) HIP_TRY(hipStreamWaitEvent(vs, h->ev_s[set], 0));
+        }
         if (persistent)
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
         if (vs != ucs) {
@@ -1074,6 +1142,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         }
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[set].as<float>(), h->P_ws[set].as<float>(),
                                     sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
+        if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 1, ucs));   // uc_done: batch b's ring slots are free
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
     }

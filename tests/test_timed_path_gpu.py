@@ -197,3 +197,33 @@ def test_consolidate_video_through_rccl_world_of_one(dev):
     assert mem1.B.shape == (1, L, N, D) and float(mem1.count[0]) == 6.0
     assert torch.equal(mem0.B, mem1.B) and torch.equal(mem0.bin_mass, mem1.bin_mass)
     torch.testing.assert_close(mem1.mean_embedding(), ctx1.mean(0), rtol=1e-5, atol=1e-6)
+
+
+def test_whole_call_chain_launch_matches_the_default(dev, monkeypatch):
+    """INFV_WHOLE_CALL=1: ONE launch of the chain kernel for every sub-batch of a call, gated on device-side counters
+    (score GEMMs done / ring slots consumed / progress).  Same arithmetic, so the outputs must equal the default path's
+    bit for bit -- including a short final sub-batch (split-K slabs) and a second call that continues the memory."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from tests.test_timed_path_gpu import _engine, _video
+dev = torch.device("cuda:0")
+k, q, projs, u, _, _ = _video(dev, 75)
+e = _engine(dev, max_batch_chunks=42)
+a = e.consolidate(k[:70], q, projs, u[:70], new_doc=True).clone()
+b = e.consolidate(k[70:], q, projs, u[70:], new_doc=False).clone()
+e.sync()
+B = [e.export_state(l)[0].cpu().numpy() for l in range(2)]
+np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bins=e.last_draw(0)[0])
+'''
+    import tempfile
+    outs = []
+    for flag in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".npz") as f:
+            env = dict(os.environ, INFV_WHOLE_CALL=flag)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+            outs.append({k_: v for k_, v in np.load(f.name).items()})
+    for key in outs[0]:
+        np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
