@@ -169,6 +169,14 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k, int32_t n_chunks, int
                          const float* q, int32_t Q, const infv_ltm_proj* proj, const double* u,
                          int32_t new_doc, float* ctx, void* stream);
 
+/* infv_ltm_consolidate from frame means the caller already holds: kbar [C,T,d] fp32 instead of k.  Same results bit
+ * for bit as infv_ltm_consolidate on tokens whose infv_ltm_pool output is kbar; the pooling stage and its stream drop
+ * out.  The video Q-former's single pass over the frame tokens (split + transpose + mean, Qformer.py:236,278-291)
+ * produces these means, so the tokens are not read a second time for the memory. */
+int infv_ltm_consolidate_pooled(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T,
+                                const float* q, int32_t Q, const infv_ltm_proj* proj, const double* u,
+                                int32_t new_doc, float* ctx, void* stream);
+
 /* Consolidated memory of one layer: B_past [N,d] (long_term_attention_gibbs.py:220) and the
  * unnormalised sticky bin masses p[n_bins-1] derived from the last scores (:200-202).
  * Export copies device -> caller's DEVICE buffers (async on stream). */

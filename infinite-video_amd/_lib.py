@@ -102,6 +102,8 @@ _SIGNATURES = {
                                    C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_consolidate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_consolidate_pooled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                              C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_export_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "infv_ltm_import_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Proj), C.c_void_p]),
     "infv_ltm_reproject": (C.c_int, [C.c_void_p, C.POINTER(Proj), C.c_void_p]),

@@ -859,12 +859,14 @@ int ensure_side_stream(infv_ltm_handle h) {
 
 extern "C" {
 
-int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, int32_t T, const float* q,
-                         int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
-                         void* stream_) {
+// k_: frame tokens (pooled here, on a stream of their own) -- or kbar_pre: frame means [n_chunks][T][d] the caller
+// already holds (infv_ltm_consolidate_pooled: the video Q-former's one pass over the tokens produces them)
+static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar_pre, int32_t n_chunks, int32_t T, const float* q,
+                            int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                            void* stream_) {
     if (int rc = check_handle(h)) return rc;
     const char* k = static_cast<const char*>(k_);               // byte addressing: the token element size depends on the handle
-    if (!k || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
+    if ((!k && !kbar_pre) || !q || !proj || !ctx || n_chunks < 0) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
     if (int rc = check_chain_error(h)) return rc;
     if (int rc = check_q(h, Q)) return rc;
     Plan* plan = nullptr;
@@ -880,9 +882,13 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
     if (!chain_supported(h->N, h->S, rows_max, plan->inf.tabw) || (h->L * h->H * Q) % 128 != 0 || (h->L * h->dm) % 128 != 0 ||
         !uc_supported(h->N, h->d, h->dm, plan->inf.tabw, rows_max)) {
         // shapes the fused chain kernel cannot hold in LDS: per-chunk stage kernels
-        for (int c = 0; c < n_chunks; ++c)
-            if (int rc = infv_ltm_forward(h, k + c * chunk_k, T, q, Q, proj, u ? u + c * chunk_u : nullptr, 0,
-                                          ctx + c * chunk_ctx, stream_)) return rc;
+        for (int c = 0; c < n_chunks; ++c) {
+            if (kbar_pre) {
+                if (int rc = infv_ltm_step(h, kbar_pre + (size_t)c * T * h->d, T, q, Q, proj, u ? u + c * chunk_u : nullptr,
+                                           ctx + c * chunk_ctx, stream_)) return rc;
+            } else if (int rc = infv_ltm_forward(h, k + c * chunk_k, T, q, Q, proj, u ? u + c * chunk_u : nullptr, 0,
+                                                 ctx + c * chunk_ctx, stream_)) return rc;
+        }
         return INFV_OK;
     }
     if (int rc = ensure_side_stream(h)) return rc;
@@ -912,11 +918,15 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
     int c = 0;
     bool uc_pending[3] = {false, false, false};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
-        if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
-        if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
+        const float* kb0 = kbar_pre;
+        if (!kb0) {
+            if ((size_t)T * h->d * sizeof(float) > h->kbar_ws.bytes) HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->kbar_ws.reserve((size_t)T * h->d * sizeof(float)));
+            if (int rc = infv_ltm_pool(h, k, T, h->kbar_ws.as<float>(), stream_)) return rc;
+            kb0 = h->kbar_ws.as<float>();
+        }
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks_fast(h, *plan, false, h->kbar_ws.as<float>(), 1, T, Q, pp, 2, &sk, &ss, stream, 0)) return rc;
+        if (int rc = project_chunks_fast(h, *plan, false, kb0, 1, T, Q, pp, 2, &sk, &ss, stream, 0)) return rc;
         const long v_cols = (long)h->L * h->dm;             // a GEMM output row is [ V' (L*dm) | scores (L*H*Q) ]
         const StepS st{&plan->first, false, h->P_ws[2].as<float>() + v_cols, nullptr, sk, ss};
         if (int rc = pipe.launch_s(st)) return rc;
@@ -989,10 +999,11 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
     // batch b+1 (pooled frames are triple-buffered either way); INFV_SPLIT_POOL=0 puts it back on the side stream.
     // (Round 1 measured this worse, 87 k vs 95 k chunks/s, because role S was then sensitive to every concurrent
     // kernel; with chain_batch2_kernel and no padding LDS on the GEMMs it is better: 112 k vs 102 k.)
-    static const bool split_pool = [] { const char* e = getenv("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
+    static const bool split_pool_env = [] { const char* e = getenv("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
+    const bool split_pool = split_pool_env && !kbar_pre;      // (frame means handed in: there is no pooling stage)
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
-    {
+    if (!kbar_pre) {
         const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
         if (need > h->kbar_side[0].bytes) {
             HIP_TRY(hipDeviceSynchronize());
@@ -1000,6 +1011,7 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         }
     }
     auto stage_pool = [&](int b) -> int {                      // frame means of batch b, on `pools`
+        if (kbar_pre) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % 3;
         // the rows kernel that read this set's pooled frames (batch b-3) is done once its projection is
@@ -1016,7 +1028,8 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
         const int set = b % 3;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
-        if (int rc = project_chunks_fast(h, *plan, true, h->kbar_side[set].as<float>(), nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
+        const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
+        if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
                                          vproj_on_uc())) return rc;
         // gemm_ready: the chain may enter batch b.  Before the event, so that whoever waits for this batch's projection
         // (the UC stream, and through it the join of the call) also waits for the counter update: the next call resets it
@@ -1157,6 +1170,20 @@ int infv_ltm_consolidate(infv_ltm_handle h, const void* k_, int32_t n_chunks, in
     }
     h->k_stale = true;                                        // K' is re-projected from B on demand (per-call path, continuation)
     return INFV_OK;
+}
+
+int infv_ltm_consolidate(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T, const float* q,
+                         int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                         void* stream) {
+    if (!k) return fail(INFV_ERR_INVALID, "consolidate: bad arguments");
+    return consolidate_impl(h, k, nullptr, n_chunks, T, q, Q, proj, u, new_doc, ctx, stream);
+}
+
+int infv_ltm_consolidate_pooled(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T, const float* q,
+                                int32_t Q, const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
+                                void* stream) {
+    if (!kbar) return fail(INFV_ERR_INVALID, "consolidate_pooled: bad arguments");
+    return consolidate_impl(h, nullptr, kbar, n_chunks, T, q, Q, proj, u, new_doc, ctx, stream);
 }
 
 }  // extern "C"

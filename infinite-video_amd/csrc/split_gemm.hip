@@ -170,9 +170,13 @@ hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, vo
 //                                                             FT_hi/FT_lo [d][n]  (B operand of the token-mean contraction)
 // 64 x 64 tiles through LDS; grid (n / 64, d / 64, chunks).
 // ------------------------------------------------------------------------------------------------------
+// With kbar != nullptr the same pass also writes the frame means kbar[chunk][n / P][d] (the long-term memory's pooled
+// frames, Qformer.py:236): P divides 64, so a tile holds 64 / P whole frames; their P tokens are summed in token order and
+// divided by P exactly as pool_frames_kernel does, so the two agree bit for bit and the frame tokens are read once.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ F, int n, int d,
                                                               __bf16* __restrict__ Fh, __bf16* __restrict__ Fl,
-                                                              __bf16* __restrict__ Th, __bf16* __restrict__ Tl) {
+                                                              __bf16* __restrict__ Th, __bf16* __restrict__ Tl,
+                                                              float* __restrict__ kbar, int P) {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -209,13 +213,26 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
             *reinterpret_cast<uint2*>(Tl + o) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
         }
     }
+    if (kbar) {
+        const int fpt = 64 / P;                      // frames per tile
+        for (int e = tid; e < fpt * 64; e += 256) {
+            const int f = e >> 6, c = e & 63;
+            if (r0 + (f + 1) * P <= n) {
+                float acc = 0.f;
+                for (int p = 0; p < P; ++p) acc += tile[f * P + p][c];
+                kbar[((long)blockIdx.z * (n / P) + r0 / P + f) * d + c0 + c] = acc / (float)P;
+            }
+        }
+    }
 }
 
 hipError_t launch_split_transpose(const float* F, int nb, int n, int d, void* Fh, void* Fl, void* Th, void* Tl,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, float* kbar, int P) {
     if (n % 32 || d % 64) return hipErrorInvalidValue;
+    if (kbar && (P < 1 || 64 % P || n % P)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(split_transpose_kernel, dim3((n + 63) / 64, d / 64, nb), dim3(256), 0, stream, F, n, d,
-                       static_cast<__bf16*>(Fh), static_cast<__bf16*>(Fl), static_cast<__bf16*>(Th), static_cast<__bf16*>(Tl));
+                       static_cast<__bf16*>(Fh), static_cast<__bf16*>(Fl), static_cast<__bf16*>(Th), static_cast<__bf16*>(Tl),
+                       kbar, P);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@ struct infv_vqf_s {
     // workspaces (grown on demand; a growing call synchronises the device first)
     DeviceBuf part, h_a, h_b, h1, h2, qkv, sa, xq, along, qt, S, O, merged, inter, kbar;
     DeviceBuf sFh, sFl, sTh, sTl, sPh, sPl, sQh, sQl;   // split-bf16 operands of the short-term attention
+    DeviceBuf wFh, wFl, wTh, wTl;                       // the same split of a WHOLE video's frame tokens (layer-major path)
+    bool fuse = true;                                   // one pass over the frame tokens: split + transpose + frame means
     // whole-video (layer-major) path
     DeviceBuf vA, v1, v2, vxq, valong, vshort, vmerged, vqkv, vsa, vinter, vu, vkbar, v_h1s, v_xqs;
     hipStream_t side = nullptr;
@@ -88,9 +90,43 @@ int run_linear(infv_vqf_s* h, const LinearCall& c, hipStream_t stream) {
 // frames [nb][n_tokens][d]; xq: per-chunk [nb*Q][hidden] (shared_q = false) or one [Q][hidden] block used by every
 // chunk (shared_q = true: layer 0 of the video Q-former, whose query does not depend on the chunk)
 //   -> merged [nb*Q][hidden] = alpha * short-term context + (1 - alpha) * along   (along == nullptr: short-term only)
+// Split-bf16 copies of frame tokens produced ahead of the attention (prepare_split): [.][n_tokens][d] and [.][d][n_tokens]
+struct SplitRef { const __bf16 *Fh, *Fl, *Th, *Tl; };
+
+static bool split_path(const infv_vqf_s* h, int n_tokens) {
+    static const bool want_fp32 = [] { const char* e = getenv("INFV_VQF_FP32"); return e && atoi(e) != 0; }();
+    return !want_fp32 && !h->exact_fp32 && h->cfg.enc_width % 64 == 0 && n_tokens % 64 == 0;   // (odd frame counts: exact-fp32 kernels)
+}
+
+// ONE pass over the frame tokens of `nb` chunks: hi/lo bf16 split, its transposed copy and (kbar != nullptr) the frame
+// means the long-term memories consume.  The tokens do not depend on the layer, so every layer's short-term attention
+// and every layer's memory share this pass (the reference reads them once per layer and once more for the pooling:
+// Qformer.py:236, 278-291).  `whole` selects the video-sized buffers of the layer-major path.
+static int prepare_split(infv_vqf_s* h, const float* frames, int nb, int n_tokens, float* kbar, bool whole, SplitRef* ref,
+                         hipStream_t stream) {
+    const int d = h->cfg.enc_width;
+    const size_t szF = (size_t)nb * n_tokens * d * 2;
+    DeviceBuf& Fh = whole ? h->wFh : h->sFh; DeviceBuf& Fl = whole ? h->wFl : h->sFl;
+    DeviceBuf& Th = whole ? h->wTh : h->sTh; DeviceBuf& Tl = whole ? h->wTl : h->sTl;
+    if (szF > Fh.bytes || szF > Fl.bytes || szF > Th.bytes || szF > Tl.bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(Fh.reserve(szF)); HIP_TRY(Fl.reserve(szF)); HIP_TRY(Th.reserve(szF)); HIP_TRY(Tl.reserve(szF));
+    }
+    for (int c0 = 0; c0 < nb; c0 += 32768) {                   // grid.z limit
+        const int n = nb - c0 < 32768 ? nb - c0 : 32768;
+        const size_t o = (size_t)c0 * n_tokens * d;
+        HIP_TRY(launch_split_transpose(frames + o, n, n_tokens, d, Fh.as<__bf16>() + o, Fl.as<__bf16>() + o, Th.as<__bf16>() + o,
+                                       Tl.as<__bf16>() + o, stream,
+                                       kbar ? kbar + (size_t)c0 * (n_tokens / h->cfg.tokens_per_frame) * d : nullptr,
+                                       h->cfg.tokens_per_frame));
+    }
+    *ref = SplitRef{Fh.as<__bf16>(), Fl.as<__bf16>(), Th.as<__bf16>(), Tl.as<__bf16>()};
+    return INFV_OK;
+}
+
 int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, const float* xq, bool shared_q,
                     const infv_linear* key, const infv_linear* value, const float* along, float* merged,
-                    hipStream_t stream, bool use_cache = false) {
+                    hipStream_t stream, bool use_cache = false, const SplitRef* pre = nullptr) {
     const infv_vqf_config& c = h->cfg;
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
@@ -128,15 +164,15 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     }
     // Both big contractions ( [H*Q x d x n_tokens] each ) run as split-bf16 (three bf16 MFMA products, fp32 accumulate):
     // their rounding (~1e-5) only feeds the read-out.  INFV_VQF_FP32=1 selects the exact-fp32 MFMA kernels instead.
-    static const bool want_fp32 = [] { const char* e = getenv("INFV_VQF_FP32"); return e && atoi(e) != 0; }();
-    if (!want_fp32 && !h->exact_fp32 && d % 64 == 0 && n_tokens % 64 == 0) {     // (odd frame counts: exact-fp32 kernels)
-        const size_t szF = (size_t)nb * n_tokens * d * 2, szP = (size_t)nb * rows * n_tokens * 2, szQ = (size_t)nq * rows * d * 2;
-        if (szF > h->sFh.bytes || szP > h->sPh.bytes || szQ > h->sQh.bytes) {
+    if (split_path(h, n_tokens)) {
+        const size_t szP = (size_t)nb * rows * n_tokens * 2, szQ = (size_t)nq * rows * d * 2;
+        if (szP > h->sPh.bytes || szQ > h->sQh.bytes) {
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(h->sFh.reserve(szF)); HIP_TRY(h->sFl.reserve(szF)); HIP_TRY(h->sTh.reserve(szF)); HIP_TRY(h->sTl.reserve(szF));
             HIP_TRY(h->sPh.reserve(szP)); HIP_TRY(h->sPl.reserve(szP)); HIP_TRY(h->sQh.reserve(szQ)); HIP_TRY(h->sQl.reserve(szQ));
         }
-        HIP_TRY(launch_split_transpose(frames, nb, n_tokens, d, h->sFh.p, h->sFl.p, h->sTh.p, h->sTl.p, stream));
+        SplitRef sr;
+        if (pre) sr = *pre;                                   // the caller split these tokens already (shared by the layers)
+        else if (int rc = prepare_split(h, frames, nb, n_tokens, nullptr, false, &sr, stream)) return rc;
         if (use_cache) {                                      // (the buffers may just have been (re)allocated above)
             qh = h->c_qh.p; ql = h->c_ql.p;
         } else {
@@ -148,14 +184,14 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
         }
         SplitGemm g{};                                        // S[b] = qt[b] . frames[b]^T
         g.A_hi = static_cast<const __bf16*>(qh); g.A_lo = static_cast<const __bf16*>(ql); g.lda = d; g.strideA = shared_q ? 0 : (long)rows * d;
-        g.B_hi = h->sFh.as<__bf16>(); g.B_lo = h->sFl.as<__bf16>(); g.ldb = d; g.strideB = (long)n_tokens * d;
+        g.B_hi = sr.Fh; g.B_lo = sr.Fl; g.ldb = d; g.strideB = (long)n_tokens * d;
         g.C = h->S.as<float>(); g.ldc = ldS; g.strideC = (long)rows * ldS; g.split_stride = 0;
         g.M = rows; g.N = n_tokens; g.K = d; g.k_per_split = d; g.splitk = 1; g.nbatch = nb;
         HIP_TRY(launch_split_gemm(g, stream));
         HIP_TRY(launch_softmax_rows_split(h->S.as<float>(), (long)nb * rows, n_tokens, ldS, h->sPh.p, h->sPl.p, n_tokens, stream));
         SplitGemm p{};                                        // O[b] = P[b] . frames[b]
         p.A_hi = h->sPh.as<__bf16>(); p.A_lo = h->sPl.as<__bf16>(); p.lda = n_tokens; p.strideA = (long)rows * n_tokens;
-        p.B_hi = h->sTh.as<__bf16>(); p.B_lo = h->sTl.as<__bf16>(); p.ldb = n_tokens; p.strideB = (long)d * n_tokens;
+        p.B_hi = sr.Th; p.B_lo = sr.Tl; p.ldb = n_tokens; p.strideB = (long)d * n_tokens;
         p.C = h->O.as<float>(); p.ldc = d; p.strideC = (long)rows * d; p.split_stride = (long)nb * rows * d;
         p.M = rows; p.N = d; p.K = n_tokens; p.k_per_split = kps; p.splitk = sk; p.nbatch = nb;
         HIP_TRY(launch_split_gemm(p, stream));
@@ -218,6 +254,10 @@ int infv_vqf_create(const infv_vqf_config* cfg, infv_vqf_handle* out) {
     infv_vqf_s* h = new (std::nothrow) infv_vqf_s();
     if (!h) return fail(INFV_ERR_INVALID, "out of host memory");
     h->cfg = *cfg;
+    {   // INFV_VQF_FUSE=0 (read per handle, for A/B tests): separate pooling pass + one split pass per layer, as in round 1
+        const char* e = getenv("INFV_VQF_FUSE");
+        h->fuse = !e || atoi(e) != 0;
+    }
     HIP_TRY(hipGetDevice(&h->dev));
     const infv_vqf_config& c = *cfg;
     const size_t row = (size_t)c.n_query * sizeof(float);
@@ -297,8 +337,16 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
         if (new_video)
             for (int l = 0; l < c.n_layers; ++l)
                 if (int rc = infv_ltm_reset(ltm[l])) return rc;
-        if (int rc = infv_ltm_pool(ltm[0], frames, T, h->kbar.as<float>(), stream_)) return rc;   // shared by all layers
     }
+    // one pass over the chunk's tokens serves the pooling and the split operands of every layer's short-term attention
+    SplitRef sref; const SplitRef* pre = nullptr;
+    const bool fused_pool = h->fuse && split_path(h, n_tokens) && 64 % c.tokens_per_frame == 0;
+    if (h->fuse && split_path(h, n_tokens)) {
+        if (int rc = prepare_split(h, frames, 1, n_tokens, use_ltm && fused_pool ? h->kbar.as<float>() : nullptr, false, &sref, stream)) return rc;
+        pre = &sref;
+    }
+    if (use_ltm && !fused_pool)
+        if (int rc = infv_ltm_pool(ltm[0], frames, T, h->kbar.as<float>(), stream_)) return rc;   // shared by all layers
 
     for (int l = 0; l < c.n_layers; ++l) {
         const infv_vqf_layer& L = w->layer[l];
@@ -330,7 +378,7 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
             along = h->along.as<float>();
         }
         if (int rc = short_attention(h, frames, 1, n_tokens, xqb, false, &L.x_k, &L.x_v, along,
-                                     h->merged.as<float>(), stream, l0c)) return rc;
+                                     h->merged.as<float>(), stream, l0c, pre)) return rc;
         LinearCall xo{h->merged.as<float>(), Q, Hd, {&L.x_o}, 1, Hd};
         xo.residual = h1; xo.res_rows = Q; xo.ln = &L.x_ln; xo.y = h->h2.as<float>();
         if (int rc = run_linear(h, xo, stream)) return rc;
@@ -403,6 +451,25 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
         HIP_TRY(h->v_h1s.reserve((size_t)Q * Hd * sizeof(float)));
         HIP_TRY(h->v_xqs.reserve((size_t)Q * Hd * sizeof(float)));
     }
+    // ---- ONE pass over the whole video's frame tokens: split-bf16 operands of every layer's short-term attention and
+    //      the frame means of every layer's memory.  The copies take 2 x the tokens' bytes (12.7 GB for the headline's
+    //      252 chunks): kept for the call when they fit INFV_VQF_SPLIT_CACHE_GB (default 64 of the 288 GB). ----
+    SplitRef wref{}; bool have_w = false, have_kbar = false;
+    {
+        static const double budget_gb = [] { const char* e = getenv("INFV_VQF_SPLIT_CACHE_GB"); return e ? atof(e) : 64.0; }();
+        const double need_gb = 4.0 * (double)C * (double)chunk_k * 2.0 / 1e9;
+        if (h->fuse && split_path(h, n_tokens) && need_gb <= budget_gb) {
+            have_kbar = use_ltm && 64 % c.tokens_per_frame == 0;
+            if (int rc = prepare_split(h, frames, C, n_tokens, have_kbar ? h->vkbar.as<float>() : nullptr, true, &wref, stream)) return rc;
+            have_w = true;
+        }
+    }
+    auto pre_at = [&](int c0, SplitRef* r) -> const SplitRef* {  // the cached split of chunks c0.. (nullptr: split per sub-batch)
+        if (!have_w) return nullptr;
+        const long o = (long)c0 * chunk_k;
+        *r = SplitRef{wref.Fh + o, wref.Fl + o, wref.Th + o, wref.Tl + o};
+        return r;
+    };
     float* vA = h->vA.as<float>(); float* v1 = h->v1.as<float>(); float* v2 = h->v2.as<float>();
     float* vxq = h->vxq.as<float>(); float* valong = h->valong.as<float>();
     float* vshort = h->vshort.as<float>(); float* vmerged = h->vmerged.as<float>();
@@ -444,14 +511,19 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
             // ---- long-term memory of every chunk with the constant query: the whole-video fast path ----
             if (use_ltm) {
                 if (int rc = ltm_u(l)) return rc;
-                if (int rc = infv_ltm_consolidate(ltm[l], frames, C, T, h->v_xqs.as<float>(), Q, &pr, u ? h->vu.as<double>() : nullptr,
-                                                  new_video, valong, stream_)) return rc;
+                if (have_kbar) {
+                    if (int rc = infv_ltm_consolidate_pooled(ltm[l], h->vkbar.as<float>(), C, T, h->v_xqs.as<float>(), Q, &pr,
+                                                             u ? h->vu.as<double>() : nullptr, new_video, valong, stream_)) return rc;
+                } else if (int rc = infv_ltm_consolidate(ltm[l], frames, C, T, h->v_xqs.as<float>(), Q, &pr,
+                                                         u ? h->vu.as<double>() : nullptr, new_video, valong, stream_)) return rc;
             }
             // ---- short-term attention, merged with the long-term context ----
             for (int c0 = 0; c0 < C; c0 += NB) {
                 const int nb = C - c0 < NB ? C - c0 : NB;
+                SplitRef sr;
                 if (int rc = short_attention(h, frames + c0 * chunk_k, nb, n_tokens, h->v_xqs.as<float>(), true, &L.x_k, &L.x_v,
-                                             use_ltm ? valong + (long)c0 * Q * Hd : nullptr, vmerged + (long)c0 * Q * Hd, stream)) return rc;
+                                             use_ltm ? valong + (long)c0 * Q * Hd : nullptr, vmerged + (long)c0 * Q * Hd, stream,
+                                             false, pre_at(c0, &sr))) return rc;
             }
         } else {
             // ---- self-attention block + cross query of every chunk (row blocks) ----
@@ -478,7 +550,8 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                 HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
                 if (new_video)
                     if (int rc = infv_ltm_reset(ltm[l])) return rc;
-                if (int rc = infv_ltm_pool(ltm[l], frames, (int64_t)C * T, h->vkbar.as<float>(), h->side)) return rc;
+                if (!have_kbar)
+                    if (int rc = infv_ltm_pool(ltm[l], frames, (int64_t)C * T, h->vkbar.as<float>(), h->side)) return rc;
                 // per-chunk queries: new-row projections of all chunks in one GEMM, then the chain chunk by chunk
                 if (int rc = infv_ltm_steps(ltm[l], h->vkbar.as<float>(), C, T, vxq, Q, &pr, u ? h->vu.as<double>() : nullptr,
                                             valong, h->side)) return rc;
@@ -486,8 +559,10 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
             }
             for (int c0 = 0; c0 < C; c0 += NB) {
                 const int nb = C - c0 < NB ? C - c0 : NB;
+                SplitRef sr;
                 if (int rc = short_attention(h, frames + c0 * chunk_k, nb, n_tokens, vxq + (long)c0 * Q * Hd, false, &L.x_k, &L.x_v,
-                                             nullptr, (use_ltm ? vshort : vmerged) + (long)c0 * Q * Hd, stream)) return rc;
+                                             nullptr, (use_ltm ? vshort : vmerged) + (long)c0 * Q * Hd, stream, false,
+                                             pre_at(c0, &sr))) return rc;
             }
             if (use_ltm) {
                 HIP_TRY(hipStreamWaitEvent(stream, h->ev_side, 0));

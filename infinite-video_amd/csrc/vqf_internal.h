@@ -62,7 +62,8 @@ hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad
 // x [rows][cols] fp32 -> hi = bf16(x), lo = bf16(x - hi)
 hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, void* hi, void* lo, long ld_out, hipStream_t stream);
 // F [nb][n][d] fp32 -> Fh/Fl [nb][n][d] and Th/Tl [nb][d][n] (bf16 hi/lo)
-hipError_t launch_split_transpose(const float* F, int nb, int n, int d, void* Fh, void* Fl, void* Th, void* Tl, hipStream_t stream);
+hipError_t launch_split_transpose(const float* F, int nb, int n, int d, void* Fh, void* Fl, void* Th, void* Tl, hipStream_t stream,
+                                  float* kbar = nullptr, int P = 0);   // kbar: also the frame means [nb][n / P][d]
 // softmax of fp32 score rows, written as bf16 hi/lo
 hipError_t launch_softmax_rows_split(const float* S, long n_rows, int len, long ld, void* Ph, void* Pl, long ld_out, hipStream_t stream);
 

@@ -215,6 +215,23 @@ class LTMEngine:
                                                       _ptr(u), int(new_doc), _ptr(out), _stream(self.device)))
         return out
 
+    def consolidate_pooled(self, kbar: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
+                           u: Optional[torch.Tensor] = None, new_doc: bool = True) -> torch.Tensor:
+        """consolidate() from frame means the caller already holds: kbar [C, T, d] fp32 (= pool() of the tokens).
+        Bit-identical to consolidate() on those tokens; the pooling stage drops out."""
+        _check_dev(kbar, self.device, "kbar")
+        if kbar.dim() != 3 or kbar.shape[2] != self.d or kbar.dtype != torch.float32:
+            raise ValueError(f"kbar must be fp32 [C, T, {self.d}], got {kbar.dtype} {tuple(kbar.shape)}")
+        Cn, T = int(kbar.shape[0]), int(kbar.shape[1])
+        Q = self._check_q(q)
+        self._check_u(u, (Cn,))
+        self.ensure_plan(T)
+        out = torch.empty(Cn, self.L, Q, self.dm, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_consolidate_pooled(self._h, _ptr(kbar), Cn, T, _ptr(q), Q, self._proj_array(projs),
+                                                             _ptr(u), int(new_doc), _ptr(out), _stream(self.device)))
+        return out
+
     def consolidate_q(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
                       u: Optional[torch.Tensor] = None, new_doc: bool = True) -> torch.Tensor:
         """Whole-video loop with a DIFFERENT query per chunk (a cross-attention layer after the first, Qformer.py:211):

@@ -355,3 +355,27 @@ def test_consolidate_with_per_chunk_queries_equals_forward_chain(dev, case):
     for c in range(Cn):
         ref = orc.step(ks[c], q[c, 0], new_doc=(c == 0), u=u[c, 0])
     np.testing.assert_allclose(batched[-1, 0].cpu().numpy(), ref, rtol=0, atol=CTX_TOL)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c.name in ("cfg1_sticky", "headline", "peaked")], ids=lambda c: c.name)
+def test_consolidate_from_pooled_frames_is_bit_identical(dev, case):
+    """infv_ltm_consolidate_pooled(pool(k)) == infv_ltm_consolidate(k): contexts, draws and memory, bit for bit
+    (fast path and its continuation over a second call)."""
+    ks, qs, ws = case_inputs(case)
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    Cn = next((i for i, t in enumerate(case.chunk_T) if t != case.chunk_T[0]), len(case.chunk_T))
+    k = torch.from_numpy(np.stack(ks[:Cn])).to(dev)
+    q = torch.from_numpy(np.stack(qs)).to(dev)
+    u = torch.from_numpy(np.stack([np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)]) for c in range(Cn)])).to(dev)
+    a, b = _engine(case, dev), _engine(case, dev)
+    kbar = b.pool(k)
+    half = max(1, Cn // 2)
+    for lo, hi in ((0, half), (half, Cn)):
+        if lo == hi:
+            continue
+        xa = a.consolidate(k[lo:hi], q, projs, u[lo:hi], new_doc=(lo == 0)).clone()
+        xb = b.consolidate_pooled(kbar[lo:hi].contiguous(), q, projs, u[lo:hi], new_doc=(lo == 0)).clone()
+        assert torch.equal(xa, xb)
+    for l in range(case.n_layers):
+        np.testing.assert_array_equal(b.last_draw(l)[0], a.last_draw(l)[0])
+        assert torch.equal(b.export_state(l)[0], a.export_state(l)[0])

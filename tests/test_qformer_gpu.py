@@ -293,3 +293,24 @@ def test_encode_video_from_the_producer_layout_equals_the_list_path():
         yb, _ = b.encode_video(new_video=(c == 0))
         assert torch.equal(ya, yb)
         assert b.n_position == a.n_position
+
+
+def test_single_token_pass_equals_separate_pooling_and_per_layer_split(monkeypatch):
+    """One pass over the frame tokens (split + transpose + frame means, shared by both layers and their memories) gives
+    the same bits as the round-1 arrangement (infv_ltm_pool + one split pass per layer): per chunk and layer-major."""
+    dev = torch.device("cuda:0")
+    case = next(c for c in QF_CASES if c.alpha != 1.0 and len(set(c.chunk_T)) == 1 and c.chunk_T[0] % 2 == 0)
+    frames, weights = qf_inputs(case)
+    Cn = len(case.chunk_T)
+    k = torch.from_numpy(np.stack(frames)).to(dev)
+    u = torch.from_numpy(np.stack([chunk_uniforms(case, c) for c in range(Cn)]))
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("INFV_VQF_FUSE", fuse)            # read when the handle is created
+        m = make_model(case, weights, dev)
+        per_chunk = [m.encode_frames(k[c:c + 1], new_video=(c == 0), u=u[c])[0].clone() for c in range(Cn)]
+        llama, mean, hidden = m.encode_frames_batch(k, new_video=True, u=u, want_hidden=True)
+        torch.cuda.synchronize()
+        outs[fuse] = (torch.stack(per_chunk), llama.clone(), hidden.clone())
+    for a, b, what in zip(outs["1"], outs["0"], ("per chunk", "layer-major llama", "layer-major hidden")):
+        assert torch.equal(a, b), what
