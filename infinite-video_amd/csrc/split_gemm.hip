@@ -35,8 +35,23 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int b = blockIdx.z / g.splitk, s = blockIdx.z - b * g.splitk;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so neighbouring ids
+    // share nothing on chip.  Deal the ids of one XCD a contiguous run of the (m fastest, then n, then batch x split)
+    // order instead: the tiles that read the same B rows (and, for a contraction with few column tiles, the same A
+    // rows) are then resident on ONE XCD at the same time and the operand reaches that L2 once.  Before: 472 MB fetched
+    // per chunk of the video Q-former's four contractions against ~130 MB of operands (profiles/r02_qformer_fetch_*).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;            // bijective for any nwg
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)((v / gridDim.x) % gridDim.y);
+        bz = (int)(v / (gridDim.x * gridDim.y));
+    }
+    const int m0 = bx * 128, n0 = by * 128;
+    const int b = bz / g.splitk, s = bz - b * g.splitk;
     const int kbeg = s * g.k_per_split;
     const int kend = (kbeg + g.k_per_split > g.K) ? g.K : kbeg + g.k_per_split;
     const int ntiles = kend > kbeg ? (kend - kbeg) / kSBK : 0;
@@ -119,8 +134,190 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same contraction with 384 x 128 x 64 tiles: 4 waves stacked along M, each a 96 x 128 block of the output
+// (3 x 4 accumulators of 32 x 32).  Why: the 128 x 128 kernel above moves as many LDS bytes per k-tile (64 KB written,
+// 128 KB read back as fragments) as its MFMAs take cycles at 128 B/clock -- it is LDS-bound near 30 % of the bf16 MFMA
+// peak.  A 3 x 4 register block reads 14 KB of fragments per 36 MFMAs instead of 8 KB per 12: LDS time is 61 % of the
+// MFMA time, and a B row reaches the chip once for all 384 rows of A (H*Q = 384 query rows in the video Q-former).
+// 144 KB of LDS: one workgroup per CU, accumulators in the AGPR half of the register file.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kWI = 3, kWJ = 4;                   // 32 x 32 accumulators per wave: kWI along M, kWJ along N
+constexpr int kWRowsA = 4 * 32 * kWI;             // 384 rows of A per workgroup
+constexpr int kWRowsB = 32 * kWJ;                 // 128 rows of B
+constexpr int kWArrA = kWRowsA * kSPitch, kWArrB = kWRowsB * kSPitch;
+constexpr int kWLds = 2 * kWArrA + 2 * kWArrB;    // A_hi, A_lo, B_hi, B_lo
+constexpr int kWVecA = kWRowsA * 8 / 256, kWVecB = kWRowsB * 8 / 256;   // 16-byte vectors per thread per array tile
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_kernel(SplitGemm g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {   // XCD-aware tile order (see split_gemm_kernel)
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)((v / gridDim.x) % gridDim.y);
+        bz = (int)(v / (gridDim.x * gridDim.y));
+    }
+    const int m0 = bx * kWRowsA, n0 = by * kWRowsB;
+    const int b = bz / g.splitk, s = bz - b * g.splitk;
+    const int kbeg = s * g.k_per_split;
+    const int kend = (kbeg + g.k_per_split > g.K) ? g.K : kbeg + g.k_per_split;
+    const int ntiles = kend > kbeg ? (kend - kbeg) / kSBK : 0;
+    float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
+
+    // staging: 8 lanes per row (one 128-B line of a row's k-tile per 8 lanes); vector e = tid + 256 * v -> (row e >> 3, seg e & 7)
+    const int seg = tid & 7, r8 = tid >> 3;                       // rows r8, r8 + 32, ...
+    const __bf16* a_hi = g.A_hi + (long)b * g.strideA + kbeg + seg * 8;
+    const __bf16* a_lo = g.A_lo + (long)b * g.strideA + kbeg + seg * 8;
+    const __bf16* b_hi = g.B_hi + (long)b * g.strideB + kbeg + seg * 8;
+    const __bf16* b_lo = g.B_lo + (long)b * g.strideB + kbeg + seg * 8;
+    // Named registers, not arrays: hipcc (ROCm 7.2) leaves a 512-B staging array in scratch memory even when every index is
+    // a constant after unrolling, which turns the prefetch into load -> wait -> scratch store -> scratch load -> ds_write.
+#define INFV_WA(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+#define INFV_WB(X) X(0) X(1) X(2) X(3)
+    static_assert(kWVecA == 12 && kWVecB == 4, "staging macros are written for 384 x 128 x 64 tiles");
+#define INFV_DECL_A(v) uint4 rah##v, ral##v;
+#define INFV_DECL_B(v) uint4 rbh##v, rbl##v;
+    INFV_WA(INFV_DECL_A) INFV_WB(INFV_DECL_B)
+    // (M % 384 == 0 and N % 128 == 0, checked by the launcher: every load is unconditional and its address affine in v --
+    // a conditional load makes the compiler branch, and drain vmcnt, around every pair of loads)
+    const long oa = (long)(m0 + r8) * g.lda, ob = (long)(n0 + r8) * g.ldb;
+    const long sa = 32 * g.lda, sb = 32 * g.ldb;
+#define INFV_LD_A(v) rah##v = *reinterpret_cast<const uint4*>(a_hi + oa + v * sa + kt); ral##v = *reinterpret_cast<const uint4*>(a_lo + oa + v * sa + kt);
+#define INFV_LD_B(v) rbh##v = *reinterpret_cast<const uint4*>(b_hi + ob + v * sb + kt); rbl##v = *reinterpret_cast<const uint4*>(b_lo + ob + v * sb + kt);
+#define INFV_WIDE_LOAD(t) { const long kt = (long)(t) * kSBK; INFV_WA(INFV_LD_A) INFV_WB(INFV_LD_B) }
+    const int st0 = r8 * kSPitch + seg * 16;
+#define INFV_ST_A(v) *reinterpret_cast<uint4*>(smem + st0 + v * 32 * kSPitch) = rah##v; *reinterpret_cast<uint4*>(smem + kWArrA + st0 + v * 32 * kSPitch) = ral##v;
+#define INFV_ST_B(v) *reinterpret_cast<uint4*>(smem + 2 * kWArrA + st0 + v * 32 * kSPitch) = rbh##v; *reinterpret_cast<uint4*>(smem + 2 * kWArrA + kWArrB + st0 + v * 32 * kSPitch) = rbl##v;
+#define INFV_WIDE_STORE() { INFV_WA(INFV_ST_A) INFV_WB(INFV_ST_B) }
+
+    floatx16 acc[kWI][kWJ];
+#pragma unroll
+    for (int i = 0; i < kWI; ++i)
+#pragma unroll
+        for (int j = 0; j < kWJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, kh = lane >> 5;
+    if (ntiles > 0) INFV_WIDE_LOAD(0);
+    for (int t = 0; t < ntiles; ++t) {
+        INFV_WIDE_STORE();
+        __syncthreads();
+        INFV_WIDE_LOAD(t + 1 < ntiles ? t + 1 : t);   // (the last iteration re-reads its own tile: no branch around the loads)
+#pragma unroll
+        for (int ks = 0; ks < kSBK / 16; ++ks) {
+            bf16x8 ah[kWI], al[kWI], bh[kWJ], bl[kWJ];
+#pragma unroll
+            for (int i = 0; i < kWI; ++i) {
+                const int off = (wave * 32 * kWI + i * 32 + li) * kSPitch + ks * 32 + kh * 16;
+                ah[i] = *reinterpret_cast<const bf16x8*>(smem + off);
+                al[i] = *reinterpret_cast<const bf16x8*>(smem + kWArrA + off);
+            }
+#pragma unroll
+            for (int j = 0; j < kWJ; ++j) {
+                const int off = (j * 32 + li) * kSPitch + ks * 32 + kh * 16;
+                bh[j] = *reinterpret_cast<const bf16x8*>(smem + 2 * kWArrA + off);
+                bl[j] = *reinterpret_cast<const bf16x8*>(smem + 2 * kWArrA + kWArrB + off);
+            }
+            // the three products as three sweeps over the accumulators: consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int i = 0; i < kWI; ++i)
+#pragma unroll
+                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < kWI; ++i)
+#pragma unroll
+                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < kWI; ++i)
+#pragma unroll
+                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < kWI; ++i)
+#pragma unroll
+        for (int j = 0; j < kWJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 * kWI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int o = n0 + j * 32 + li;
+                C[(long)m * g.ldc + o] = acc[i][j][r];
+            }
+#undef INFV_WIDE_LOAD
+#undef INFV_WIDE_STORE
+#undef INFV_WA
+#undef INFV_WB
+#undef INFV_DECL_A
+#undef INFV_DECL_B
+#undef INFV_LD_A
+#undef INFV_LD_B
+#undef INFV_ST_A
+#undef INFV_ST_B
+}
+
+// the wide tiles need whole 384 x 128 tiles and enough of them to fill the chip
+bool split_gemm_wide_applies(const SplitGemm& g) {
+    static const int mode = [] { const char* e = getenv("INFV_SPLIT_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    if (!mode) return false;
+    if (g.M % kWRowsA || g.N % kWRowsB) return false;               // whole tiles only (unconditional loads and stores)
+    const long mt = g.M / kWRowsA;
+    const long wgs = mt * ((g.N + kWRowsB - 1) / kWRowsB) * g.nbatch * g.splitk;
+    return mode > 1 || wgs >= 192;
+}
+
+// split-K count (and k per split, a multiple of 64) that fills the 256 CUs best with whichever tile shape will run
+int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split) {
+    const int ktiles = K / kSBK;
+    auto best_for = [&](long tiles, int* sk_out) {
+        double best = -1.0; int bsk = 1;
+        for (int sk = 1; sk <= 16 && sk <= ktiles; ++sk) {
+            const int per = (ktiles + sk - 1) / sk;
+            if ((long)per * (sk - 1) >= ktiles) continue;             // an empty last split
+            const long wgs = tiles * sk;
+            const double eff = (double)tiles * ktiles / ((double)((wgs + 255) / 256) * 256.0 * per) - 0.004 * sk;
+            if (eff > best) { best = eff; bsk = sk; }
+        }
+        *sk_out = bsk;
+        return best;
+    };
+    int sk = 1;
+    SplitGemm probe{};
+    probe.M = M; probe.N = N; probe.K = K; probe.nbatch = nbatch;
+    const long tiles_w = (long)((M + kWRowsA - 1) / kWRowsA) * ((N + kWRowsB - 1) / kWRowsB) * nbatch;
+    int sk_w = 1;
+    best_for(tiles_w, &sk_w);
+    probe.splitk = sk_w;
+    if (split_gemm_wide_applies(probe)) sk = sk_w;
+    else best_for((long)((M + 127) / 128) * ((N + 127) / 128) * nbatch, &sk);
+    *k_per_split = ((ktiles + sk - 1) / sk) * kSBK;
+    return sk;
+}
+
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad) {
     if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0) return hipSuccess;
+    if (lds_pad <= 0 && split_gemm_wide_applies(g)) {
+        static bool attr_w = false;
+        if (!attr_w) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_wide_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_w = true;
+        }
+        if (g.K % kSBK || g.k_per_split % kSBK || g.k_per_split <= 0 || g.lda % 8 || g.ldb % 8 || g.strideA % 8 || g.strideB % 8)
+            return hipErrorInvalidValue;
+        dim3 grid((g.M + kWRowsA - 1) / kWRowsA, (g.N + kWRowsB - 1) / kWRowsB, g.nbatch * g.splitk);
+        hipLaunchKernelGGL(split_gemm_wide_kernel, grid, dim3(256), kWLds, stream, g);
+        return hipGetLastError();
+    }
     {                                                   // tiles live in dynamic LDS; `lds_pad` more (unused) bytes cap the kernel at one workgroup per CU
         static bool attr_set = false;
         if (!attr_set) {
@@ -275,9 +472,71 @@ __global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* __
     }
 }
 
+// The same softmax for rows of up to 1024 * NV floats, each row read ONCE: a thread keeps its NV float4 in registers
+// between the max, the sum and the write (same per-thread order of operations as the three-pass kernel above: same bits).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_split_reg_kernel(const float* __restrict__ S, int len, long ld,
+                                                                     __bf16* __restrict__ Ph, __bf16* __restrict__ Pl, long ld_out) {
+    __shared__ float red[4];
+    const float* row = S + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    floatx4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (c < len) {
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(row + c));
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+        }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (c < len) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = expf(v[i][k] - mx);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    __bf16* ph = Ph + (long)blockIdx.x * ld_out;
+    __bf16* pl = Pl + (long)blockIdx.x * ld_out;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (c < len) {
+            __bf16 h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split2(v[i][k] * inv, h[k], l[k]);
+            *reinterpret_cast<uint2*>(ph + c) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+            *reinterpret_cast<uint2*>(pl + c) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+        }
+    }
+}
+
 hipError_t launch_softmax_rows_split(const float* S, long n_rows, int len, long ld, void* Ph, void* Pl, long ld_out,
                                      hipStream_t stream) {
     if (len % 4 || ld % 4 || ld_out % 4) return hipErrorInvalidValue;
+    if (len <= 2048) {
+        hipLaunchKernelGGL(softmax_rows_split_reg_kernel<2>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
+                           static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
+        return hipGetLastError();
+    }
+    if (len <= 8192) {
+        hipLaunchKernelGGL(softmax_rows_split_reg_kernel<8>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
+                           static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(softmax_rows_split_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
                        static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
     return hipGetLastError();

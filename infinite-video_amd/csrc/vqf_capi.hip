@@ -132,10 +132,7 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
     int kps = n_tokens;
     int sk = qf_pick_splitk_fill(rows, d, n_tokens, nb, &kps);
-    if (n_tokens % 64 == 0) {                                 // the split-bf16 kernel works on 64-deep k-tiles
-        kps = (kps + 63) / 64 * 64;
-        sk = (n_tokens + kps - 1) / kps;
-    }
+    if (split_path(h, n_tokens)) sk = split_gemm_pick_splitk(rows, d, n_tokens, nb, &kps);   // (64-deep k-tiles, its own tile shapes)
     const int nq = shared_q ? 1 : nb;
     // leading dimension of the score matrix: padded by 256 B so that its rows (the A operand of the second
     // contraction, one 128-B line per row per k-tile) do not all map to the same memory channel
@@ -431,6 +428,10 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
             const double eff = (double)t / (double)(((t + 255) / 256) * 256);
             if (eff >= best - 1e-9) { best = eff; NB = nb; }
         }
+    }
+    {
+        static const int nb_env = [] { const char* e = getenv("INFV_VQF_NB"); return e ? atoi(e) : 0; }();   // (sweeps)
+        if (nb_env > 0) NB = nb_env < C ? nb_env : C;
     }
     {
         const size_t act = (size_t)M * Hd * sizeof(float);
