@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=2048, help="chunks of the synthetic video (whole job)")
     ap.add_argument("--batch-chunks", type=int, default=42,
-                    help="largest sub-batch (the library uses 28 for calls shorter than 768 chunks, e.g. multi-GPU shards)")
+                    help="largest sub-batch (the library uses 32 for calls shorter than 768 chunks, e.g. multi-GPU shards)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode-video", action="store_true", help="skip the secondary per-chunk Q-former leg")
@@ -322,7 +322,7 @@ def main():
         shard256_ms = 1e3 * sorted(ts)[len(ts) // 2]
 
     # ---- the HBM-bound kernel on its own (no other stream running): 5 launches of one sub-batch ----
-    nb = min(args.batch_chunks if c_local >= 768 else min(args.batch_chunks, 28), c_local)
+    nb = min(args.batch_chunks if c_local >= 768 else min(args.batch_chunks, 32), c_local)
     eng.pool(k[:nb])
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -33,7 +33,7 @@ namespace {
 // INFV_VPROJ_ON_UC (default on): in the sub-batch pipeline only the SCORE half of the new-row projection stays on the
 // side stream (role S waits for it); the V' half, which only the UC kernel reads, is issued on the UC stream right
 // before that kernel -- the side stream stops being the longest of the three.
-bool vproj_on_uc() { static const bool v = [] { const char* e = getenv("INFV_VPROJ_ON_UC"); return !e || atoi(e) != 0; }(); return v; }
+// (the per-handle choice: infv_ltm_s::vproj_on_uc)
 
 int skip_mask() { static const int m = [] { const char* e = getenv("INFV_SKIP"); return e ? atoi(e) : 0; }(); return m; }
 
@@ -126,7 +126,7 @@ struct infv_ltm_s {
     hipStream_t aux = nullptr;          // V' projection + softmax weights of a sub-batch (feeds the UC kernel)
     hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_in = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
     DeviceBuf Sp[2], cqbuf;
@@ -143,6 +143,13 @@ struct infv_ltm_s {
     unsigned int* err_host = nullptr; unsigned int* err_dev = nullptr;
     int k_bf16 = 0;                     // frame tokens arrive as bf16 (infv_ltm_set_token_dtype)
     bool v_split = false;               // INFV_VPROJ_SPLIT=1 at create: V' half of the sub-batch projection as a split-bf16 contraction
+    // Where the V' half of a sub-batch's projection runs.  Long calls: on the UC stream, as its own GEMM (the side stream then
+    // delivers the score half, which the chain waits for, sooner).  Short calls (< 768 chunks, e.g. the 256-chunk shard of an
+    // 8-GPU run): inside the side stream's one [V' | S'] GEMM -- there the UC stream (V' GEMM -> softmax weights -> update, 275 us
+    // per 28 chunks against 150 us of chain) is the critical path; a 256-chunk call drops from 3.17 to 2.81 ms.
+    // INFV_VPROJ_ON_UC=0/1 at create forces either; the split-bf16 V' projection implies the UC stream.
+    int v_on_uc_mode = -1;
+    bool vproj_on_uc(int n_chunks) const { return v_on_uc_mode >= 0 ? v_on_uc_mode != 0 : (v_split || n_chunks >= 768); }
     int spin_limit = 1 << 22; int expect_extra = 0;     // INFV_CHAIN_FAULT=1 (tests): expect one arrival too many -> every wait times out
     int32_t* trace_bins = nullptr; float* trace_probs = nullptr; long trace_cap = 0;   // draw trace of consolidate (caller's device buffers)
     DeviceBuf bins_forced; unsigned forced_mask = 0;    // one-shot forced draw of the per-call path
@@ -160,6 +167,8 @@ struct infv_ltm_s {
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_q) (void)hipEventDestroy(ev_q);
         for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
         if (err_host) (void)hipHostFree(err_host);
     }
@@ -366,6 +375,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (e == hipSuccess) e = h->bins_forced.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (const char* f = getenv("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
     if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
+    if (const char* f = getenv("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
     h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
@@ -852,6 +862,8 @@ int ensure_side_stream(infv_ltm_handle h) {
     HIP_TRY(hipStreamCreateWithPriority(&h->pools, hipStreamNonBlocking, lo));
     HIP_TRY(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
     return INFV_OK;
 }
 
@@ -900,6 +912,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
+    // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
+    HIP_TRY(hipEventRecord(h->ev_start, stream));
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
     {   // rings of role S's per-chunk outputs (sized for this call's Q)
         const size_t need_a = (size_t)h->ring * pipe.alpha_slot() * sizeof(float);
@@ -915,6 +929,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     hipStream_t side = h->side, ucs = h->ucs;
     // pre-multiplied queries qt = (q/sqrt(dh)) . Wk_h and the bias term cq = q_h . bk_h / sqrt(dh), once per call
     HIP_TRY(launch_qtilde(q, Q, h->H, h->d, h->L, pp, h->qt_buf.as<float>(), h->cqbuf.as<float>(), stream));
+    HIP_TRY(hipEventRecord(h->ev_q, stream));                 // the side stream's projections need no more than this
     int c = 0;
     bool uc_pending[3] = {false, false, false};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
@@ -954,12 +969,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
     const int first_c = c;
     // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
-    // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 28 so that the
+    // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 32 so that the
     // pipeline fills and drains quickly.  INFV_SUB_BATCH overrides.
     static const int sub_env = [] { const char* e = getenv("INFV_SUB_BATCH"); return e ? atoi(e) : 0; }();
     int sub = h->maxC;
     if (sub_env > 0) sub = sub_env < h->maxC ? sub_env : h->maxC;
-    else if (n_chunks < 768 && sub > 28) sub = 28;
+    else if (n_chunks < 768 && sub > 32) sub = 32;             // (28 while the V' GEMM ran on the UC stream; 2.84 -> 2.68 ms per 256 chunks)
     const int n_batches = (n_chunks - first_c + sub - 1) / sub;
     const size_t rows = plan->inf.rows;
     std::vector<int> sks(n_batches > 0 ? n_batches : 1, 1);
@@ -977,7 +992,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // ones either way.  Kept as an option (parity-tested) for configurations where role S is the longest stream.
     static const bool want_wc = [] { const char* e = getenv("INFV_WHOLE_CALL"); return e && atoi(e) != 0; }();
     const int s_blocks = h->H * chain_s_tiles(Q) * h->L;
-    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && vproj_on_uc() && !(skip_mask() & 8) &&
+    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && h->vproj_on_uc(n_chunks) && !(skip_mask() & 8) &&
                     chain_batch2_shape_ok(h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S, Q);
     if (wc) {
         // the kernel holds the addresses of all three workspace sets: size them before it is launched
@@ -1030,7 +1045,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
         const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
-                                         vproj_on_uc())) return rc;
+                                         h->vproj_on_uc(n_chunks))) return rc;
         // gemm_ready: the chain may enter batch b.  Before the event, so that whoever waits for this batch's projection
         // (the UC stream, and through it the join of the call) also waits for the counter update: the next call resets it
         if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 0, side));
@@ -1040,8 +1055,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     };
     if (n_batches > 0) {
         HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
-        HIP_TRY(hipStreamWaitEvent(side, h->ev_in, 0));
-        if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_in, 0));
+        HIP_TRY(hipStreamWaitEvent(side, wc ? h->ev_in : h->ev_q, 0));   // (whole-call mode: also after the counters' reset)
+        if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_start, 0));
         if (wc) HIP_TRY(hipStreamWaitEvent(ucs, h->ev_in, 0));   // its gate kernels must not read the counters before their reset
         if (int rc = stage_pool(0)) return rc;
         if (n_batches > 1)
@@ -1104,7 +1119,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         // 18.0 ms per video): a fifth concurrent kernel slows role S and the GEMMs more than the shorter chain gains.
         static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
         hipStream_t vs = use_aux ? h->aux : ucs;
-        if (vproj_on_uc() && (long)nb * plan->inf.rows >= 1024 && !(skip_mask() & 2)) {
+        if (h->vproj_on_uc(n_chunks) && (long)nb * plan->inf.rows >= 1024 && !(skip_mask() & 2)) {
             // V' half of this sub-batch's projection: needs the new rows (ev_p), feeds only the UC kernel below
             HIP_TRY(hipStreamWaitEvent(vs, h->ev_p[set], 0));
             Timed t_(h->prof, INFV_KERNEL_PROJECT, vs);

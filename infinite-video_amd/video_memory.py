@@ -86,8 +86,8 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
     This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
     raises if the persistent chain kernel reported a failure instead of passing an invalid memory on."""
     ctx = engine.consolidate(k_local, q, projs, u_local, new_doc=True)
-    engine.sync()
-    payload = pack_local_memory(engine, ctx)
+    payload = pack_local_memory(engine, ctx)         # stream-ordered behind the consolidation: no host round trip in between
+    engine.sync()                                    # a latched chain failure raises here, before anything is handed on
     have_group = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if have_group else 1
     if have_group:
