@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode-video", action="store_true", help="skip the secondary per-chunk Q-former leg")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the split-bf16 V' projection line")
     return ap.parse_args()
 
 
@@ -307,6 +308,29 @@ def main():
         check = selfcheck(LTMEngine, dev, k, q, projs, u, ctx_chk, trace, args.batch_chunks)
         del trace
 
+    # ---- secondary line (N = 1): the same call with the V' half of the projection as three bf16 MFMA products
+    #      (INFV_VPROJ_SPLIT=1 at engine creation).  V' only feeds the read-out (1e-3 budget); the draw is unchanged. ----
+    vsplit = None
+    if world == 1 and not args.no_secondary and os.environ.get("INFV_VPROJ_SPLIT", "0") in ("", "0"):
+        os.environ["INFV_VPROJ_SPLIT"] = "1"
+        try:
+            eng2 = LTMEngine(N, H, DH, D, P, tau=TAU, sticky=True, n_layers=L, max_q=Q, device=dev,
+                             max_batch_chunks=args.batch_chunks)
+        finally:
+            del os.environ["INFV_VPROJ_SPLIT"]
+        for _ in range(2):
+            consolidate_video(eng2, k, q, projs, u)
+        torch.cuda.synchronize()
+        n2 = max(1, min(args.steps, 40))
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            ctx2, _ = consolidate_video(eng2, k, q, projs, u)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        vsplit = {"dtype": "f32 (V' projection bf16x3)", "value": args.chunks * n2 / dt2, "unit": "frame-chunks/s",
+                  "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "max_abs_diff_vs_f32": float((ctx2 - ctx).abs().max())}
+        del eng2, ctx2
+
     # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing ----
     shard256_ms = None
     if world == 1 and c_local >= 256:
@@ -377,6 +401,20 @@ def main():
                         "chunks_per_s": n_enc / dt, "ms_per_chunk": 1e3 * dt / n_enc, "chunks": n_enc,
                         "short_attention_gflop_per_chunk": flop / 1e9,
                         "short_attention_tflops_over_whole_chunk_time": flop * n_enc / dt / 1e12}
+        # the same model, layer-major over a whole video (infv_vqf_encode_video: frame tokens read once per chunk)
+        n_lm = min(252, c_local)
+        u_lm = torch.from_numpy(synth.gibbs_uniforms(n_lm, L)).to(dev)
+        model.encode_frames_batch(k[:n_lm], new_video=True, u=u_lm)     # full-size warm-up: workspaces grow here
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            model.encode_frames_batch(k[:n_lm], new_video=True, u=u_lm)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        dt = sorted(ts)[1]
+        encode_video["layer_major"] = {"chunks": n_lm, "chunks_per_s": n_lm / dt, "ms_per_chunk": 1e3 * dt / n_lm,
+                                       "short_attention_tflops_over_whole_chunk_time": flop * n_lm / dt / 1e12}
         del model
 
     if rank == 0:
@@ -400,6 +438,8 @@ def main():
             out["selfcheck_max_abs_err"] = check["max_abs_err"]
         if shard256_ms is not None:
             out["shard256_ms"] = shard256_ms
+        if vsplit is not None:
+            out["secondary_vproj_bf16x3"] = vsplit
         if encode_video is not None:
             out["encode_video"] = encode_video
         if world == 1 and not args.no_cpu_baseline:

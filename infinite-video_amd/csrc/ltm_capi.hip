@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -159,10 +160,11 @@ struct infv_ltm_s {
     Profiler prof;
     ~infv_ltm_s() {
         for (auto& kv : plans) delete kv.second;
-        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-        if (ucs) { (void)hipStreamSynchronize(ucs); (void)hipStreamDestroy(ucs); }
-        if (pools) { (void)hipStreamSynchronize(pools); (void)hipStreamDestroy(pools); }
-        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+        // (the streams belong to the process-wide pool, see shared_streams(): synchronise, do not destroy)
+        if (side) (void)hipStreamSynchronize(side);
+        if (ucs) (void)hipStreamSynchronize(ucs);
+        if (pools) (void)hipStreamSynchronize(pools);
+        if (aux) (void)hipStreamSynchronize(aux);
         for (int i = 0; i < 3; ++i) if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
@@ -384,6 +386,10 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (e == hipSuccess) e = h->bins.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (e == hipSuccess) e = h->idx.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (e == hipSuccess) e = h->scores.reserve((size_t)h->L * h->H * h->maxQ * h->N * sizeof(float));
+    // what infv_ltm_get_draw returns before any draw has happened (non-sticky handles never draw) is defined: zeros
+    if (e == hipSuccess) e = hipMemset(h->probs.p, 0, h->probs.bytes);
+    if (e == hipSuccess) e = hipMemset(h->bins.p, 0, h->bins.bytes);
+    if (e == hipSuccess) e = hipMemset(h->idx.p, 0, h->idx.bytes);
     if (e != hipSuccess) {
         delete h;
         return fail(INFV_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e));
@@ -846,9 +852,54 @@ int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const floa
     return INFV_OK;
 }
 
+// The worker streams are shared by every handle of a device.  The HIP runtime multiplexes a process's streams onto a few
+// hardware queues (4 by default, GPU_MAX_HW_QUEUES): a second handle with four more streams of its own shared queues with
+// the first one's and its pipeline ran 12 % slower (107 k against 120 k chunks/s for the second engine of bench.py).
+// Handles are not re-entrant and their calls are issued from one host thread at a time, so FIFO order within a shared
+// stream is the order the host issued the work in; cross-stream dependencies are events, as before.
+struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr, aux = nullptr; };
+int shared_streams(int dev, SharedStreams** out) {
+    static std::mutex mu;
+    static SharedStreams pool[64];
+    if (dev < 0 || dev >= 64) return fail(INFV_ERR_INVALID, "device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    SharedStreams& p = pool[dev];
+    if (!p.side) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent
+        HIP_TRY(hipStreamCreateWithFlags(&p.ucs, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, lo));
+        static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
+        if (use_aux) HIP_TRY(hipStreamCreateWithPriority(&p.aux, hipStreamNonBlocking, lo));
+        HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, lo));   // last: marks the set complete
+    }
+    *out = &p;
+    return INFV_OK;
+}
+
+}  // namespace
+
+namespace infv {
+// the normal-priority worker stream of the shared set, for the video Q-former's layer-major schedule (its side stream
+// runs the per-call LTM chain of the later layers while the caller's stream runs their short-term attention)
+int shared_worker_stream(hipStream_t* out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    SharedStreams* sh = nullptr;
+    if (int rc = shared_streams(dev, &sh)) return rc;
+    *out = sh->ucs;
+    return INFV_OK;
+}
+}  // namespace infv
+
+namespace {
 int ensure_side_stream(infv_ltm_handle h) {
     if (h->side) return INFV_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&h->ucs, hipStreamNonBlocking));
+    SharedStreams* sh = nullptr;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));                              // (the caller's current device: where the handle was created)
+    if (int rc = shared_streams(dev, &sh)) return rc;
+    h->ucs = sh->ucs; h->pools = sh->pools; h->aux = sh->aux;
     for (int i = 0; i < 3; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_s[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
@@ -856,14 +907,10 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
     }
-    int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least urgent
-    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
-    HIP_TRY(hipStreamCreateWithPriority(&h->pools, hipStreamNonBlocking, lo));
-    HIP_TRY(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
+    h->side = sh->side;                                       // last: h->side != nullptr means "streams and events exist"
     return INFV_OK;
 }
 

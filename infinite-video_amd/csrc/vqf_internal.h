@@ -59,6 +59,7 @@ struct SplitGemm {
     int M, N, K, k_per_split, splitk, nbatch;
 };
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad = 0);
+int shared_worker_stream(hipStream_t* out);   // ltm_capi.hip: the process-wide worker streams
 int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split);   // fills the chip with the tile shape that will run
 // x [rows][cols] fp32 -> hi = bf16(x), lo = bf16(x - hi)
 hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, void* hi, void* lo, long ld_out, hipStream_t stream);

@@ -4,10 +4,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encode-video > $out/bench_trace.json 2> $out/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encode-video --no-secondary > $out/bench_trace.json 2> $out/trace.err
 export INFV_SUB_BATCH=42   # the PMC passes run a 252-chunk video: force the 42-chunk launches of the full-length run (6 full launches)
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck > $out/bench_fetch.json 2> $out/fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck > $out/bench_write.json 2> $out/write.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_fetch.json 2> $out/fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_write.json 2> $out/write.err
 unset INFV_SUB_BATCH
 python3 - <<PY
 import csv,glob,collections,json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): tools/quick_bench.sh <tag> [steps]  -- short headline bench line + per-kernel ms, no CPU legs
 tag=$1; steps=${2:-10}
-python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-encode-video > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-encode-video --no-secondary > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$tag.json"))
