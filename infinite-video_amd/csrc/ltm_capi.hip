@@ -951,11 +951,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         return INFV_OK;
     }
     if (int rc = ensure_side_stream(h)) return rc;
-    // Padding LDS caps the pooling kernel's occupancy at ONE 512-thread workgroup (88 KB) per CU, so a role-S workgroup
+    // Padding LDS caps the pooling kernel's occupancy at ONE 512-thread workgroup (84 KB: two do not fit, one leaves room for
+    // a 74 KB workgroup of the loader-wave GEMM) per CU, so a role-S workgroup
     // always finds LDS and wave slots and the pool's bytes in flight stay bounded.  The GEMMs carry no padding any more
     // (INFV_GEMM_PAD): their workgroups (36 KB, one wave per SIMD) co-reside with a pooling workgroup -- MFMA work beside
     // memory work -- instead of taking the CU away from it.
-    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 88 * 1024; }();
+    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 84 * 1024; }();
     static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call

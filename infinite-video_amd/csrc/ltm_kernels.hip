@@ -293,6 +293,133 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             }
 }
 
+// ======================================================================================
+// 3b. The same GEMM with dedicated LOADER waves (sub-batch projections of the fast path; INFV_GEMM_LW=0 disables).  While the pooling kernel streams on the same CU every
+//     vector-memory instruction waits ~0.2 us at issue; in gemm_nt_kernel the wave that issues a tile's 8 loads is the
+//     wave that should be issuing its 64 MFMAs, so the kernel runs at 50-55 TFLOP/s in situ against 88 alone.  Here waves
+//     0-3 only read LDS and issue MFMAs (same fragment reads, same MFMA order: same bits) and waves 4-7 only move tiles:
+//     global -> registers three tiles ahead (three register sets) -> LDS one tile ahead (two buffers), ONE barrier per
+//     k-tile, which orders LDS traffic only (no vmcnt drain).  Measured in situ (2048-chunk video): the two projection GEMMs
+//     10.3 -> 7.1 ms busy, 111 k -> 115 k chunks/s (with the pooling kernel's padding LDS at 84 KB, so that a 74 KB
+//     workgroup of this kernel still fits beside a pooling workgroup).
+// ======================================================================================
+__device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BM, int BN, int NT>
+__global__ __launch_bounds__(512) void gemm_nt_lw_kernel(const float* __restrict__ A, int M, int K, WSegs segs,
+                                                         float* __restrict__ C, int ldc, long split_stride) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int kBuf = (BM + BN) * kLdsStride;       // floats per LDS buffer
+    extern __shared__ __attribute__((aligned(16))) float lw_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    constexpr int ntiles = NT;                         // k-tiles per split: a compile-time constant, so that the loader's
+    const int kbeg = blockIdx.z * (NT * kBK);          // loop unrolls completely and every vmcnt wait is an exact count
+    C += (long)blockIdx.z * split_stride;
+
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int lt = tid - 256;
+        const int c4 = lt & 7, row0 = lt >> 3;
+        const float* a_src[AR];
+        const float* b_src[BR];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + row0 + 32 * i;
+            a_src[i] = A + (long)(m < M ? m : M - 1) * K + kbeg + c4 * 4;     // rows past M: clamped (their outputs are dropped)
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int o = n0 + row0 + 32 * i;
+            int seg = 0;
+            while (o >= segs.start[seg + 1]) ++seg;
+            b_src[i] = segs.base[seg] + (long)(o - segs.start[seg]) * K + kbeg + c4 * 4;
+        }
+        floatx4 a0[AR], b0[BR], a1[AR], b1[BR], a2[AR], b2[BR];
+#define INFV_LW_LOAD(t, ar, br)                                                                              \
+        {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) ar[i] = *reinterpret_cast<const floatx4*>(a_src[i] + (t) * kBK); \
+            _Pragma("unroll") for (int i = 0; i < BR; ++i) br[i] = *reinterpret_cast<const floatx4*>(b_src[i] + (t) * kBK); \
+        }
+#define INFV_LW_STORE(t, ar, br)                                                                             \
+        {                                                                                                    \
+            float* As_ = lw_smem + ((t) & 1) * kBuf;                                                         \
+            float* Bs_ = As_ + BM * kLdsStride;                                                              \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                   \
+                *reinterpret_cast<floatx4*>(&As_[(row0 + 32 * i) * kLdsStride + c4 * 4]) = ar[i];            \
+            _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                   \
+                *reinterpret_cast<floatx4*>(&Bs_[(row0 + 32 * i) * kLdsStride + c4 * 4]) = br[i];            \
+        }
+        // NT % 3 == 0.  Straight-line code (full unroll): in a rolled loop, or with loads behind conditions, the compiler's
+        // wait-count analysis falls back to vmcnt(0) at the first store of an iteration, which drains the two tiles that
+        // should stay in flight.
+        static_assert(NT % 3 == 0 && NT >= 3, "three register sets");
+        constexpr int last = NT - 1;
+        INFV_LW_LOAD(0, a0, b0);
+        INFV_LW_LOAD(1, a1, b1);
+        INFV_LW_LOAD(2, a2, b2);
+#pragma unroll
+        for (int t = 0; t < NT; t += 3) {
+            INFV_LW_STORE(t, a0, b0);
+            INFV_LW_LOAD(t + 3 < last ? t + 3 : last, a0, b0);
+            lds_only_barrier();
+            INFV_LW_STORE(t + 1, a1, b1);
+            INFV_LW_LOAD(t + 4 < last ? t + 4 : last, a1, b1);
+            lds_only_barrier();
+            INFV_LW_STORE(t + 2, a2, b2);
+            INFV_LW_LOAD(t + 5 < last ? t + 5 : last, a2, b2);
+            lds_only_barrier();
+        }
+#undef INFV_LW_LOAD
+#undef INFV_LW_STORE
+        return;
+    }
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int li = lane & 31, kk = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        lds_only_barrier();                              // tile t is in buffer t & 1
+        const float* As = lw_smem + (t & 1) * kBuf;
+        const float* Bs = As + BM * kLdsStride;
+        floatx4 af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                af[i][v] = *reinterpret_cast<const floatx4*>(&As[(wm * (BM / 2) + i * 32 + li) * kLdsStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                bf[j][v] = *reinterpret_cast<const floatx4*>(&Bs[(wn * (BN / 2) + j * 32 + li) * kLdsStride + 16 * kk + 4 * v]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int o = n0 + wn * (BN / 2) + j * 32 + li;
+                if (m < M) __builtin_nontemporal_store(acc[i][j][r], &C[(long)m * ldc + o]);
+            }
+}
+
 static void segs_clear(WSegs& s) {
     for (int i = 0; i < kMaxSegs; ++i) s.base[i] = nullptr;
     for (int i = 0; i <= kMaxSegs; ++i) s.start[i] = 0x7fffffff;
@@ -324,6 +451,28 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
+    }
+    static const bool want_lw = [] { const char* e = getenv("INFV_GEMM_LW"); return !e || atoi(e) != 0; }();   // default on
+    if (want_lw && M >= 1024 && lds_pad <= 0 && k_per_split == 24 * kBK) {
+        static bool attr_lw = false;
+        if (!attr_lw) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_lw_kernel<128, 128, 24>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_lw_kernel<64, 128, 24>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+            attr_lw = true;
+        }
+        if (((M + 127) / 128) * (n_cols / 128) <= 160 && ((M + 63) / 64) * (n_cols / 128) <= 256) {
+            dim3 grid((M + 63) / 64, n_cols / 128, splitk);
+            hipLaunchKernelGGL((gemm_nt_lw_kernel<64, 128, 24>), grid, dim3(512), 2 * (64 + 128) * kLdsStride * sizeof(float), stream,
+                               A, M, K, segs, C, ldc, split_stride);
+        } else {
+            dim3 grid((M + 127) / 128, n_cols / 128, splitk);
+            hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), 2 * (128 + 128) * kLdsStride * sizeof(float), stream,
+                               A, M, K, segs, C, ldc, split_stride);
+        }
+        return hipGetLastError();
     }
     if (M >= 1024 && ((M + 127) / 128) * (n_cols / 128) <= 160 && ((M + 63) / 64) * (n_cols / 128) <= 256) {
         // few column tiles (the score half of the fast path: 126 tiles of 128 x 128 would leave half the CUs idle):
