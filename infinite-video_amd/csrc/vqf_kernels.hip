@@ -11,6 +11,7 @@
 // so one chunk costs two [H*Q x d x T*P] contractions (4.8 GFLOP each at the headline shape) instead of the
 // 2 x 9.7 GFLOP K/V projections plus the attention itself.
 #include "vqf_internal.h"
+#include <cstdint>
 #include "ltm_device.h"
 
 namespace infv {
@@ -287,10 +288,98 @@ __global__ __launch_bounds__(256) void qf_epilogue_kernel(QfEpilogue e) {
     }
 }
 
+// The same epilogue with 16-byte accesses: a thread owns NV float4 of the row (columns 4 * (tid + 256 v)), so a 768-wide
+// row is ONE float4 per thread and slab instead of up to 16 predicated scalar slots (9 us -> 4 us per launch on the
+// 32-row calls of the per-chunk path, which issues twelve of them per chunk).  Same slab summation order.
+template <int NV>
+__global__ __launch_bounds__(256) void qf_epilogue_vec_kernel(QfEpilogue e) {
+    __shared__ double scratch[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* in = e.parts + (long)m * e.ld_in;
+    const float* res = e.residual ? e.residual + (long)(m % e.res_rows) * e.ld_res : nullptr;
+    floatx4 x[NV], bias_v[NV], res_v[NV], gam_v[NV], bet_v[NV];
+    bool on[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = 4 * (tid + 256 * v);
+        on[v] = c < e.width;
+        x[v] = floatx4{0.f, 0.f, 0.f, 0.f}; bias_v[v] = x[v]; res_v[v] = x[v]; bet_v[v] = x[v];
+        gam_v[v] = floatx4{1.f, 1.f, 1.f, 1.f};
+        if (on[v]) {
+            const int seg = c / e.seg_cols;
+            if (e.bias[seg]) bias_v[v] = *reinterpret_cast<const floatx4*>(e.bias[seg] + (c - seg * e.seg_cols));
+            if (res) res_v[v] = *reinterpret_cast<const floatx4*>(res + c);
+            if (e.gamma) { gam_v[v] = *reinterpret_cast<const floatx4*>(e.gamma + c); bet_v[v] = *reinterpret_cast<const floatx4*>(e.beta + c); }
+        }
+    }
+    for (int s = 0; s < e.nsplit; s += 8) {             // eight slabs in flight
+        floatx4 t[NV][8];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                t[v][k] = (on[v] && s + k < e.nsplit) ? *reinterpret_cast<const floatx4*>(in + (long)(s + k) * e.split_stride + 4 * (tid + 256 * v))
+                                                      : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[v] += t[v][k];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = x[v][j] + bias_v[v][j];
+            if (e.act == QF_ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+            y *= e.scale;
+            if (res) y += e.res_scale * res_v[v][j];
+            x[v][j] = y;
+        }
+    if (e.gamma) {
+        double sum = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (on[v]) sum += ((double)x[v][0] + (double)x[v][1]) + ((double)x[v][2] + (double)x[v][3]);
+        const float mean = (float)(block_sum<256>(sum, scratch) / e.width);
+        double sq = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (on[v]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float dlt = x[v][j] - mean; sq += (double)dlt * dlt; }
+            }
+        const float var = (float)(block_sum<256>(sq, scratch) / e.width);
+        const float rstd = 1.0f / sqrtf(var + e.eps);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[v][j] = (x[v][j] - mean) * rstd * gam_v[v][j] + bet_v[v][j];
+    }
+    float* out = e.out + (long)m * e.ld_out;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if (on[v]) *reinterpret_cast<floatx4*>(out + 4 * (tid + 256 * v)) = x[v];
+}
+
 hipError_t launch_qf_epilogue(const QfEpilogue& e, hipStream_t stream) {
     if (e.M <= 0) return hipSuccess;
     if (e.width > 256 * kEpiMaxPerThread || e.seg_cols <= 0 || (e.width + e.seg_cols - 1) / e.seg_cols > kQfMaxSeg)
         return hipErrorInvalidValue;
+    {
+        auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        bool vec = e.width % 4 == 0 && e.seg_cols % 4 == 0 && e.ld_in % 4 == 0 && e.split_stride % 4 == 0 && e.ld_out % 4 == 0 &&
+                   al(e.parts) && al(e.out) && (!e.residual || (al(e.residual) && e.ld_res % 4 == 0)) &&
+                   (!e.gamma || (al(e.gamma) && al(e.beta)));
+        for (int sg = 0; sg < kQfMaxSeg; ++sg) vec = vec && (!e.bias[sg] || al(e.bias[sg]));
+        if (vec && e.width <= 1024) {
+            hipLaunchKernelGGL(qf_epilogue_vec_kernel<1>, dim3(e.M), dim3(256), 0, stream, e);
+            return hipGetLastError();
+        }
+        if (vec && e.width <= 4096) {
+            hipLaunchKernelGGL(qf_epilogue_vec_kernel<4>, dim3(e.M), dim3(256), 0, stream, e);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(qf_epilogue_kernel, dim3(e.M), dim3(256), 0, stream, e);
     return hipGetLastError();
 }
