@@ -36,8 +36,9 @@ for grp in ("mfma", "lds"):
 rows = []
 for k, d in res.items():
     if "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"] > 0:
-        # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs (4 per CU, 256 CUs); GRBM_GUI_ACTIVE is wall cycles of the dispatch
-        d["mfma_util_pct"] = 100.0 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] * 4 * 256)
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs (4 per CU, 256 CUs); GRBM_GUI_ACTIVE is the dispatch's active
+        # cycles summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS): wall cycles = GRBM / 8
+        d["mfma_util_pct"] = 100.0 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] / 8.0 * 4 * 256)
     if d.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
         d["lds_bank_conflict_pct"] = 100.0 * d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
     rows.append((d.get("GRBM_GUI_ACTIVE", 0.0), k, d))
