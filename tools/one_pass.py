@@ -25,6 +25,11 @@ k = torch.empty(chunks, T * P, D, device=dev)
 gen = torch.Generator(device=dev).manual_seed(1)
 for i in range(0, chunks, 64):
     k[i:i + 64].normal_(generator=gen)
+if len(sys.argv) > 3 and sys.argv[3] == "bf16":     # frame tokens as the optional bf16 producer layout (halves the pooled bytes)
+    k16 = torch.empty(chunks, T * P, D, device=dev, dtype=torch.bfloat16)
+    for i in range(0, chunks, 64):
+        k16[i:i + 64] = k[i:i + 64]
+    k = k16
 torch.cuda.synchronize()
 for p in range(passes):
     t0 = time.perf_counter()
