@@ -227,3 +227,24 @@ np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bi
             outs.append({k_: v for k_, v in np.load(f.name).items()})
     for key in outs[0]:
         np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
+
+
+@pytest.mark.parametrize("n_chunks,max_batch,split", [(33, 42, 0), (45, 7, 0), (70, 28, 37), (129, 42, 1), (97, 13, 50),
+                                                       (300, 42, 0), (64, 32, 63)])
+def test_odd_call_lengths_sub_batches_and_continuations(dev, n_chunks, max_batch, split):
+    """Call lengths that are no multiple of the sub-batch, short last sub-batches (split-K slabs), one-chunk calls and a
+    document continued by a second consolidate call (``new_doc=False``): every one must equal the per-chunk chain."""
+    k, q, projs, u, ws, qs = _video(dev, n_chunks)
+    fast = _engine(dev, max_batch_chunks=max_batch)
+    pieces = [(0, n_chunks)] if split == 0 else [(0, split), (split, n_chunks)]
+    ctxs, bins, probs = [], [], []
+    for lo, hi in pieces:
+        b, p = fast.set_trace(hi - lo)
+        ctxs.append(fast.consolidate(k[lo:hi], q, projs, u[lo:hi], new_doc=(lo == 0)).clone())
+        fast.sync()
+        bins.append(b.clone()); probs.append(p.clone())
+    fast.set_trace(0)
+    ctx, bins_all, probs_all = torch.cat(ctxs), torch.cat(bins), torch.cat(probs)
+    assert int((bins_all[1:] < 0).sum()) == 0 and int((bins_all[0] >= 0).sum()) == 0
+    budget = max(4, int(4e-5 * n_chunks * L * S))
+    _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, budget)
