@@ -198,6 +198,7 @@ struct UcArgs {
     const float* bv[kMaxLayers];
     float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks
     long long* dbg;                 // timing experiments: phase stamps of one V' workgroup, or nullptr
+    int v16;                        // uc_fast_kernel: V' slices of 16 columns (twice the workgroups, half the read-out each)
 };
 // scores -> softmax weights + row sums of the ring slots the persistent role S filled (in place)
 hipError_t launch_alpha_rows(float* alpha_ring, long alpha_slot, float* asum_ring, long asum_slot, long slot0, int ring,

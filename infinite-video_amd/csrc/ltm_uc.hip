@@ -318,37 +318,49 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, rows = a.op.rows;
-    floatx4* cur = reinterpret_cast<floatx4*>(lds);
-    floatx4* nxt = cur + N * 8;
-    float* red = lds + 2 * N * 32;
-    float* Asm = red + 8 * 64 * 4;                      // alpha tile [32][N + 4] of the current chunk
     const int apitch = N + 4;
 
-    const int sb = a.d / kUcCols, sv = a.dm / kUcCols;
+    // a.v16: V' slices are 16 columns wide (B slices stay 32): twice as many read-out workgroups, each with half the
+    // MFMA work (the fp32 read-out is matrix-pipe-bound on its CU) and half the update
+    const int vcols = a.v16 ? 16 : kUcCols;
+    const int sb = a.d / kUcCols, sv = a.dm / vcols;
     const int per_layer = sb + sv;
     const int l = blockIdx.x / per_layer;
     const int sl = blockIdx.x - l * per_layer;
     const bool isV = sl >= sb;
-    const int col0 = (isV ? sl - sb : sl) * kUcCols;
+    const bool narrow = isV && a.v16;                   // this workgroup's slice has 4 float4 per row
+    const int col0 = isV ? (sl - sb) * vcols : sl * kUcCols;
     const int dm = a.dm, H = a.H, Q = a.Q;
     const int h = col0 / kHeadSize;
     const int pitch = isV ? 2 * dm : a.d;
     const float* src = isV ? a.KV_prev + (long)l * N * 2 * dm + dm + col0 : a.B_prev + (long)l * N * a.d + col0;
     float* dst = isV ? a.KV_next + (long)l * N * 2 * dm + dm + col0 : a.B_next + (long)l * N * a.d + col0;
 
-    const int bi = tid >> 3, c4 = tid & 7;
-    const int NP = N / 64;
+    // LDS: two copies of the slice (N x 16 or N x 32 floats), then -- V' slices only -- the k-partials and the alpha tile.
+    // With 16-column V' slices a workgroup needs at most 73 KB (64 KB for a B slice): two of them, or one and a workgroup of
+    // the projection GEMM, share a CU.
+    floatx4* cur = reinterpret_cast<floatx4*>(lds);
+    floatx4* nxt = cur + N * (narrow ? 4 : 8);
+    float* red = lds + 2 * N * (narrow ? 16 : 32);
+    float* Asm = red + 8 * 64 * 4;                      // alpha tile [32][N + 4] of the current chunk
+    const int sh = narrow ? 2 : 3;                      // log2(float4 per row)
+    const int bi = tid >> sh, c4 = tid & ((1 << sh) - 1);
+    const int rpp = kUcNT >> sh;                        // boxes per pass (64 or 128)
+    const int NP = (N + rpp - 1) / rpp;
+    // LDS slot (float4 index) of (row r, float4 column j4): 32-column slices are swizzled (column bit 4 by row bit 5, see
+    // above); 16-column slices are plain -- their read-out takes consecutive rows on consecutive lane groups
+    auto slot = [&](int r, int j4) { return narrow ? r * 4 + j4 : uf_slot(r, j4); };
     // ---- load the slice; static operator entries of this thread's boxes ----
     float val[kUfNP]; int brow[kUfNP];
 #pragma unroll
     for (int p = 0; p < kUfNP; ++p) {
-        const int n = bi + 64 * p;
+        const int n = bi + rpp * p;
         val[p] = 0.f; brow[p] = -1;
-        if (p < NP) {
+        if (p < NP && n < N) {
             val[p] = a.op.box_val[n]; brow[p] = a.op.box_row[n];
             floatx4 v = {0.f, 0.f, 0.f, 0.f};
             if (a.have_state) v = *reinterpret_cast<const floatx4*>(src + (long)n * pitch + 4 * c4);
-            cur[uf_slot(n, c4)] = v;
+            cur[slot(n, c4)] = v;
         }
     }
     // ---- per-chunk prefetch state ----
@@ -370,8 +382,9 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
         for (int p = 0; p < kUfNP; ++p) {
             tabv[p] = make_int4(-1, -1, -1, -1);
             newv[p] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (p < NP) {
-                if (a.gather) tabv[p] = *reinterpret_cast<const int4*>(tb + (bi + 64 * p) * 4);
+            const int n = bi + rpp * p;
+            if (p < NP && n < N) {
+                if (a.gather) tabv[p] = *reinterpret_cast<const int4*>(tb + n * 4);
                 if (brow[p] >= 0) {
                     floatx4 v = *reinterpret_cast<const floatx4*>(nb + (long)brow[p] * nr_ld);
                     for (int k = 1; k < nsplit; ++k) v += *reinterpret_cast<const floatx4*>(nb + (long)brow[p] * nr_ld + k * a.split_stride);
@@ -380,11 +393,14 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
             }
         }
     };
-    // read-out geometry: 8 waves = 2 query tiles x 2 column tiles x 2 halves of the box dimension
+    // read-out geometry.  32-column slices: 8 waves = 2 query tiles x 2 column tiles x 2 halves of the box dimension, lane
+    // group g takes a contiguous run of boxes.  16-column slices: 2 query tiles x 4 quarters of the box dimension, and the
+    // four k of one MFMA are four CONSECUTIVE boxes (lane group g <-> box 4j + g): consecutive 64-byte rows, no conflicts.
     const int c = lane & 15, g = lane >> 4;
-    const int qt = wave & 1, ct = (wave >> 1) & 1, ks = wave >> 2;
-    const int per = N / 2, KL = per / 4;                  // boxes per wave half, per lane
-    const int kb = ks * per + g * KL;
+    const int qt = wave & 1, ct = narrow ? 0 : (wave >> 1) & 1, ks = narrow ? wave >> 1 : wave >> 2;
+    const int nks = narrow ? 4 : 2;                      // partial sums per output tile
+    const int per = N / nks, KL = per / 4;               // boxes per wave, per lane
+    const int kb = narrow ? ks * per : ks * per + g * KL;
     const int qrow = 16 * qt + c;
     const long al_slot = (long)a.L * H * Q * N, as_slot = (long)a.L * H * Q;
     const float* al_base = a.alpha + ((long)l * H + h) * (long)Q * N;
@@ -430,11 +446,11 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
         // ---- memory update: X_c[n] = val_n * sum_k X_{c-1}[tab[n][k]] + new row of n ----
 #pragma unroll
         for (int p = 0; p < kUfNP; ++p) {
-            if (p < NP) {
-                const int n = bi + 64 * p;
+            const int n = bi + rpp * p;
+            if (p < NP && n < N) {
                 const int4 t = tabv[p];
-                const floatx4 g0 = cur[uf_slot(max(t.x, 0), c4)], g1 = cur[uf_slot(max(t.y, 0), c4)];
-                const floatx4 g2 = cur[uf_slot(max(t.z, 0), c4)], g3 = cur[uf_slot(max(t.w, 0), c4)];
+                const floatx4 g0 = cur[slot(max(t.x, 0), c4)], g1 = cur[slot(max(t.y, 0), c4)];
+                const floatx4 g2 = cur[slot(max(t.z, 0), c4)], g3 = cur[slot(max(t.w, 0), c4)];
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
                 const float vn = val[p];
 #pragma unroll
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
                     if (brow[p] >= 0) x += newv[p][e];
                     acc[e] = x;
                 }
-                nxt[uf_slot(n, c4)] = acc;
+                nxt[slot(n, c4)] = acc;
             }
         }
         USTAMP(3);
@@ -458,6 +474,16 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
         if (isV) {
             const float* curf = reinterpret_cast<const float*>(cur);
             floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (narrow) {
+                // lane (c, g): A = alpha[qrow][kb + 4 j + g], B = V'[kb + 4 j + g][col c]
+                const float* arow = Asm + qrow * apitch + kb + g;
+                const float* bcol = curf + (long)(kb + g) * 16 + c;
+#pragma unroll 8
+                for (int j = 0; j < per / 4; j += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j], bcol[64 * j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 4], bcol[64 * j + 64], acc1, 0, 0, 0);
+                }
+            } else {
             const int colj = 16 * ct + c;
             const float* arow = Asm + qrow * apitch + kb;
 #pragma unroll
@@ -474,6 +500,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
                     }
                 }
             }
+            }
             USTAMP(5);
             const floatx4 accw = acc0 + acc1;
             *reinterpret_cast<floatx4*>(&red[(wave * 64 + lane) * 4]) = accw;
@@ -481,7 +508,13 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
             USTAMP(6);
             if (ks == 0) {
                 floatx4 tot = accw;
-                tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
+                if (narrow) {
+                    tot += *reinterpret_cast<const floatx4*>(&red[((wave + 2) * 64 + lane) * 4]);
+                    tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
+                    tot += *reinterpret_cast<const floatx4*>(&red[((wave + 6) * 64 + lane) * 4]);
+                } else {
+                    tot += *reinterpret_cast<const floatx4*>(&red[((wave + 4) * 64 + lane) * 4]);
+                }
                 float* ctx = a.ctx + (long)i * a.L * Q * dm + (long)l * Q * dm + col0;
                 const float asr[4] = {as0, as1, as2, as3};
 #pragma unroll
@@ -496,11 +529,10 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     lds_barrier();
     // ---- write the slice back ----
 #pragma unroll
-    for (int p = 0; p < kUfNP; ++p)
-        if (p < NP) {
-            const int n = bi + 64 * p;
-            *reinterpret_cast<floatx4*>(dst + (long)n * pitch + 4 * c4) = cur[uf_slot(n, c4)];
-        }
+    for (int p = 0; p < kUfNP; ++p) {
+        const int n = bi + rpp * p;
+        if (p < NP && n < N) *reinterpret_cast<floatx4*>(dst + (long)n * pitch + 4 * c4) = cur[slot(n, c4)];
+    }
 }
 
 bool uc_fast_supported(int N, int Q, int tabw) { return tabw == 4 && Q <= kUcQ && N % 64 == 0 && N <= 256; }
@@ -527,7 +559,17 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
     static const bool want_fast = [] { const char* e = getenv("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
     if (want_fast && uc_fast_supported(a.N, a.Q, a.tabw)) {
-        hipLaunchKernelGGL(uc_fast_kernel, dim3(blocks), dim3(kUcNT), (size_t)(2 * a.N * 32 + 8 * 64 * 4 + kUcQ * (a.N + 4)) * sizeof(float), stream, a);
+        // INFV_UC_V16=1: 16-column V' slices (N a multiple of 16 boxes per lane group: N % 64 == 0 holds here)
+        static const bool v16 = [] { const char* e = getenv("INFV_UC_V16"); return e && atoi(e) != 0; }();
+        UcArgs b = a;
+        b.v16 = (v16 && a.dm % 16 == 0) ? 1 : 0;
+        const int nblk = b.v16 ? a.L * (a.d / kUcCols + a.dm / 16) : blocks;
+        size_t lds_floats = (size_t)2 * a.N * 32 + 8 * 64 * 4 + kUcQ * (a.N + 4);
+        if (b.v16) {
+            const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
+            lds_floats = vfl > bfl ? vfl : bfl;
+        }
+        hipLaunchKernelGGL(uc_fast_kernel, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
