@@ -111,6 +111,11 @@ class LTMEngine:
     def _proj_array(self, projs: Sequence[ProjTensors]):
         if len(projs) != self.L:
             raise ValueError(f"expected projections for {self.L} layers, got {len(projs)}")
+        # the same weight tensors call after call (the per-chunk loop): validated once, the ctypes array is reused
+        key = tuple((t.data_ptr(), t.shape[0]) for p in projs for t in p)
+        cached = getattr(self, "_proj_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         arr = (_lib.Proj * self.L)()
         for l, (wk, bk, wv, bv) in enumerate(projs):
             for name, t, shape in (("wk", wk, (self.dm, self.d)), ("bk", bk, (self.dm,)),
@@ -119,6 +124,7 @@ class LTMEngine:
                 if tuple(t.shape) != shape:
                     raise ValueError(f"{name}[{l}] has shape {tuple(t.shape)}, expected {shape}")
             arr[l] = _lib.Proj(wk.data_ptr(), bk.data_ptr(), wv.data_ptr(), bv.data_ptr())
+        self._proj_cache = (key, arr, [tuple(p) for p in projs])      # (the tensors are kept alive with their addresses)
         return arr
 
     def _check_q(self, q: torch.Tensor) -> int:

@@ -106,6 +106,20 @@ class LongTermAttention(nn.Module):
         return eng
 
     def _proj(self, device):
+        # the borrowed key/value Linear layers rarely change between calls: reuse the fp32 views while the parameters are the
+        # same tensors at the same in-place version
+        pk, pv = self.proj_key, self.proj_value
+        stamp = (pk.weight.data_ptr(), pk.weight._version, pv.weight.data_ptr(), pv.weight._version,
+                 None if pk.bias is None else (pk.bias.data_ptr(), pk.bias._version),
+                 None if pv.bias is None else (pv.bias.data_ptr(), pv.bias._version), device)
+        cached = getattr(self, "_proj_views", None)
+        if cached is not None and cached[0] == stamp:
+            return cached[1]
+        views = self._proj_build(device)
+        self._proj_views = (stamp, views)
+        return views
+
+    def _proj_build(self, device):
         def f32(t):
             t = t.detach()
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
@@ -167,6 +181,33 @@ class LongTermAttention(nn.Module):
         eng.import_state(0, state["B_past"].to(device=device, dtype=torch.float32).contiguous(),
                          state["bin_mass"].to(device=device, dtype=torch.float32).contiguous(), self._proj(device))
 
+    _U_RING = 8
+
+    def _draw_uniforms(self, device) -> torch.Tensor:
+        """512 float64 uniforms for the bin draw + 512 for the degenerate in-bin draw (:204-206) from the global CPU generator,
+        staged through a small ring of pinned buffers so that the host never waits for the copy (a slot is reused only after
+        the copy that read it has completed)."""
+        ring = getattr(self, "_u_ring", None)
+        if ring is None or ring["device"] != device:
+            S = self.nb_samples
+            ring = {"device": device, "i": 0,
+                    "pin": [torch.empty(2, S, dtype=torch.float64).pin_memory() for _ in range(self._U_RING)],
+                    "dev": [torch.empty(1, S, dtype=torch.float64, device=device) for _ in range(self._U_RING)],
+                    "ev": [None] * self._U_RING}
+            self._u_ring = ring
+        i = ring["i"]
+        ring["i"] = (i + 1) % self._U_RING
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        pin, dev = ring["pin"][i], ring["dev"][i]
+        torch.rand(self.nb_samples, dtype=torch.float64, out=pin[0])
+        torch.rand(self.nb_samples, dtype=torch.float64, out=pin[1])      # consumed like the reference's second draw
+        dev.copy_(pin[0:1], non_blocking=True)
+        ev = ring["ev"][i] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["ev"][i] = ev
+        return dev
+
     # ------------------------------------------------------------------ forward
     def forward(self, k, q, new_doc, layer_n):
         """k [1, T*P, d] frame tokens, q [1, Q, H*dh] -> [1, Q, H*dh]   (reference :288-346)."""
@@ -201,9 +242,7 @@ class LongTermAttention(nn.Module):
         u = None
         if eng.has_memory and self.sticky_memories:
             # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
-            u = torch.rand(self.nb_samples, dtype=torch.float64)
-            torch.rand(self.nb_samples, dtype=torch.float64)          # the in-bin draw of :206
-            u = u.to(k.device, non_blocking=True).unsqueeze(0)
+            u = self._draw_uniforms(k.device)
         qf = q.detach()
         if qf.dtype != torch.float32 or not qf.is_contiguous():
             qf = qf.float().contiguous()
