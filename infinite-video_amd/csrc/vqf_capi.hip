@@ -22,6 +22,7 @@ struct infv_vqf_s {
     DeviceBuf sFh, sFl, sTh, sTl, sPh, sPl, sQh, sQl;   // split-bf16 operands of the short-term attention
     DeviceBuf wFh, wFl, wTh, wTl;                       // the same split of a WHOLE video's frame tokens (layer-major path)
     bool fuse = true;                                   // one pass over the frame tokens: split + transpose + frame means
+    double split_cache_gb = 64.0;                       // budget for a whole video's split tokens (INFV_VQF_SPLIT_CACHE_GB at create)
     // whole-video (layer-major) path
     DeviceBuf vA, v1, v2, vxq, valong, vshort, vmerged, vqkv, vsa, vinter, vu, vkbar, v_h1s, v_xqs;
     hipStream_t side = nullptr;
@@ -257,6 +258,7 @@ int infv_vqf_create(const infv_vqf_config* cfg, infv_vqf_handle* out) {
     {   // INFV_VQF_FUSE=0 (read per handle, for A/B tests): separate pooling pass + one split pass per layer, as in round 1
         const char* e = getenv("INFV_VQF_FUSE");
         h->fuse = !e || atoi(e) != 0;
+        if (const char* g = getenv("INFV_VQF_SPLIT_CACHE_GB")) h->split_cache_gb = atof(g);
     }
     HIP_TRY(hipGetDevice(&h->dev));
     const infv_vqf_config& c = *cfg;
@@ -460,7 +462,7 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     //      252 chunks): kept for the call when they fit INFV_VQF_SPLIT_CACHE_GB (default 64 of the 288 GB). ----
     SplitRef wref{}; bool have_w = false, have_kbar = false;
     {
-        static const double budget_gb = [] { const char* e = getenv("INFV_VQF_SPLIT_CACHE_GB"); return e ? atof(e) : 64.0; }();
+        const double budget_gb = h->split_cache_gb;
         const double need_gb = 4.0 * (double)C * (double)chunk_k * 2.0 / 1e9;
         if (h->fuse && split_path(h, n_tokens) && need_gb <= budget_gb) {
             have_kbar = use_ltm && 64 % c.tokens_per_frame == 0;

@@ -305,12 +305,16 @@ def test_single_token_pass_equals_separate_pooling_and_per_layer_split(monkeypat
     k = torch.from_numpy(np.stack(frames)).to(dev)
     u = torch.from_numpy(np.stack([chunk_uniforms(case, c) for c in range(Cn)]))
     outs = {}
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("INFV_VQF_FUSE", fuse)            # read when the handle is created
+    for fuse in ("1", "0", "nocache"):
+        # (both knobs are read when the handle is created)  "nocache": single token pass per chunk call, but the whole video's
+        # split copies do not fit the budget, so the layer-major schedule splits per sub-batch and pools from the tokens
+        monkeypatch.setenv("INFV_VQF_FUSE", "0" if fuse == "0" else "1")
+        monkeypatch.setenv("INFV_VQF_SPLIT_CACHE_GB", "0" if fuse == "nocache" else "64")
         m = make_model(case, weights, dev)
         per_chunk = [m.encode_frames(k[c:c + 1], new_video=(c == 0), u=u[c])[0].clone() for c in range(Cn)]
         llama, mean, hidden = m.encode_frames_batch(k, new_video=True, u=u, want_hidden=True)
         torch.cuda.synchronize()
         outs[fuse] = (torch.stack(per_chunk), llama.clone(), hidden.clone())
-    for a, b, what in zip(outs["1"], outs["0"], ("per chunk", "layer-major llama", "layer-major hidden")):
-        assert torch.equal(a, b), what
+    for other in ("0", "nocache"):
+        for a, b, what in zip(outs["1"], outs[other], ("per chunk", "layer-major llama", "layer-major hidden")):
+            assert torch.equal(a, b), f"{other}: {what}"
