@@ -459,17 +459,28 @@ __global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 64; ++e) w[e] = wk[(long)(h * 64 + e) * d + j];
     float* out = qt + ((long)b * H * Q + (long)h * Q + q0) * d + j;
-    for (int r = 0; r < qn; ++r) {
-        float a = 0.f;
+    // four rows at a time: each row is a chain of 64 dependent FMAs, four independent chains keep the VALU busy
+    // (rows past qn are zero in LDS and not stored); same per-row order, so the same bits
+    for (int r = 0; r < 32; r += 4) {
+        if (r >= qn) break;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int e4 = 0; e4 < 16; ++e4) {
-            const floatx4 qv = *reinterpret_cast<const floatx4*>(&qs[r * 64 + e4 * 4]);
-            a = fmaf(qv[0], w[e4 * 4 + 0], a);
-            a = fmaf(qv[1], w[e4 * 4 + 1], a);
-            a = fmaf(qv[2], w[e4 * 4 + 2], a);
-            a = fmaf(qv[3], w[e4 * 4 + 3], a);
+            const floatx4 q0v = *reinterpret_cast<const floatx4*>(&qs[(r + 0) * 64 + e4 * 4]);
+            const floatx4 q1v = *reinterpret_cast<const floatx4*>(&qs[(r + 1) * 64 + e4 * 4]);
+            const floatx4 q2v = *reinterpret_cast<const floatx4*>(&qs[(r + 2) * 64 + e4 * 4]);
+            const floatx4 q3v = *reinterpret_cast<const floatx4*>(&qs[(r + 3) * 64 + e4 * 4]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float wv = w[e4 * 4 + t];
+                a0 = fmaf(q0v[t], wv, a0); a1 = fmaf(q1v[t], wv, a1);
+                a2 = fmaf(q2v[t], wv, a2); a3 = fmaf(q3v[t], wv, a3);
+            }
         }
-        out[(long)r * d] = a;
+        out[(long)r * d] = a0;
+        if (r + 1 < qn) out[(long)(r + 1) * d] = a1;
+        if (r + 2 < qn) out[(long)(r + 2) * d] = a2;
+        if (r + 3 < qn) out[(long)(r + 3) * d] = a3;
     }
 }
 
