@@ -83,7 +83,9 @@ int infv_vqf_short_attention(infv_vqf_handle h, const float* frames, int32_t n_t
  *   u           [n_layers][nb_samples] float64 Gibbs uniforms (device) or NULL (first chunk / non-sticky / alpha == 1)
  *   new_video   resets the memories first (Qformer.py:221 new_doc=new_video)
  *   hidden_out  [n_query][hidden]    last_hidden_state        (may be NULL)
- *   llama_out   [n_query][proj_out]  llama_proj(last_hidden)  (may be NULL) */
+ *   llama_out   [n_query][proj_out]  llama_proj(last_hidden)  (may be NULL)
+ * The chunk's frame tokens are read ONCE: one pass yields the split-bf16 operands of every layer's short-term attention
+ * (Qformer.py:278-291) and the frame means every layer's memory pools (long_term_attention_gibbs.py:304). */
 int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const float* frames, int32_t T,
                           const infv_vqf_weights* w, const double* u, int32_t new_video,
                           float* hidden_out, float* llama_out, void* stream);
@@ -94,7 +96,10 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
  *     pre-multiplied query block;
  *   - later layers have per-chunk queries: their LTM is the sequential per-call chain, issued on an internal side
  *     stream while the caller's stream runs the layer's short-term attention for all chunks;
- *   - every query-token block (linear / LayerNorm / GELU / self-attention) is batched over chunks.
+ *   - every query-token block (linear / LayerNorm / GELU / self-attention) is batched over chunks;
+ *   - the frame tokens of the whole video are read once: their split-bf16 copies (2 x the tokens' bytes) are kept for the
+ *     call when they fit INFV_VQF_SPLIT_CACHE_GB (default 64), and layer 0's memory runs from the frame means of that pass
+ *     (infv_ltm_consolidate_pooled).
  * Results equal n_chunks calls of infv_vqf_encode_chunk (new_video on the first only).
  *   frames [n_chunks][T * tokens_per_frame][enc_width], u [n_chunks][n_layers][nb_samples] or NULL,
  *   hidden_out [n_chunks][n_query][hidden] / llama_out [n_chunks][n_query][proj_out] / llama_mean [n_query][proj_out]
