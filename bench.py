@@ -42,7 +42,9 @@ BYTES_PER_CHUNK = BYTES_K + L * BYTES_LAYER                        # 39 727 104 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed passes over the video (200 x ~15 ms: a timed region of ~3 s)")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed passes over the video; default 200 x the number of GPUs (a pass takes ~18 ms on one GPU and "
+                         "shrinks with the shard: the timed region stays >= 3 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=2048, help="chunks of the synthetic video (whole job)")
     ap.add_argument("--batch-chunks", type=int, default=42,
@@ -245,6 +247,8 @@ def main():
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.steps is None:
+        args.steps = 200 * world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
