@@ -314,6 +314,7 @@ constexpr int kUfKL = 32;                 // boxes per lane of the read-out (N /
 
 __device__ inline int uf_slot(int r, int j4) { return r * 8 + (j4 ^ (((r >> 5) & 1) << 2)); }   // float4 index
 
+template <bool V16>
 __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,13 +323,13 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
 
     // a.v16: V' slices are 16 columns wide (B slices stay 32): twice as many read-out workgroups, each with half the
     // MFMA work (the fp32 read-out is matrix-pipe-bound on its CU) and half the update
-    const int vcols = a.v16 ? 16 : kUcCols;
+    const int vcols = V16 ? 16 : kUcCols;               // (template parameter: the default kernel carries none of the narrow-slice selects)
     const int sb = a.d / kUcCols, sv = a.dm / vcols;
     const int per_layer = sb + sv;
     const int l = blockIdx.x / per_layer;
     const int sl = blockIdx.x - l * per_layer;
     const bool isV = sl >= sb;
-    const bool narrow = isV && a.v16;                   // this workgroup's slice has 4 float4 per row
+    const bool narrow = V16 && isV;                     // this workgroup's slice has 4 float4 per row
     const int col0 = isV ? (sl - sb) * vcols : sl * kUcCols;
     const int dm = a.dm, H = a.H, Q = a.Q;
     const int h = col0 / kHeadSize;
@@ -549,7 +550,9 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel),
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel<true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -559,8 +562,9 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
     static const bool want_fast = [] { const char* e = getenv("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
     if (want_fast && uc_fast_supported(a.N, a.Q, a.tabw)) {
-        // INFV_UC_V16=1: 16-column V' slices (N a multiple of 16 boxes per lane group: N % 64 == 0 holds here)
-        static const bool v16 = [] { const char* e = getenv("INFV_UC_V16"); return e && atoi(e) != 0; }();
+        // 16-column V' slices by default (INFV_UC_V16=0: 32-column slices as in round 1): twice the read-out workgroups with
+        // half the MFMA work each, 73 KB of LDS: the UC kernel 10.0 -> 7.8 ms per video in situ, the call 17.9 -> 16.9 ms
+        static const bool v16 = [] { const char* e = getenv("INFV_UC_V16"); return !e || atoi(e) != 0; }();
         UcArgs b = a;
         b.v16 = (v16 && a.dm % 16 == 0) ? 1 : 0;
         const int nblk = b.v16 ? a.L * (a.d / kUcCols + a.dm / 16) : blocks;
@@ -569,7 +573,8 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
             const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
             lds_floats = vfl > bfl ? vfl : bfl;
         }
-        hipLaunchKernelGGL(uc_fast_kernel, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
+        if (b.v16) hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
+        else hipLaunchKernelGGL(uc_fast_kernel<false>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);

@@ -220,20 +220,20 @@ np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bi
 '''
     import tempfile
     outs = []
-    for env_add in ({"INFV_WHOLE_CALL": "0"}, {"INFV_WHOLE_CALL": "1"}, {"INFV_UC_V16": "1"}):
+    for env_add in ({"INFV_WHOLE_CALL": "0"}, {"INFV_WHOLE_CALL": "1"}, {"INFV_UC_V16": "0"}):
         with tempfile.NamedTemporaryFile(suffix=".npz") as f:
             env = dict(os.environ, **env_add)
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
             outs.append({k_: v for k_, v in np.load(f.name).items()})
     for key in outs[0]:
         np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
-    # INFV_UC_V16=1 (16-column V' slices in the UC kernel: four k-partials per read-out tile instead of two): same memory
-    # and draws bit for bit, contexts equal up to the association of the read-out sum
+    # INFV_UC_V16=0 (32-column V' slices in the UC kernel: two k-partials per read-out tile instead of the default four): same
+    # memory and draws bit for bit, contexts equal up to the association of the read-out sum
     for key in ("B0", "B1", "bins"):
         np.testing.assert_array_equal(outs[0][key], outs[2][key], err_msg=key)
     for key in ("a", "b"):
         np.testing.assert_allclose(outs[0][key], outs[2][key], rtol=0, atol=2e-6, err_msg=key)
-        assert np.abs(outs[0][key] - outs[2][key]).max() > 0, "the 16-column variant did not run"
+        assert np.abs(outs[0][key] - outs[2][key]).max() > 0, "the 32-column variant did not run"
 
 
 @pytest.mark.parametrize("n_chunks,max_batch,split", [(33, 42, 0), (45, 7, 0), (70, 28, 37), (129, 42, 1), (97, 13, 50),
