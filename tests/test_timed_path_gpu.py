@@ -255,3 +255,19 @@ def test_odd_call_lengths_sub_batches_and_continuations(dev, n_chunks, max_batch
     assert int((bins_all[1:] < 0).sum()) == 0 and int((bins_all[0] >= 0).sum()) == 0
     budget = max(4, int(4e-5 * n_chunks * L * S))
     _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, budget)
+
+
+@pytest.mark.parametrize("n_query", [16, 24, 5])
+def test_fewer_query_rows_than_a_full_tile(dev, n_query):
+    """Q < 32: the fast path (Q = 16: half-empty read-out tiles in the UC kernel, one 8-row chain tile fewer) and the
+    shapes it hands to the per-chunk path (Q = 24, 5) must equal the per-chunk forward chain."""
+    k, q, projs, u, _, _ = _video(dev, 40)
+    qq = q[:, :n_query].contiguous()
+    a, b = _engine(dev, max_batch_chunks=42), _engine(dev, max_batch_chunks=42)
+    fast = a.consolidate(k, qq, projs, u, new_doc=True)
+    a.sync()
+    ref = torch.stack([b.forward(k[c], qq, projs, u[c], new_doc=(c == 0)) for c in range(k.shape[0])])
+    assert float((fast - ref).abs().max()) <= CTX_TOL
+    for l in range(L):
+        np.testing.assert_array_equal(a.last_draw(l)[0], b.last_draw(l)[0])
+        np.testing.assert_allclose(a.export_state(l)[0].cpu().numpy(), b.export_state(l)[0].cpu().numpy(), rtol=0, atol=B_TOL)
