@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode-video", action="store_true", help="skip the secondary per-chunk Q-former leg")
     ap.add_argument("--no-selfcheck", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the split-bf16 V' projection line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (split-bf16 V' projection, bf16 frame tokens)")
     return ap.parse_args()
 
 
@@ -335,6 +335,29 @@ def main():
                   "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "max_abs_diff_vs_f32": float((ctx2 - ctx).abs().max())}
         del eng2, ctx2
 
+    # ---- secondary line (N = 1): the optional bf16 producer layout of the frame tokens (infv_ltm_set_token_dtype; half the
+    #      bytes of the only HBM-heavy stream; everything after the pooling stays fp32) ----
+    bf16_tokens = None
+    if world == 1 and not args.no_secondary:
+        k16 = torch.empty(c_local, T * P, D, device=dev, dtype=torch.bfloat16)
+        for i in range(0, c_local, 64):
+            k16[i:i + 64] = k[i:i + 64]
+        eng3 = LTMEngine(N, H, DH, D, P, tau=TAU, sticky=True, n_layers=L, max_q=Q, device=dev,
+                         max_batch_chunks=args.batch_chunks)
+        for _ in range(2):
+            consolidate_video(eng3, k16, q, projs, u)
+        torch.cuda.synchronize()
+        n3 = max(1, min(args.steps, 40))
+        t1 = time.perf_counter()
+        for _ in range(n3):
+            ctx3, _ = consolidate_video(eng3, k16, q, projs, u)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t1
+        bf16_tokens = {"dtype": "f32 arithmetic on bf16-rounded frame tokens", "value": args.chunks * n3 / dt3,
+                       "unit": "frame-chunks/s", "steps": n3, "ms_per_step": 1e3 * dt3 / n3,
+                       "max_abs_diff_vs_f32_tokens": float((ctx3 - ctx).abs().max())}
+        del eng3, ctx3, k16
+
     # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing ----
     shard256_ms = None
     if world == 1 and c_local >= 256:
@@ -444,6 +467,8 @@ def main():
             out["shard256_ms"] = shard256_ms
         if vsplit is not None:
             out["secondary_vproj_bf16x3"] = vsplit
+        if bf16_tokens is not None:
+            out["secondary_bf16_tokens"] = bf16_tokens
         if encode_video is not None:
             out["encode_video"] = encode_video
         if world == 1 and not args.no_cpu_baseline:
