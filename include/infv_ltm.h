@@ -184,6 +184,18 @@ int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin
 /* Import + recompute the projected memory with the given weights. */
 int infv_ltm_import_state(infv_ltm_handle h, int32_t layer, const float* B, const float* bin_mass,
                           const infv_ltm_proj* proj, void* stream);
+/* Exact hand-off of the memory chain between handles (multi-GPU correctness mode: rank r continues where rank r-1
+ * stopped, reference semantics of one process walking the whole video, long_term_attention_gibbs.py:194-222).
+ * The blob is everything infv_ltm_consolidate carries from chunk to chunk, in fp32:
+ *   B [L][N][d] | projected memory [L][N][2][dm] | bias-free scores under the call's query [L][H][Q][N] | sticky bin
+ *   masses [L][n_bins]
+ * so a consolidate call that follows an import (same q and proj, new_doc = 0) continues BIT FOR BIT as if the exporting
+ * handle had gone on itself -- unlike export_state/import_state, which hand over B and the masses only and re-derive the
+ * rest (same values up to fp32 rounding).  export needs a memory whose last step ran in infv_ltm_consolidate with query
+ * length Q; blob = DEVICE buffer of infv_ltm_chain_state_bytes(h, Q) bytes; both are asynchronous on `stream`. */
+int64_t infv_ltm_chain_state_bytes(infv_ltm_handle h, int32_t Q);
+int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* stream);
+int infv_ltm_import_chain_state(infv_ltm_handle h, int32_t Q, const void* blob, void* stream);
 /* Recompute projected memory of every layer from B (weights changed since the last step). */
 int infv_ltm_reproject(infv_ltm_handle h, const infv_ltm_proj* proj, void* stream);
 

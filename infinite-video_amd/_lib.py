@@ -106,6 +106,9 @@ _SIGNATURES = {
                                               C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_export_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "infv_ltm_import_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Proj), C.c_void_p]),
+    "infv_ltm_chain_state_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "infv_ltm_export_chain_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_import_chain_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_reproject": (C.c_int, [C.c_void_p, C.POINTER(Proj), C.c_void_p]),
     "infv_ltm_get_draw": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, f32p, f32p, C.c_void_p]),
     "infv_ltm_set_probs": (C.c_int, [C.c_void_p, C.c_int32, f32p]),

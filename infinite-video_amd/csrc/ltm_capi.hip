@@ -111,6 +111,7 @@ struct infv_ltm_s {
     int lastQ = 0;                     // query length of the last attend
     bool last_fast = false;            // last step ran in the fused chain kernel (scores = Sp + cq)
     bool k_stale = false;              // the K' half of KV is out of date (the fast path does not maintain it)
+    bool carry_scores = false;         // one-shot (import_chain_state): the next consolidate continues from Sp / V' as they are
     int parts = 0;                     // row count of bin_part per layer, set by the last attend
     DeviceBuf bin_part[2];             // [L][max_parts][n_bins]  sticky partials (ping-pong in the fast path)
     int pc = 0;                        // which bin_part holds the latest partials
@@ -118,7 +119,7 @@ struct infv_ltm_s {
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
-    DeviceBuf kbar_ws, kbar_side[3], R_ws[3], P_ws[3], Snew_ws[3];
+    DeviceBuf kbar_ws, kbar_side[3], R_ws[5], P_ws[3], Snew_ws[3];   // R: sets 0-3 rotate over the sub-batches, 4 = first chunk of a document
     DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
@@ -127,6 +128,7 @@ struct infv_ltm_s {
     hipStream_t aux = nullptr;          // V' projection + softmax weights of a sub-batch (feeds the UC kernel)
     hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_r[4] = {nullptr, nullptr, nullptr, nullptr};   // the UC kernel that read R set i is done
     hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
@@ -167,6 +169,7 @@ struct infv_ltm_s {
         if (aux) (void)hipStreamSynchronize(aux);
         for (int i = 0; i < 3; ++i) if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
+        for (int i = 0; i < 4; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -776,19 +779,20 @@ struct FastPipe {
 // [ V' projection of the row (L*dm) | its scores under the call's pre-multiplied queries (L*H*Q) ]
 int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T, int Q,
                         const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad,
-                        bool defer_values = false) {
+                        bool defer_values = false, int rset = -1, bool rows_done = false) {
+    if (rset < 0) rset = set;                                 // R buffer of the sub-batch (the pooling kernel may have filled it)
     const Operator& op = inf ? plan.inf : plan.first;
     const long M = (long)n_chunks * op.rows;
     const int n_out = h->L * h->H * Q;
     const long ld = (long)h->L * h->dm + n_out;
     const int sk_max = 8;
     const size_t needR = (size_t)(M ? M : 1) * h->d * sizeof(float), needP = (size_t)(M ? M : 1) * ld * sk_max * sizeof(float);
-    if (needR > h->R_ws[set].bytes || (M < 1024 ? needP : needP / sk_max) > h->P_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(h->R_ws[set].reserve(needR));
+    if (needR > h->R_ws[rset].bytes || (M < 1024 ? needP : needP / sk_max) > h->P_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(h->R_ws[rset].reserve(needR));
     HIP_TRY(h->P_ws[set].reserve(M < 1024 ? needP : needP / sk_max));
-    {
+    if (!rows_done) {
         Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
-        HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[set].as<float>(), stream));
+        HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[rset].as<float>(), stream));
     }
     // INFV_LTM_SPLIT=1 (experiment, off by default): the V' half of a sub-batch's projection only feeds the read-out, so
     // it can run as a split-bf16 contraction (three bf16 MFMA products, ~1e-5 relative) while the score half stays on
@@ -814,24 +818,24 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
                                           h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, stream));
             h->wv_split_valid = true;
         }
-        HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, M, h->d, h->R_hi.p, h->R_lo.p, h->d, stream));
+        HIP_TRY(launch_split_rows(h->R_ws[rset].as<float>(), h->d, M, h->d, h->R_hi.p, h->R_lo.p, h->d, stream));
         SplitGemm g{};
         g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
         g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
         g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.strideC = 0; g.split_stride = 0;
         g.M = (int)M; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
         HIP_TRY(launch_split_gemm(g, stream, gemm_pad));
-        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
                                       h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
         *splitk = 1;
     } else if (defer_values && M >= 1024) {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
                                       h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
         *splitk = 1;
     } else {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-        HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[set].as<float>(),
+        HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
                                     h->P_ws[set].as<float>(), splitk, stream, gemm_pad));
     }
     *split_stride = M * ld;
@@ -907,6 +911,7 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_r[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
@@ -989,32 +994,40 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             kb0 = h->kbar_ws.as<float>();
         }
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks_fast(h, *plan, false, kb0, 1, T, Q, pp, 2, &sk, &ss, stream, 0)) return rc;
+        if (int rc = project_chunks_fast(h, *plan, false, kb0, 1, T, Q, pp, 2, &sk, &ss, stream, 0, false, 4)) return rc;
         const long v_cols = (long)h->L * h->dm;             // a GEMM output row is [ V' (L*dm) | scores (L*H*Q) ]
         const StepS st{&plan->first, false, h->P_ws[2].as<float>() + v_cols, nullptr, sk, ss};
         if (int rc = pipe.launch_s(st)) return rc;
         HIP_TRY(hipEventRecord(h->ev_s[2], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[2], 0));
-        if (int rc = pipe.launch_uc(plan->first, false, 1, 0, h->R_ws[2].as<float>(), h->P_ws[2].as<float>(), sk, ss, ctx, ucs)) return rc;
+        if (int rc = pipe.launch_uc(plan->first, false, 1, 0, h->R_ws[4].as<float>(), h->P_ws[2].as<float>(), sk, ss, ctx, ucs)) return rc;
         HIP_TRY(hipEventRecord(h->ev_uc[2], ucs));
         uc_pending[2] = true;
         c = 1;
     } else {
-        // continue an existing memory: bias-free scores of the current K' rows under this query
-        if (h->k_stale)
-            if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
-        Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
-        HIP_TRY(launch_new_scores(q, Q, h->H, h->L, 1, h->N, h->KV[h->cur].as<float>(), 0, 2L * h->dm,
-                                  (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
-                                  stream));
+        // continue an existing memory
+        if (h->carry_scores && h->last_fast && h->lastQ == Q) {
+            // ... handed over by infv_ltm_import_chain_state: the scores under this query and the projected memory are the
+            // exporting handle's own; nothing is re-derived, the chain goes on bit for bit
+        } else {
+            // ... bias-free scores of the current K' rows under this query
+            if (h->k_stale)
+                if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
+            Timed t_(h->prof, INFV_KERNEL_SCORES, stream);
+            HIP_TRY(launch_new_scores(q, Q, h->H, h->L, 1, h->N, h->KV[h->cur].as<float>(), 0, 2L * h->dm,
+                                      (long)h->N * 2 * h->dm, 1, 0, pp, h->Sp[h->sc].as<float>(), h->cqbuf.as<float>(),
+                                      stream));
+        }
     }
+    h->carry_scores = false;
     // ---- sub-batches.  Streams: `side` = chunk-parallel stage of batch b+1, caller's stream = role S of
     //      batch b (one launch per chunk), `ucs` = memory update + read-out of batch b-1 ----
     // INFV_PERSISTENT=0 falls back to one role-S launch per chunk
     static const bool want_persistent = [] { const char* e = getenv("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
     const bool persistent = want_persistent &&
         chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L) &&
-        chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L);
+        chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L,
+                             h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, Q);
     const int first_c = c;
     // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
     // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 32 so that the
@@ -1051,10 +1064,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const size_t needP_reg = M * ld * (M < 1024 ? 8 : 1), needP_last = Ml * ld * (Ml < 1024 ? 8 : 1);
         const size_t needR = M * h->d * sizeof(float), needP = (needP_reg > needP_last ? needP_reg : needP_last) * sizeof(float);
         bool grow = false;
-        for (int i = 0; i < 3; ++i) grow = grow || needR > h->R_ws[i].bytes || needP > h->P_ws[i].bytes;
+        for (int i = 0; i < 3; ++i) grow = grow || needP > h->P_ws[i].bytes;
+        for (int i = 0; i < 4; ++i) grow = grow || needR > h->R_ws[i].bytes;
         if (grow) {
             HIP_TRY(hipDeviceSynchronize());
-            for (int i = 0; i < 3; ++i) { HIP_TRY(h->R_ws[i].reserve(needR)); HIP_TRY(h->P_ws[i].reserve(needP)); }
+            for (int i = 0; i < 3; ++i) HIP_TRY(h->P_ws[i].reserve(needP));
+            for (int i = 0; i < 4; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
         }
         HIP_TRY(hipMemsetAsync(h->wc_flags.p, 0, 8 * sizeof(unsigned long long), stream));
     }
@@ -1066,17 +1081,46 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     const bool split_pool = split_pool_env && !kbar_pre;      // (frame means handed in: there is no pooling stage)
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
-    if (!kbar_pre) {
+    bool r_pending[4] = {false, false, false, false};         // ev_r[rset] has been recorded in this call
+    // Pool + rows in one kernel (default): the pooling stream writes the sub-batch's new rows R straight from the tokens --
+    // in this path the frame means are consumed by the rows kernel only (see pool_rows_kernel).  INFV_POOL_ROWS=0 keeps the
+    // two kernels (frame means on the pooling stream, rows in front of the GEMM).
+    static const bool pr_env = [] { const char* e = getenv("INFV_POOL_ROWS"); return !e || atoi(e) != 0; }();
+    const bool use_pr = pr_env && !kbar_pre && pool_rows_supported(h->P, h->d);
+    static const int pr_u = [] { const char* e = getenv("INFV_PR_U"); return e ? atoi(e) : 4; }();
+    static const int pr_nt = [] { const char* e = getenv("INFV_PR_NT"); return e ? atoi(e) : 512; }();
+    static const int pr_pad = [] { const char* e = getenv("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
+    if (!kbar_pre && !use_pr) {
         const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
         if (need > h->kbar_side[0].bytes) {
             HIP_TRY(hipDeviceSynchronize());
             for (int i = 0; i < 3; ++i) HIP_TRY(h->kbar_side[i].reserve(need));
         }
     }
-    auto stage_pool = [&](int b) -> int {                      // frame means of batch b, on `pools`
+    if (n_batches > 0) {                                      // the rotating R sets are written off the side stream: size them here
+        const size_t needR = (size_t)sub * rows * h->d * sizeof(float);
+        bool grow = false;
+        for (int i = 0; i < 4; ++i) grow = grow || needR > h->R_ws[i].bytes;
+        if (grow) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < 4; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
+        }
+    }
+    auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
         if (kbar_pre) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3;
+        const int set = b % 3, rset = b % 4;
+        if (use_pr) {
+            // R set rset was last read by the UC kernel (and the projections) of batch b-4
+            if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
+            if (!(skip_mask() & 1)) {
+                Timed t_(h->prof, INFV_KERNEL_POOL, pools);
+                HIP_TRY(launch_pool_rows(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
+                                         pools, pr_u, pr_nt, pr_pad));
+            }
+            if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
+            return INFV_OK;
+        }
         // the rows kernel that read this set's pooled frames (batch b-3) is done once its projection is
         if (split_pool && p_pending[set]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_p[set], 0));
         if (!(skip_mask() & 1)) {
@@ -1088,12 +1132,13 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     };
     auto stage_project = [&](int b) -> int {                   // rows -> [V'new | S'new] GEMM of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3;
+        const int set = b % 3, rset = b % 4;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
+        if (r_pending[rset] && !use_pr) HIP_TRY(hipStreamWaitEvent(side, h->ev_r[rset], 0));   // (the rows kernel writes R here)
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
         const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
-                                         h->vproj_on_uc(n_chunks))) return rc;
+                                         h->vproj_on_uc(n_chunks), rset, use_pr)) return rc;
         // gemm_ready: the chain may enter batch b.  Before the event, so that whoever waits for this batch's projection
         // (the UC stream, and through it the join of the call) also waits for the counter update: the next call resets it
         if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 0, side));
@@ -1131,7 +1176,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     }
     for (int b = 0; b < n_batches; ++b) {
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3;
+        const int set = b % 3, rset = b % 4;
         if (!wc) {
             HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
             // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
@@ -1189,7 +1234,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                                   h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, vs));
                     h->wv_split_valid = true;
                 }
-                HIP_TRY(launch_split_rows(h->R_ws[set].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, vs));
+                HIP_TRY(launch_split_rows(h->R_ws[rset].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, vs));
                 SplitGemm g{};
                 g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
                 g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
@@ -1197,7 +1242,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                 g.M = (int)Mv; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
                 HIP_TRY(launch_split_gemm(g, vs, kGemmPad));
             } else {
-                HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, h->R_ws[set].as<float>(),
+                HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, h->R_ws[rset].as<float>(),
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
@@ -1216,11 +1261,13 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             HIP_TRY(hipEventRecord(h->ev_aux[set], vs));
             HIP_TRY(hipStreamWaitEvent(ucs, h->ev_aux[set], 0));
         }
-        if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[set].as<float>(), h->P_ws[set].as<float>(),
+        if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[rset].as<float>(), h->P_ws[set].as<float>(),
                                     sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
         if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 1, ucs));   // uc_done: batch b's ring slots are free
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
+        HIP_TRY(hipEventRecord(h->ev_r[rset], ucs));
+        r_pending[rset] = true;
     }
     // join: the memory and every ctx are complete once the last UC kernel is; then hand the sticky histogram
     // back as one float partial row and bring the K' half of the projected memory up to date
@@ -1265,6 +1312,49 @@ int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin
         HIP_TRY(launch_sum_parts(h->bin_part[h->pc].as<float>() + (size_t)layer * h->parts * h->n_bins, h->parts, h->n_bins,
                                  bin_mass, stream));
     }
+    return INFV_OK;
+}
+
+int64_t infv_ltm_chain_state_bytes(infv_ltm_handle h, int32_t Q) {
+    if (!h || Q <= 0 || Q > h->maxQ) return -1;
+    return (int64_t)sizeof(float) * ((int64_t)h->L * h->N * h->d + (int64_t)h->L * h->N * 2 * h->dm +
+                                     (int64_t)h->L * h->H * Q * h->N + (int64_t)h->L * h->n_bins);
+}
+
+int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!blob) return fail(INFV_ERR_INVALID, "export_chain_state: null blob");
+    if (int rc = check_q(h, Q)) return rc;
+    if (int rc = check_chain_error(h)) return rc;
+    if (!h->has_memory || !h->last_fast || h->lastQ != Q || h->parts != 1)
+        return fail(INFV_ERR_STATE, "export_chain_state: the memory's last step must come from infv_ltm_consolidate with Q=%d", Q);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* out = static_cast<float*>(blob);
+    const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,
+                 nM = (size_t)h->L * h->n_bins;
+    HIP_TRY(hipMemcpyAsync(out, h->B[h->cur].p, nB * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(out + nB, h->KV[h->cur].p, nKV * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(out + nB + nKV, h->Sp[h->sc].p, nS * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(out + nB + nKV + nS, h->bin_part[h->pc].p, nM * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return INFV_OK;
+}
+
+int infv_ltm_import_chain_state(infv_ltm_handle h, int32_t Q, const void* blob, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!blob) return fail(INFV_ERR_INVALID, "import_chain_state: null blob");
+    if (int rc = check_q(h, Q)) return rc;
+    if (int rc = check_chain_error(h)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const float* in = static_cast<const float*>(blob);
+    const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,
+                 nM = (size_t)h->L * h->n_bins;
+    HIP_TRY(hipMemcpyAsync(h->B[h->cur].p, in, nB * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h->KV[h->cur].p, in + nB, nKV * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h->Sp[h->sc].p, in + nB + nKV, nS * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h->bin_part[h->pc].p, in + nB + nKV + nS, nM * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    h->has_memory = true; h->parts = 1; h->lastQ = Q; h->last_fast = true;
+    h->k_stale = true;                 // the K' half came from a fast-path handle: re-projected on demand
+    h->carry_scores = true;
     return INFV_OK;
 }
 

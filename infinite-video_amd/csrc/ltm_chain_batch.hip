@@ -554,6 +554,12 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         }
         __syncthreads();                                                         // barrier 1
         B2STAMP(2);
+        // Clear the accumulator slot of step i+1 (it held the totals of step i-2).  Wave 0 has just seen every arrival of
+        // step i-1, and a workgroup arrives only after its own poll of step i-2's totals, so nobody reads the slot any
+        // more; nobody adds to it before having seen all arrivals of step i, this workgroup's included -- and that arrival
+        // (behind barrier 3) is held back until the clear has been acknowledged: the clearing waves drain vmcnt before
+        // they join barrier 3.  (Round 2 issued the clear behind barrier 3, beside the arrival, with nothing ordering the two.)
+        if (writer && tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + (tid - 128) * kAccStride, 0ull);
         if (tid < a.S) {
             // ---- lower bound of this thread's uniform in the cdf == number of entries below it ----
             const float my_uf = (lds + m.uf + (i & 1) * a.S)[tid];
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             Msm[wave * kMPitch + lane] = row_ok ? ((d0n * inv_z + d0nn * inv_z) * dxa) * 0.5f : 0.f;
             if (lane + 64 < kBins - 1) Msm[wave * kMPitch + lane + 64] = row_ok ? ((d1n * inv_z + d1nn * inv_z) * dxb) * 0.5f : 0.f;
         }
+        if (writer && (wave == 2 || wave == 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clear above is complete
         __syncthreads();                                                         // barrier 3
         B2STAMP(4);
         if (tid < kBins - 1) {
@@ -641,7 +648,6 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         } else {
             // ---- waves 1-6, stores only: publish the step for alpha_rows2_kernel / the UC kernel ----
             if (writer) {
-                if (tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + (tid - 128) * kAccStride, 0ull);   // slot of the NEXT step: idle until then
                 int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;          // source BOX of every slot (UC kernel)
                 int32_t* tabb_out = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;        // drawn BIN of every slot
                 for (int e = tid - 64; e < N * tabw; e += kBNT - 128) {
@@ -910,12 +916,26 @@ bool chain_batch2_applies(const ChainBatchArgs& a) {
     return chain_batch2_shape_ok(a.draw_mode, a.st.points_ok, a.op.rows, a.S, a.Q) && a.crit_ring != nullptr;
 }
 
-bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks) {
+static size_t chain_batch2_launch_lds(int N, int S, int rows, int tabw) {
+    // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
+    static const int pad = [] { const char* e = getenv("INFV_S_LDS"); return e ? atoi(e) : 0; }();
+    size_t lds = (size_t)batch2_smem(N, S, rows, tabw).total * sizeof(float);
+    if ((size_t)pad > lds) lds = pad;
+    return lds;
+}
+
+// Asks about the kernel and the dynamic LDS size that launch_chain_batch will really use for this shape.
+bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int draw_mode, int points_ok, int Q) {
     if (chain_batch_attr() != hipSuccess) return false;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch_kernel, kBNT, chain_batch_lds_bytes(N, S, rows, tabw)) != hipSuccess) return false;
+    hipError_t e;
+    if (chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q))
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel, kBNT, chain_batch2_launch_lds(N, S, rows, tabw));
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch_kernel, kBNT, chain_batch_lds_bytes(N, S, rows, tabw));
+    if (e != hipSuccess) return false;
     const int safe = per_cu > 1 ? per_cu - 1 : per_cu;
     return (long)safe * cus >= n_blocks;
 }
@@ -926,11 +946,7 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
     const int blocks = a.H * a.QS * a.L;
     if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, blocks)) return hipErrorInvalidValue;
     if (chain_batch2_applies(a)) {
-        // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
-        static const int pad = [] { const char* e = getenv("INFV_S_LDS"); return e ? atoi(e) : 0; }();
-        size_t lds = (size_t)batch2_smem(a.N, a.S, a.op.rows, a.op.tabw).total * sizeof(float);
-        if ((size_t)pad > lds) lds = pad;
-        hipLaunchKernelGGL(chain_batch2_kernel, dim3(blocks), dim3(kBNT), lds, stream, a);
+        hipLaunchKernelGGL(chain_batch2_kernel, dim3(blocks), dim3(kBNT), chain_batch2_launch_lds(a.N, a.S, a.op.rows, a.op.tabw), stream, a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(chain_batch_kernel, dim3(blocks), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),

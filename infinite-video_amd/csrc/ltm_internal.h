@@ -57,6 +57,11 @@ hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames,
 
 // R[c][r][:] = val * sum of the frames of row r of chunk c;  Pnew[sk][c][r][l][kv][dm] = split-K
 // partials of R . W[l][kv]^T  (sk = project_splitk(n_chunks*rows, d) slabs of n_chunks*rows*L*2*dm floats).
+// pool + rows in one pass (fast path): R straight from the tokens, bit-identical to launch_pool + launch_rows.
+// u: 1-KiB loads per group (two groups in flight per wave), nt: threads per workgroup (256 / 512), lds_pad: occupancy cap.
+bool pool_rows_supported(int P, int d);
+hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                            hipStream_t stream, int u, int nt, int lds_pad);
 int project_splitk(int M, int K);
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream);
@@ -179,7 +184,7 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
 // stream-ordered counter arithmetic for the whole-call chain kernel: add 1 / spin until the counter reaches `target`
 hipError_t launch_signal_add(unsigned long long* counter, hipStream_t stream);
 hipError_t launch_gate(unsigned long long* counter, unsigned long long target, unsigned int* error, hipStream_t stream);
-bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks);   // all workgroups fit on the device at once
+bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int draw_mode, int points_ok, int Q);   // all workgroups of the kernel the launch will use fit on the device at once
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
 
 // ---- state update + read-out of a sub-batch in one launch (ltm_uc.hip) ----

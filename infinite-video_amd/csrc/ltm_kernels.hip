@@ -166,6 +166,119 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 }
 
 // ======================================================================================
+// 2b. pool + rows in one pass (fast path):  R[c][r][:] = sum_{f in [begin_r,end_r)} val_r * (sum_p k[c][f][p][:] / P)
+//     In the whole-video path the frame means are consumed by build_rows_kernel only, and a new row is the weighted sum
+//     of a CONTIGUOUS block of tokens (its frames are consecutive: 4 frames x 32 tokens x 3 KiB = 384 KiB at the headline
+//     shape), so the pooling kernel can emit R directly: no kbar round trip, no second kernel, no event hop.
+//     One wave per (chunk, row, 256-float column slice); it streams the block's (end-begin)*P token rows as 1 KiB loads,
+//     U of them per group, two groups in flight (register double buffer: the loads of group g+1 are issued before group g
+//     is summed).  The arithmetic is pool_frames_kernel's followed by build_rows_kernel's in the same order -- token sum in
+//     p order, division by P, fma chain over the frames -- so R is bit-identical to the two-kernel path.
+//     Needs P % U == 0 (a group never straddles a frame).
+// ======================================================================================
+template <int U, int NT, class Tok>
+__global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ k_, long chunk_stride /*token vectors per chunk*/,
+                                                       int P, int d4, int slices, OperatorView op, long n_units,
+                                                       float* __restrict__ R) {
+    typedef typename Tok::vec tvec;
+    const int lane = threadIdx.x & 63;
+    const long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int s = (int)(unit % slices);
+    const long cr = unit / slices;
+    const int r = (int)(cr % op.rows);
+    const long c = cr / op.rows;
+    const int c4 = s * 64 + lane;
+    if (c4 >= d4) return;
+    const int fb = op.row_begin[r], fe = op.row_end[r];
+    const float val = op.box_val[op.row_box[r]];
+    const tvec* src = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)fb * P * d4 + c4;
+    const int gpf = P / U;                               // groups per frame
+    const int n_groups = (fe - fb) * gpf;
+    const float fp = (float)P;
+    tvec va[U], vb[U];
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f}, racc = {0.f, 0.f, 0.f, 0.f};
+    int in_frame = 0;
+    auto consume = [&](const tvec (&v)[U]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
+        if (++in_frame == gpf) {
+            in_frame = 0;
+            acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does (LTM.py:304)
+            racc.x = fmaf(val, acc.x, racc.x); racc.y = fmaf(val, acc.y, racc.y);
+            racc.z = fmaf(val, acc.z, racc.z); racc.w = fmaf(val, acc.w, racc.w);
+            acc = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)i * d4);
+    int g = 0;
+    for (; g + 2 < n_groups; g += 2) {
+        const tvec* s1 = src + (long)(g + 1) * U * d4;
+#pragma unroll
+        for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(s1 + (long)i * d4);
+        consume(va);
+        const tvec* s2 = src + (long)(g + 2) * U * d4;
+#pragma unroll
+        for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(s2 + (long)i * d4);
+        consume(vb);
+    }
+    if (g + 1 < n_groups) {
+        const tvec* s1 = src + (long)(g + 1) * U * d4;
+#pragma unroll
+        for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(s1 + (long)i * d4);
+        consume(va);
+        consume(vb);
+    } else {
+        consume(va);
+    }
+    __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + (c * op.rows + r) * (long)d4 + c4);
+}
+
+bool pool_rows_supported(int P, int d) { return P % 4 == 0 && d % 4 == 0; }
+
+template <int U, int NT, class Tok>
+static hipError_t launch_pool_rows_v(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                                     hipStream_t stream, int lds_pad) {
+    const int d4 = d / 4, slices = (d4 + 63) / 64;
+    const long n_units = (long)n_chunks * op.rows * slices;
+    if (lds_pad > 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<U, NT, Tok>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((pool_rows_kernel<U, NT, Tok>), dim3((unsigned)((n_units + NT / 64 - 1) / (NT / 64))), dim3(NT), lds_pad, stream,
+                       k, (long)T * P * d4, P, d4, slices, op, n_units, R);
+    return hipGetLastError();
+}
+
+template <class Tok>
+static hipError_t launch_pool_rows_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                                     hipStream_t stream, int u, int nt, int lds_pad) {
+    if (P % 8 != 0 && u > 4) u = 4;
+    if (nt == 512) {
+        if (u >= 8) return launch_pool_rows_v<8, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+        if (u >= 4) return launch_pool_rows_v<4, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+        return launch_pool_rows_v<2, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+    }
+    if (u >= 8) return launch_pool_rows_v<8, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+    if (u >= 4) return launch_pool_rows_v<4, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+    return launch_pool_rows_v<2, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+}
+
+hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                            hipStream_t stream, int u, int nt, int lds_pad) {
+    if (op.rows == 0 || n_chunks == 0) return hipSuccess;
+    if (!pool_rows_supported(P, d)) return hipErrorInvalidValue;
+    return k_bf16 ? launch_pool_rows_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad)
+                  : launch_pool_rows_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad);
+}
+
+// ======================================================================================
 // 3. projection GEMM (NT):  C[sk][m][o] = sum_{k in split sk} A[m][k] * Wrow(o)[k]
 //    A [M][K] row-major; Wrow(o) = row (o % rows_per_seg) of segment o / rows_per_seg (a list of row-major
 //    [rows_per_seg][K] matrices: the layers' Wk / Wv, or the pre-multiplied queries of the fast path).

@@ -281,6 +281,28 @@ class LTMEngine:
             _lib.check(self.lib.infv_ltm_import_state(self._h, layer, _ptr(B), _ptr(bin_mass), C.byref(p),
                                                        _stream(self.device)))
 
+    def export_chain_state(self, Q: int) -> torch.Tensor:
+        """Everything ``consolidate`` carries from chunk to chunk as one fp32 device tensor (infv_ltm_export_chain_state):
+        importing it into another engine and calling ``consolidate(..., new_doc=False)`` with the same query and weights
+        continues the chain bit for bit."""
+        n = int(self.lib.infv_ltm_chain_state_bytes(self._h, Q))
+        if n <= 0:
+            raise ValueError(f"bad query length {Q}")
+        blob = torch.empty(n // 4, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_export_chain_state(self._h, Q, _ptr(blob), _stream(self.device)))
+        return blob
+
+    def import_chain_state(self, Q: int, blob: torch.Tensor):
+        _check_dev(blob, self.device, "blob")
+        if blob.numel() * 4 != int(self.lib.infv_ltm_chain_state_bytes(self._h, Q)):
+            raise ValueError("chain-state blob does not match this engine's shape")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_import_chain_state(self._h, Q, _ptr(blob), _stream(self.device)))
+
+    def chain_state_numel(self, Q: int) -> int:
+        return int(self.lib.infv_ltm_chain_state_bytes(self._h, Q)) // 4
+
     def reproject(self, projs: Sequence[ProjTensors]):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_reproject(self._h, self._proj_array(projs), _stream(self.device)))

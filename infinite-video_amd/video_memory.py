@@ -16,6 +16,10 @@ There is no other collective on the data path.
 
 The Gibbs uniforms are keyed by GLOBAL chunk index, so rank r's result equals a single-GPU
 run on the sub-video made of rank r's chunks.
+
+Correctness mode (``consolidate_video(..., handoff=True)``): the ranks hand the memory chain on from block to block
+(point-to-point send/recv of ~5.5 MB at the headline shape) and reproduce the single-stream run bit for bit; they
+run one after the other.
 """
 from __future__ import annotations
 
@@ -74,8 +78,39 @@ def unpack_memory(payload: torch.Tensor, world: int, L: int, N: int, d: int, Q: 
         count=payload[:, -1])
 
 
+def _device_collectives(group=None) -> bool:
+    """True when the group's backend moves device tensors itself ("nccl" = RCCL over xGMI); gloo (CPU tests, two
+    processes on one GPU) needs host staging."""
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_gather_payload(payload: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    if _device_collectives(group):
+        gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=payload.dtype)
+        dist.all_gather_into_tensor(gathered, payload, group=group)
+        return gathered
+    host = payload.cpu()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    return torch.cat(parts).to(payload.device)
+
+
+def _send(t: torch.Tensor, dst: int, group=None):
+    dist.send(t if _device_collectives(group) else t.cpu(), dst, group=group)
+
+
+def _recv(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
+    if _device_collectives(group):
+        dist.recv(t, src, group=group)
+        return t
+    host = torch.empty(t.shape, dtype=t.dtype)
+    dist.recv(host, src, group=group)
+    return host.to(t.device)
+
+
 def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Sequence,
-                      u_local: Optional[torch.Tensor], group=None) -> Tuple[torch.Tensor, ConsolidatedMemory]:
+                      u_local: Optional[torch.Tensor], group=None, handoff: bool = False
+                      ) -> Tuple[torch.Tensor, ConsolidatedMemory]:
     """Consolidate this rank's block of chunks and all-gather the consolidated memory.
 
     k_local [C_local, T*P, d]; q [L, Q, dm]; u_local [C_local, L, S] (rows keyed by global chunk id).
@@ -83,17 +118,33 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
     Works without an initialised process group (world = 1, no collective); with an initialised group the
     all-gather is issued whatever its size (a world of one still goes through RCCL).
 
+    ``handoff=False`` (default, the throughput mode of SURVEY.md section 8e): every rank's block is its own document;
+    the ranks run concurrently and the result equals single-GPU runs on the sub-videos -- NOT the single-stream run
+    (a block starts from an empty memory; the difference decays within ~63 chunks of a boundary).
+    ``handoff=True`` (the correctness mode): rank r first receives rank r-1's chain state (B, projected memory, scores,
+    sticky bin masses: ``engine.export_chain_state``), imports it and runs its block with ``new_doc=False``, then
+    passes its own state on to rank r+1.  Every chunk then sees the memory of all earlier chunks exactly as in the
+    reference's one-process loop (long_term_attention_gibbs.py:194-222): the outputs equal the single-stream run bit
+    for bit -- and the ranks run one after the other, so it does not scale.
+
     This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
     raises if the persistent chain kernel reported a failure instead of passing an invalid memory on."""
-    ctx = engine.consolidate(k_local, q, projs, u_local, new_doc=True)
-    payload = pack_local_memory(engine, ctx)         # stream-ordered behind the consolidation: no host round trip in between
-    engine.sync()                                    # a latched chain failure raises here, before anything is handed on
     have_group = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if have_group else 1
-    if have_group:
-        gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=payload.dtype)
-        dist.all_gather_into_tensor(gathered, payload, group=group)
-    else:
-        gathered = payload
+    rank = dist.get_rank(group) if have_group else 0
+    Q = int(q.shape[1])
+    chained = handoff and world > 1
+    if chained and rank > 0:
+        blob = torch.empty(engine.chain_state_numel(Q), device=k_local.device, dtype=torch.float32)
+        blob = _recv(blob, rank - 1, group)
+        engine.import_chain_state(Q, blob)
+    ctx = engine.consolidate(k_local, q, projs, u_local, new_doc=not (chained and rank > 0))
+    if chained and rank < world - 1:
+        blob = engine.export_chain_state(Q)
+        engine.sync()                                # complete (and free of a latched chain failure) before it leaves
+        _send(blob, rank + 1, group)
+    payload = pack_local_memory(engine, ctx)         # stream-ordered behind the consolidation: no host round trip in between
+    engine.sync()                                    # a latched chain failure raises here, before anything is handed on
+    gathered = _all_gather_payload(payload, world, group) if have_group else payload
     mem = unpack_memory(gathered, world, engine.L, engine.N, engine.d, q.shape[1], engine.dm)
     return ctx, mem

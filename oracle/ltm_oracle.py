@@ -258,8 +258,13 @@ class ClosedFormOracle:
         return (cum[..., 1:] - cum[..., :-1]).sum(dim=(0, 1)).numpy()
 
     def step(self, k: np.ndarray, q: np.ndarray, new_doc: bool, u: Optional[np.ndarray] = None,
-             probs_override: Optional[np.ndarray] = None) -> np.ndarray:
-        """k [T*P, d], q [Q, H*dh] -> ctx [Q, H*dh].  ``u``: S float64 uniforms (sticky, not first)."""
+             probs_override: Optional[np.ndarray] = None, bins_override: Optional[np.ndarray] = None) -> np.ndarray:
+        """k [T*P, d], q [Q, H*dh] -> ctx [Q, H*dh].  ``u``: S float64 uniforms (sticky, not first).
+
+        ``bins_override`` (test infrastructure): resample THESE bins (LTM.py:207-208 onwards) while the oracle's own
+        probabilities and its own draw from ``u`` are still computed and kept in ``last_probs`` / ``last_bins`` --
+        a long chain can then be compared draw by draw with a device path whose fp32 reduction order differs, without
+        the two runs parting at the first uniform that falls within rounding of a cdf edge."""
         if new_doc:
             self.B_past = None                                         # LTM.py:300-302
         kbar = self.pool(k, self.P)
@@ -279,6 +284,8 @@ class ClosedFormOracle:
                 self.last_probs = probs
                 b = inverse_cdf_draw(probs, u)                         # LTM.py:204-205
                 self.last_bins = b
+                if bins_override is not None:
+                    b = np.asarray(bins_override, np.int64)
                 idx = self.bin_box[b]                                  # LTM.py:207-208
             else:
                 idx = mp.uniform_idx                                   # LTM.py:212

@@ -36,6 +36,20 @@ class OracleEngine:
     def sync(self):
         pass
 
+    # chain state of the stand-in: B_past and the last scores of every layer (the oracle derives everything else)
+    def chain_state_numel(self, Q):
+        return L * (N * D + H * Q * N)
+
+    def export_chain_state(self, Q):
+        return torch.cat([torch.from_numpy(np.concatenate([o.B_past.reshape(-1), o.S_prev.reshape(-1)])) for o in self.layers])
+
+    def import_chain_state(self, Q, blob):
+        per = N * D + H * Q * N
+        for l, o in enumerate(self.layers):
+            part = blob[l * per:(l + 1) * per].numpy()
+            o.B_past = part[:N * D].reshape(N, D).copy()
+            o.S_prev = part[N * D:].reshape(H, Q, N).copy()
+
     def export_state(self, l):
         o = self.layers[l]
         return torch.from_numpy(o.B_past), torch.from_numpy(o.sticky_p_raw(o.S_prev).astype(np.float32))
@@ -106,6 +120,41 @@ def test_two_rank_gloo_equals_single_process_subvideos():
         np.testing.assert_array_equal(B[rank, 0], ref.export_state(0)[0].numpy())
         np.testing.assert_allclose(ctx_sum[rank], ctx_ref.sum(0).numpy(), rtol=1e-6, atol=1e-6)
     assert list(ret[0][4]) == [3.0, 3.0]
+
+
+def _handoff_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, q, u = _inputs()
+        a, b = shard_range(C, world, rank)
+        ctx, mem = consolidate_video(OracleEngine(), k[a:b], q, None, u[a:b], handoff=True)
+        ret[rank] = (ctx.numpy(), mem.B.numpy(), mem.count.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_handoff_equals_the_single_stream_run_bit_for_bit():
+    """consolidate_video(handoff=True): rank 1 continues rank 0's memory chain (send/recv of the chain state over gloo);
+    the concatenated outputs and the final memory equal ONE process walking the whole video -- the reference's loop."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_handoff_worker, args=(2, port, ret), nprocs=2, join=True)
+    k, q, u = _inputs()
+    single = OracleEngine()
+    ctx_ref = single.consolidate(k, q, None, u).numpy()
+    got = np.concatenate([ret[0][0], ret[1][0]])
+    np.testing.assert_array_equal(got, ctx_ref)
+    # the last rank's memory is the single-stream memory; rank 0's is the memory at the block boundary
+    np.testing.assert_array_equal(ret[0][1][1, 0], single.export_state(0)[0].numpy())
+    assert list(ret[1][2]) == [3.0, 3.0]
+    # and it differs from the independent-documents mode (the default), whose rank 1 starts from an empty memory
+    indep = OracleEngine()
+    a, b = shard_range(C, 2, 1)
+    assert np.abs(indep.consolidate(k[a:b], q, None, u[a:b]).numpy() - ctx_ref[a:b]).max() > 1e-3
 
 
 def _qf_gather_worker(rank, world, port, out_q):

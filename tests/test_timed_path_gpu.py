@@ -94,6 +94,40 @@ def _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, fl
     return ref, flips
 
 
+def _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast=None):
+    """The CPU oracle (pinned to the reference by the goldens) over the first ``n_or`` chunks of the timed call, both
+    layers, fed the call's traced bins (reference semantics: LTM.py:194-222 update, :251-286 read-out).  Per chunk:
+    ctx within 1e-4, the oracle's OWN probabilities within 2e-5 relative and its own draw equal to the traced bins but
+    for a counted handful of adjacent-bin flips.  With ``fast`` (the whole call was replayed): final B and last scores."""
+    bins_host = bins_all[:n_or].cpu().numpy()
+    probs_host = probs_all[:n_or].cpu().numpy()
+    u_host = u[:n_or].cpu().numpy()
+    orcs = [O.ClosedFormOracle(N, H, DH, 0.75, True, *ws[l], tokens_per_frame=P) for l in range(L)]
+    worst, worst_p, flips = 0.0, 0.0, 0
+    for c in range(n_or):
+        kc = k[c].cpu().numpy()
+        yc = ctx[c].cpu().numpy()
+        for l in range(L):
+            out = orcs[l].step(kc, qs[l], new_doc=(c == 0), u=u_host[c, l] if c else None,
+                               bins_override=bins_host[c, l] if c else None)
+            err = float(np.abs(out - yc[l]).max())
+            assert err <= CTX_TOL, f"chunk {c} layer {l}: |ctx(HIP) - ctx(oracle)| = {err:.3e}"
+            worst = max(worst, err)
+            if c:
+                d = orcs[l].last_bins != bins_host[c, l]
+                flips += int(d.sum())
+                assert np.abs(orcs[l].last_bins[d] - bins_host[c, l][d]).max(initial=0) <= 1, "a differing draw is not an adjacent bin"
+                worst_p = max(worst_p, float(np.abs(orcs[l].last_probs / probs_host[c, l, :127] - 1).max()))
+    assert worst_p <= 2e-5, f"sticky probabilities of the HIP path and the oracle differ by {worst_p:.2e} relative"
+    budget = max(4, int(4e-5 * n_or * L * S))
+    assert flips <= budget, f"{flips} of {(n_or - 1) * L * S} oracle draws differ from the HIP path's"
+    if fast is not None:
+        for l in range(L):
+            np.testing.assert_allclose(fast.export_state(l)[0].cpu().numpy(), orcs[l].B_past, rtol=0, atol=B_TOL)
+            np.testing.assert_allclose(fast.last_scores(l, Q), orcs[l].S_prev, rtol=1e-4, atol=2e-5)
+    return worst, flips
+
+
 @pytest.mark.parametrize("n_chunks", [64, 256, 2048])
 def test_bench_call_matches_per_chunk_chain(dev, n_chunks):
     """64 chunks: two 28-chunk sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
@@ -120,12 +154,11 @@ def test_bench_call_matches_per_chunk_chain(dev, n_chunks):
     budget = max(4, int(4e-5 * n_chunks * L * S))
     ref, flips = _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, budget)
     print(f"[timed path] {n_chunks} chunks: {flips} of {(n_chunks - 1) * L * S} draws differ between consolidate and the per-chunk chain")
-    # oracle on chunk 1 of layer 0 (one CPU step at this shape costs ~1 s)
-    orc = O.ClosedFormOracle(N, H, DH, 0.75, True, *ws[0], tokens_per_frame=P)
-    kc, uc = k[:2].cpu().numpy(), u[:2].cpu().numpy()
-    for c in range(2):
-        out = orc.step(kc[c], qs[0], new_doc=(c == 0), u=uc[c, 0])
-        np.testing.assert_allclose(ctx[c, 0].cpu().numpy(), out, rtol=0, atol=CTX_TOL)
+    # the CPU oracle itself, both layers, teacher-forced to the call's traced bins: the whole call up to 256 chunks (then
+    # also final B and last scores), the first 128 chunks (three 42-chunk sub-batches) of the 2048-chunk bench call
+    n_or = n_chunks if n_chunks <= 256 else 128
+    worst, oflips = _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast if n_or == n_chunks else None)
+    print(f"[timed path] {n_chunks} chunks vs the CPU oracle over {n_or}: max |ctx diff| {worst:.2e}, {oflips} draws differ")
 
 
 def test_split_bf16_value_projection_stays_inside_tolerance(dev, monkeypatch):
