@@ -4,6 +4,7 @@
 #include "capi_common.h"
 #include "vqf_internal.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +102,10 @@ struct Timed {
 
 }  // namespace
 
+// New-row buffers R of the sub-batch pipeline: the pooling stream fills set b % kRSets for sub-batch b and may run that many
+// sub-batches ahead of the UC kernel, the last reader of a set (three sets coupled the pooling to the UC stream's progress).
+constexpr int kRSets = 8;
+
 struct infv_ltm_s {
     infv_ltm_config cfg;
     int N, H, dh, d, dm, P, L, S, maxQ, maxC;
@@ -119,7 +124,7 @@ struct infv_ltm_s {
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
-    DeviceBuf kbar_ws, kbar_side[3], R_ws[5], P_ws[3], Snew_ws[3];   // R: sets 0-3 rotate over the sub-batches, 4 = first chunk of a document
+    DeviceBuf kbar_ws, kbar_side[3], R_ws[kRSets + 1], P_ws[3], Snew_ws[3];   // R: sets 0..kRSets-1 rotate over the sub-batches, kRSets = first chunk of a document
     DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
@@ -128,7 +133,7 @@ struct infv_ltm_s {
     hipStream_t aux = nullptr;          // V' projection + softmax weights of a sub-batch (feeds the UC kernel)
     hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_r[4] = {nullptr, nullptr, nullptr, nullptr};   // the UC kernel that read R set i is done
+    hipEvent_t ev_r[kRSets] = {};      // the UC kernel that read R set i is done
     hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
@@ -146,13 +151,14 @@ struct infv_ltm_s {
     unsigned int* err_host = nullptr; unsigned int* err_dev = nullptr;
     int k_bf16 = 0;                     // frame tokens arrive as bf16 (infv_ltm_set_token_dtype)
     bool v_split = false;               // INFV_VPROJ_SPLIT=1 at create: V' half of the sub-batch projection as a split-bf16 contraction
-    // Where the V' half of a sub-batch's projection runs.  Long calls: on the UC stream, as its own GEMM (the side stream then
-    // delivers the score half, which the chain waits for, sooner).  Short calls (< 768 chunks, e.g. the 256-chunk shard of an
-    // 8-GPU run): inside the side stream's one [V' | S'] GEMM -- there the UC stream (V' GEMM -> softmax weights -> update, 275 us
-    // per 28 chunks against 150 us of chain) is the critical path; a 256-chunk call drops from 3.17 to 2.81 ms.
-    // INFV_VPROJ_ON_UC=0/1 at create forces either; the split-bf16 V' projection implies the UC stream.
+    // Where the V' half of a sub-batch's projection runs.  Default (round 3): inside the side stream's one [V' | S'] GEMM.  The
+    // UC stream (V' GEMM -> softmax weights -> update, serial per sub-batch) was the second-longest stream of the pipeline
+    // and a GEMM workgroup cannot share a CU with a UC workgroup (272 + 320 of the 512 registers per SIMD), so the V' GEMM
+    // only ever delayed the UC kernel behind it; with 16-row chain tiles (48 role-S workgroups instead of 96) the merged
+    // GEMM has the CUs to finish well before the chain needs its score half.  Round 2 ran long calls (>= 768 chunks) with the
+    // V' half on the UC stream (INFV_VPROJ_ON_UC=1 restores that; the split-bf16 V' projection implies it).
     int v_on_uc_mode = -1;
-    bool vproj_on_uc(int n_chunks) const { return v_on_uc_mode >= 0 ? v_on_uc_mode != 0 : (v_split || n_chunks >= 768); }
+    bool vproj_on_uc(int /*n_chunks*/) const { return v_on_uc_mode >= 0 ? v_on_uc_mode != 0 : v_split; }
     int spin_limit = 1 << 22; int expect_extra = 0;     // INFV_CHAIN_FAULT=1 (tests): expect one arrival too many -> every wait times out
     int32_t* trace_bins = nullptr; float* trace_probs = nullptr; long trace_cap = 0;   // draw trace of consolidate (caller's device buffers)
     DeviceBuf bins_forced; unsigned forced_mask = 0;    // one-shot forced draw of the per-call path
@@ -169,7 +175,7 @@ struct infv_ltm_s {
         if (aux) (void)hipStreamSynchronize(aux);
         for (int i = 0; i < 3; ++i) if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
-        for (int i = 0; i < 4; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
+        for (int i = 0; i < kRSets; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -871,11 +877,13 @@ int shared_streams(int dev, SharedStreams** out) {
     if (!p.side) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent
-        HIP_TRY(hipStreamCreateWithFlags(&p.ucs, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, lo));
+        // INFV_PRIO_UCS / _POOL / _SIDE (experiments): -1 most urgent, 0 normal, 1 least urgent
+        auto prio = [&](const char* name, int dflt) { const char* e = getenv(name); int v = e ? atoi(e) : dflt; return v < hi ? hi : (v > lo ? lo : v); };
+        HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio("INFV_PRIO_UCS", 0)));
+        HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio("INFV_PRIO_POOL", lo)));
         static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
         if (use_aux) HIP_TRY(hipStreamCreateWithPriority(&p.aux, hipStreamNonBlocking, lo));
-        HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, lo));   // last: marks the set complete
+        HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio("INFV_PRIO_SIDE", lo)));   // last: marks the set complete
     }
     *out = &p;
     return INFV_OK;
@@ -911,7 +919,7 @@ int ensure_side_stream(infv_ltm_handle h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
     }
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_r[i], hipEventDisableTiming));
+    for (int i = 0; i < kRSets; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_r[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
@@ -994,13 +1002,13 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             kb0 = h->kbar_ws.as<float>();
         }
         int sk = 1; long ss = 0;
-        if (int rc = project_chunks_fast(h, *plan, false, kb0, 1, T, Q, pp, 2, &sk, &ss, stream, 0, false, 4)) return rc;
+        if (int rc = project_chunks_fast(h, *plan, false, kb0, 1, T, Q, pp, 2, &sk, &ss, stream, 0, false, kRSets)) return rc;
         const long v_cols = (long)h->L * h->dm;             // a GEMM output row is [ V' (L*dm) | scores (L*H*Q) ]
         const StepS st{&plan->first, false, h->P_ws[2].as<float>() + v_cols, nullptr, sk, ss};
         if (int rc = pipe.launch_s(st)) return rc;
         HIP_TRY(hipEventRecord(h->ev_s[2], stream));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[2], 0));
-        if (int rc = pipe.launch_uc(plan->first, false, 1, 0, h->R_ws[4].as<float>(), h->P_ws[2].as<float>(), sk, ss, ctx, ucs)) return rc;
+        if (int rc = pipe.launch_uc(plan->first, false, 1, 0, h->R_ws[kRSets].as<float>(), h->P_ws[2].as<float>(), sk, ss, ctx, ucs)) return rc;
         HIP_TRY(hipEventRecord(h->ev_uc[2], ucs));
         uc_pending[2] = true;
         c = 1;
@@ -1026,7 +1034,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     static const bool want_persistent = [] { const char* e = getenv("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
     const bool persistent = want_persistent &&
         chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L) &&
-        chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L,
+        chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw,
+                             chain_batch_blocks(h->H, Q, h->L, h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S),
                              h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, Q);
     const int first_c = c;
     // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
@@ -1052,8 +1061,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // (pool stream 19.7 ms instead of 15.8) than the launch gaps were worth, the three other streams being the longer
     // ones either way.  Kept as an option (parity-tested) for configurations where role S is the longest stream.
     static const bool want_wc = [] { const char* e = getenv("INFV_WHOLE_CALL"); return e && atoi(e) != 0; }();
-    const int s_blocks = h->H * chain_s_tiles(Q) * h->L;
-    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && h->vproj_on_uc(n_chunks) && !(skip_mask() & 8) &&
+    const int s_blocks = chain_batch_blocks(h->H, Q, h->L, h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S);
+    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && !(skip_mask() & 8) &&
                     chain_batch2_shape_ok(h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S, Q);
     if (wc) {
         // the kernel holds the addresses of all three workspace sets: size them before it is launched
@@ -1065,11 +1074,11 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const size_t needR = M * h->d * sizeof(float), needP = (needP_reg > needP_last ? needP_reg : needP_last) * sizeof(float);
         bool grow = false;
         for (int i = 0; i < 3; ++i) grow = grow || needP > h->P_ws[i].bytes;
-        for (int i = 0; i < 4; ++i) grow = grow || needR > h->R_ws[i].bytes;
+        for (int i = 0; i < kRSets; ++i) grow = grow || needR > h->R_ws[i].bytes;
         if (grow) {
             HIP_TRY(hipDeviceSynchronize());
             for (int i = 0; i < 3; ++i) HIP_TRY(h->P_ws[i].reserve(needP));
-            for (int i = 0; i < 4; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
+            for (int i = 0; i < kRSets; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
         }
         HIP_TRY(hipMemsetAsync(h->wc_flags.p, 0, 8 * sizeof(unsigned long long), stream));
     }
@@ -1081,15 +1090,18 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     const bool split_pool = split_pool_env && !kbar_pre;      // (frame means handed in: there is no pooling stage)
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
-    bool r_pending[4] = {false, false, false, false};         // ev_r[rset] has been recorded in this call
-    // Pool + rows in one kernel (default): the pooling stream writes the sub-batch's new rows R straight from the tokens --
-    // in this path the frame means are consumed by the rows kernel only (see pool_rows_kernel).  INFV_POOL_ROWS=0 keeps the
-    // two kernels (frame means on the pooling stream, rows in front of the GEMM).
-    static const bool pr_env = [] { const char* e = getenv("INFV_POOL_ROWS"); return !e || atoi(e) != 0; }();
+    bool r_pending[kRSets] = {};                              // ev_r[rset] has been recorded in this call
+    // Pool + rows in one kernel (INFV_POOL_ROWS=1, off by default): the pooling stream writes the sub-batch's new rows R
+    // straight from the tokens -- in this path the frame means are consumed by the rows kernel only (see pool_rows_kernel);
+    // same bits.  Measured in situ (round 3, tools/sweep_r03*.sh): the fused kernel streams faster (218-270 us per 42-chunk
+    // launch against 304) but its longer-lived workgroups cost the chain launches their CUs -- chain 13.5-15.7 ms per video
+    // against 12.6 -- and the call ends up slower (116-121 k against 130 k chunks/s); the two-kernel form stays the default.
+    static const bool pr_env = [] { const char* e = getenv("INFV_POOL_ROWS"); return e && atoi(e) != 0; }();
     const bool use_pr = pr_env && !kbar_pre && pool_rows_supported(h->P, h->d);
     static const int pr_u = [] { const char* e = getenv("INFV_PR_U"); return e ? atoi(e) : 4; }();
     static const int pr_nt = [] { const char* e = getenv("INFV_PR_NT"); return e ? atoi(e) : 512; }();
     static const int pr_pad = [] { const char* e = getenv("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
+    static const int pr_wgs = [] { const char* e = getenv("INFV_PR_WGS"); return e ? atoi(e) : 0; }();
     if (!kbar_pre && !use_pr) {
         const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
         if (need > h->kbar_side[0].bytes) {
@@ -1100,23 +1112,23 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     if (n_batches > 0) {                                      // the rotating R sets are written off the side stream: size them here
         const size_t needR = (size_t)sub * rows * h->d * sizeof(float);
         bool grow = false;
-        for (int i = 0; i < 4; ++i) grow = grow || needR > h->R_ws[i].bytes;
+        for (int i = 0; i < kRSets; ++i) grow = grow || needR > h->R_ws[i].bytes;
         if (grow) {
             HIP_TRY(hipDeviceSynchronize());
-            for (int i = 0; i < 4; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
+            for (int i = 0; i < kRSets; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
         }
     }
     auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
         if (kbar_pre) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % 4;
+        const int set = b % 3, rset = b % kRSets;
         if (use_pr) {
-            // R set rset was last read by the UC kernel (and the projections) of batch b-4
+            // R set rset was last read by the UC kernel (and the projections) of batch b - kRSets
             if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
             if (!(skip_mask() & 1)) {
                 Timed t_(h->prof, INFV_KERNEL_POOL, pools);
                 HIP_TRY(launch_pool_rows(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
-                                         pools, pr_u, pr_nt, pr_pad));
+                                         pools, pr_u, pr_nt, pr_pad, pr_wgs));
             }
             if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
             return INFV_OK;
@@ -1132,7 +1144,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     };
     auto stage_project = [&](int b) -> int {                   // rows -> [V'new | S'new] GEMM of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % 4;
+        const int set = b % 3, rset = b % kRSets;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (r_pending[rset] && !use_pr) HIP_TRY(hipStreamWaitEvent(side, h->ev_r[rset], 0));   // (the rows kernel writes R here)
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
@@ -1174,9 +1186,13 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         if (int rc = pipe.launch_s_batch(n_chunks - first_c, nullptr, M_reg >= 1024 ? 1 : project_splitk((int)M_reg, h->d), M_reg * ld,
                                          u ? u + (size_t)first_c * chunk_u : nullptr, &w)) return rc;
     }
+    static const bool host_trace = getenv("INFV_HOST_TRACE") != nullptr;   // host time of every loop iteration (is the host ahead of the device?)
+    std::vector<double> host_us;
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int b = 0; b < n_batches; ++b) {
+        if (host_trace) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % 4;
+        const int set = b % 3, rset = b % kRSets;
         if (!wc) {
             HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
             // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
@@ -1268,6 +1284,11 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         uc_pending[set] = true;
         HIP_TRY(hipEventRecord(h->ev_r[rset], ucs));
         r_pending[rset] = true;
+    }
+    if (host_trace && !host_us.empty()) {
+        fprintf(stderr, "[host trace] %d iterations, issue time us:", n_batches);
+        for (size_t i = 0; i < host_us.size(); i += 4) fprintf(stderr, " %.0f", host_us[i]);
+        fprintf(stderr, " | end %.0f\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
     }
     // join: the memory and every ctx are complete once the last UC kernel is; then hand the sticky histogram
     // back as one float partial row and bring the K' half of the projected memory up to date

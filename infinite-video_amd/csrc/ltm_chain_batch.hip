@@ -296,7 +296,8 @@ constexpr int kB2Ld = 4;                  // float4 pieces of the new-row score 
 struct Batch2Smem { int cdf, coarse, pos, tabb, box_val, box_row, pb, sc0, sc1, Snew, uf, Msm, total; };
 constexpr int kScPitch = kBins + 4;
 
-__host__ __device__ inline Batch2Smem batch2_smem(int N, int S, int rows, int tabw) {
+// rpw: query rows per wave (the workgroup's tile is 8 * rpw rows of one head)
+__host__ __device__ inline Batch2Smem batch2_smem(int N, int S, int rows, int tabw, int rpw = 1) {
     Batch2Smem m;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -307,11 +308,11 @@ __host__ __device__ inline Batch2Smem batch2_smem(int N, int S, int rows, int ta
     m.box_val = take(N);
     m.box_row = take(N);
     m.pb = take(kBins);
-    m.sc0 = take(kBRows * kScPitch);
-    m.sc1 = take(kBRows * kScPitch);
-    m.Snew = take(2 * kBRows * (rows + 1));
+    m.sc0 = take(rpw * kBRows * kScPitch);
+    m.sc1 = take(rpw * kBRows * kScPitch);
+    m.Snew = take(2 * rpw * kBRows * (rows + 1));
     m.uf = take(2 * S);
-    m.Msm = take(kBRows * kMPitch);
+    m.Msm = take(rpw * kBRows * kMPitch);
     m.total = o;
     return m;
 }
@@ -321,17 +322,24 @@ __device__ inline float wave_shl1(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
+// RPW query rows per wave: wave w owns rows w, w + 8, ... of the workgroup's 8*RPW-row tile.  More rows per wave = fewer
+// workgroups on the chip (H * ceil(Q / (8 RPW)) per layer; each owns a whole CU by its registers) and fewer arrivals per
+// exchange; the rows of a wave are independent dependency chains that share the table reads and overlap each other's
+// LDS / DPP latencies.  Same arithmetic per row for every RPW: the results do not depend on it.
+template <int RPW>
 __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
+    constexpr int TR = kBRows * RPW;                                   // rows of the tile
+    constexpr int PPR = TR / 4;                                        // float4 pieces per new row of the S'new tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!(a.exp_flags & 1)) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
     const int rows = a.op.rows, tabw = a.op.tabw;
-    const Batch2Smem m = batch2_smem(N, a.S, rows, tabw);
+    const Batch2Smem m = batch2_smem(N, a.S, rows, tabw, RPW);
     const int b = blockIdx.x;
     const int h = b % H, qs = (b / H) % QS, l = b / (H * QS);
     const int blocks_per_layer = H * QS;
-    const int sn = rows + 1, sn_tile = kBRows * sn;
+    const int sn = rows + 1, sn_tile = TR * sn;
     float* cdf = lds + m.cdf;
     float* coarse = lds + m.coarse;
     int32_t* tabb = reinterpret_cast<int32_t*>(lds + m.tabb);          // bin of the k-th resampled slot of box n, -1 = none
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     const float* box_val = lds + m.box_val;
     const int32_t* box_row = reinterpret_cast<const int32_t*>(lds + m.box_row);
     float* Msm = lds + m.Msm;
-    const long tile = (((long)l * H + h) * Q + qs * kBRows);
-    const int valid = min(kBRows, Q - qs * kBRows);
+    const long tile = (((long)l * H + h) * Q + qs * TR);
+    const int valid = min(TR, Q - qs * TR);
     const bool writer = (h == 0 && qs == 0);
     const bool loader = wave == kBRows - 1;
     const long tile_snew = (long)rows * a.snew_ld;
@@ -363,9 +371,11 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         __syncthreads();
     }
     const int my_pos = (tid < a.S) ? reinterpret_cast<const int32_t*>(lds + m.pos)[tid] : -1;
-    const bool row_ok = wave < valid;
-    float* scc = lds + m.sc0 + wave * kScPitch;                        // this wave's row of point scores (bias-free), current
-    float* scn = lds + m.sc1 + wave * kScPitch;                        // ... and next
+    bool row_ok[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) row_ok[j] = wave + kBRows * j < valid;
+    float* scc = lds + m.sc0 + wave * kScPitch;                        // this wave's first row of point scores (bias-free), current
+    float* scn = lds + m.sc1 + wave * kScPitch;                        // ... and next  (row j of the wave: + j * kBRows * kScPitch)
     // the two points of this lane: boxes, operator entries, edge validity and spacings (static)
     const int n0 = pb[lane], n1 = pb[lane + 64];
     const float val0 = box_val[n0], val1 = box_val[n1];
@@ -373,24 +383,27 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     const bool e0ok = a.st.edge_box[lane] >= 0, e1ok = a.st.edge_box[lane + 64] >= 0;     // edge 0 lies left of every box
     const float dx0 = a.st.edge_dx[lane], dx1 = a.st.edge_dx[lane + 64];
     const float dxa = a.st.edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? a.st.edge_dx[lane + 65] : 0.f;
-    const float cqr = row_ok ? a.cq[tile + wave] : 0.f;
-    {
-        const float i0 = row_ok ? a.Sp_in[(tile + wave) * N + n0] : 0.f;
-        const float i1 = row_ok ? a.Sp_in[(tile + wave) * N + n1] : 0.f;
-        scc[lane] = i0;
-        scc[lane + 64] = i1;
-        if (a.publish_init && row_ok) {
+    float cqr[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int row = wave + kBRows * j;
+        cqr[j] = row_ok[j] ? a.cq[tile + row] : 0.f;
+        const float i0 = row_ok[j] ? a.Sp_in[(tile + row) * N + n0] : 0.f;
+        const float i1 = row_ok[j] ? a.Sp_in[(tile + row) * N + n1] : 0.f;
+        scc[j * kBRows * kScPitch + lane] = i0;
+        scc[j * kBRows * kScPitch + lane + 64] = i1;
+        if (a.publish_init && row_ok[j]) {
             // first launch of a call: the state before its first step, for the rows alpha_rows2_kernel rebuilds of that step
             const long prev = (a.step0 % a.ring == 0) ? a.ring - 1 : a.step0 % a.ring - 1;
-            float* cr = a.crit_ring + prev * a.crit_slot + (tile + wave) * kBins;
+            float* cr = a.crit_ring + prev * a.crit_slot + (tile + row) * kBins;
             cr[lane] = i0;
             cr[lane + 64] = i1;
         }
     }
 
     // ---- loader (wave 7): the S'new tile and the uniforms of a step in registers, two sets (steps in flight: i+1, i+2).
-    // Wide loads only.   S'new tile: new row nr holds this tile's 8 scores contiguously -> float4 e4 = lane + 64 k:
-    // row e4 >> 1, half e4 & 1;   uniforms: S float64 -> double2 per lane
+    // Wide loads only.   S'new tile: new row nr holds this tile's TR scores contiguously -> float4 e4 = lane + 64 k:
+    // row e4 / PPR, piece e4 % PPR;   uniforms: S float64 -> double2 per lane
     struct LdSet { floatx4 sn[kB2Ld]; double2 u[4]; };
     LdSet ldA, ldB;
     // whole-call mode: before the first input of sub-batch `sbi` is requested, its new-row scores must be complete and the
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
 #pragma unroll
         for (int k = 0; k < kB2Ld; ++k) {
             const int e4 = lane + 64 * k;
-            const int nr = e4 >> 1, hf = e4 & 1;
+            const int nr = e4 / PPR, hf = e4 % PPR;
             floatx4 v = {0.f, 0.f, 0.f, 0.f};
             if (nr < rows && 4 * hf < valid) {
                 const float* src = sb + (long)nr * a.snew_ld + 4 * hf;
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
 #pragma unroll
         for (int k = 0; k < kB2Ld; ++k) {
             const int e4 = lane + 64 * k;
-            const int nr = e4 >> 1, hf = e4 & 1;
+            const int nr = e4 / PPR, hf = e4 % PPR;
             if (nr < rows) {
                 st[(4 * hf + 0) * sn + nr] = r.sn[k].x; st[(4 * hf + 1) * sn + nr] = r.sn[k].y;
                 st[(4 * hf + 2) * sn + nr] = r.sn[k].z; st[(4 * hf + 3) * sn + nr] = r.sn[k].w;
@@ -590,41 +603,51 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         if (loader && !last) { if ((i + 1) & 1) ld_park(i + 1, ldB); else ld_park(i + 1, ldA); }
         __syncthreads();                                                         // barrier 2
         B2STAMP(3);
-        // ---- wave = row: recurrence of the 128 point scores, edge densities, bin masses (registers + DPP) ----
-        float acc0 = 0.f, acc1 = 0.f;
+        // ---- wave = rows: recurrence of the 128 point scores of each of its rows, edge densities, bin masses (registers + DPP) ----
+        float acc0[RPW], acc1[RPW];
         {
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) acc0[j] = acc1[j] = 0.f;
             for (int k0 = 0; k0 < tabw; k0 += 4) {
                 const int4 s0 = *reinterpret_cast<const int4*>(&tabb[n0 * tabw + k0]);
                 const int4 s1 = *reinterpret_cast<const int4*>(&tabb[n1 * tabw + k0]);
-                const float v0 = scc[max(s0.x, 0)], v1 = scc[max(s0.y, 0)], v2 = scc[max(s0.z, 0)], v3 = scc[max(s0.w, 0)];
-                const float w0 = scc[max(s1.x, 0)], w1 = scc[max(s1.y, 0)], w2 = scc[max(s1.z, 0)], w3 = scc[max(s1.w, 0)];
-                if (s0.x >= 0) acc0 = fmaf(val0, v0, acc0);
-                if (s0.y >= 0) acc0 = fmaf(val0, v1, acc0);
-                if (s0.z >= 0) acc0 = fmaf(val0, v2, acc0);
-                if (s0.w >= 0) acc0 = fmaf(val0, v3, acc0);
-                if (s1.x >= 0) acc1 = fmaf(val1, w0, acc1);
-                if (s1.y >= 0) acc1 = fmaf(val1, w1, acc1);
-                if (s1.z >= 0) acc1 = fmaf(val1, w2, acc1);
-                if (s1.w >= 0) acc1 = fmaf(val1, w3, acc1);
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    const float* sc = scc + j * kBRows * kScPitch;
+                    const float v0 = sc[max(s0.x, 0)], v1 = sc[max(s0.y, 0)], v2 = sc[max(s0.z, 0)], v3 = sc[max(s0.w, 0)];
+                    const float w0 = sc[max(s1.x, 0)], w1 = sc[max(s1.y, 0)], w2 = sc[max(s1.z, 0)], w3 = sc[max(s1.w, 0)];
+                    if (s0.x >= 0) acc0[j] = fmaf(val0, v0, acc0[j]);
+                    if (s0.y >= 0) acc0[j] = fmaf(val0, v1, acc0[j]);
+                    if (s0.z >= 0) acc0[j] = fmaf(val0, v2, acc0[j]);
+                    if (s0.w >= 0) acc0[j] = fmaf(val0, v3, acc0[j]);
+                    if (s1.x >= 0) acc1[j] = fmaf(val1, w0, acc1[j]);
+                    if (s1.y >= 0) acc1[j] = fmaf(val1, w1, acc1[j]);
+                    if (s1.z >= 0) acc1[j] = fmaf(val1, w2, acc1[j]);
+                    if (s1.w >= 0) acc1[j] = fmaf(val1, w3, acc1[j]);
+                }
             }
-            if (br0 >= 0) acc0 += Snew[wave * sn + br0];
-            if (br1 >= 0) acc1 += Snew[wave * sn + br1];
-            scn[lane] = acc0;
-            scn[lane + 64] = acc1;
-            // densities at the 129 edges: edge j (1..127) sits in the box of point j, edges 0 and 128 in none (score 0)
-            const float s0 = e0ok ? acc0 + cqr : 0.f, s1 = e1ok ? acc1 + cqr : 0.f;
-            const float md = fmaxf(wave_max(fmaxf(e0ok ? s0 : -INFINITY, e1ok ? s1 : -INFINITY)), 0.f);
-            const float d0 = expf(s0 - md), d1 = expf(s1 - md);
-            const float d128 = expf(0.f - md);
-            const float d0n = wave_shl1(d0, readlane_f32(d1, 0));               // D[lane + 1]
-            const float d1n = wave_shl1(d1, d128);                              // D[lane + 65]
-            const float d0nn = wave_shl1(d0n, readlane_f32(d1, 1));             // D[lane + 2]
-            const float d1nn = wave_shl1(d1n, 0.f);                             // D[lane + 66]  (lane 63: unused)
-            const float z = wave_sum((d0 + d0n) * dx0 + (d1 + d1n) * dx1) * 0.5f;
-            const float inv_z = 1.0f / z;
-            // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
-            Msm[wave * kMPitch + lane] = row_ok ? ((d0n * inv_z + d0nn * inv_z) * dxa) * 0.5f : 0.f;
-            if (lane + 64 < kBins - 1) Msm[wave * kMPitch + lane + 64] = row_ok ? ((d1n * inv_z + d1nn * inv_z) * dxb) * 0.5f : 0.f;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int row = wave + kBRows * j;
+                if (br0 >= 0) acc0[j] += Snew[row * sn + br0];
+                if (br1 >= 0) acc1[j] += Snew[row * sn + br1];
+                scn[j * kBRows * kScPitch + lane] = acc0[j];
+                scn[j * kBRows * kScPitch + lane + 64] = acc1[j];
+                // densities at the 129 edges: edge j (1..127) sits in the box of point j, edges 0 and 128 in none (score 0)
+                const float s0 = e0ok ? acc0[j] + cqr[j] : 0.f, s1 = e1ok ? acc1[j] + cqr[j] : 0.f;
+                const float md = fmaxf(wave_max(fmaxf(e0ok ? s0 : -INFINITY, e1ok ? s1 : -INFINITY)), 0.f);
+                const float d0 = expf(s0 - md), d1 = expf(s1 - md);
+                const float d128 = expf(0.f - md);
+                const float d0n = wave_shl1(d0, readlane_f32(d1, 0));               // D[lane + 1]
+                const float d1n = wave_shl1(d1, d128);                              // D[lane + 65]
+                const float d0nn = wave_shl1(d0n, readlane_f32(d1, 1));             // D[lane + 2]
+                const float d1nn = wave_shl1(d1n, 0.f);                             // D[lane + 66]  (lane 63: unused)
+                const float z = wave_sum((d0 + d0n) * dx0 + (d1 + d1n) * dx1) * 0.5f;
+                const float inv_z = 1.0f / z;
+                // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
+                Msm[row * kMPitch + lane] = row_ok[j] ? ((d0n * inv_z + d0nn * inv_z) * dxa) * 0.5f : 0.f;
+                if (lane + 64 < kBins - 1) Msm[row * kMPitch + lane + 64] = row_ok[j] ? ((d1n * inv_z + d1nn * inv_z) * dxb) * 0.5f : 0.f;
+            }
         }
         if (writer && (wave == 2 || wave == 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clear above is complete
         __syncthreads();                                                         // barrier 3
@@ -632,7 +655,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         if (tid < kBins - 1) {
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < kBRows; ++r) t += Msm[r * kMPitch + tid];
+            for (int r = 0; r < TR; ++r) t += Msm[r * kMPitch + tid];
             if (!(a.exp_flags & 16)) atomicAdd(&acc_cur[tid * kAccStride], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
         }
         if (loader) {
@@ -664,14 +687,18 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                     }
                 }
             }
-            // point scores after this step: own row from registers; wave 1 also row 0, wave 6 also row 7 (from LDS)
+            // point scores after this step: own rows from registers; wave 1 also wave 0's rows, wave 6 also wave 7's (from LDS)
             float* cr = a.crit_ring + slot * a.crit_slot + tile * kBins;
-            if (row_ok && !(a.exp_flags & 4)) { cr[wave * kBins + lane] = acc0; cr[wave * kBins + lane + 64] = acc1; }
-            const int extra = (wave == 1) ? 0 : ((wave == 6) ? kBRows - 1 : -1);
-            if (extra >= 0 && extra < valid) {
-                const float* sx = lds + ((i & 1) ? m.sc0 : m.sc1) + extra * kScPitch;            // that row's NEXT buffer
-                cr[extra * kBins + lane] = sx[lane];
-                cr[extra * kBins + lane + 64] = sx[lane + 64];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int row = wave + kBRows * j;
+                if (row_ok[j] && !(a.exp_flags & 4)) { cr[row * kBins + lane] = acc0[j]; cr[row * kBins + lane + 64] = acc1[j]; }
+                const int extra = (wave == 1) ? kBRows * j : ((wave == 6) ? kBRows * j + kBRows - 1 : -1);
+                if (extra >= 0 && extra < valid) {
+                    const float* sx = lds + ((i & 1) ? m.sc0 : m.sc1) + extra * kScPitch;        // that row's NEXT buffer
+                    cr[extra * kBins + lane] = sx[lane];
+                    cr[extra * kBins + lane + 64] = sx[lane + 64];
+                }
             }
         }
         { float* t = scc; scc = scn; scn = t; }
@@ -693,9 +720,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         // issued); Msm behind barrier 2; the rows read by waves 1 and 6 are rewritten behind barrier 2 of step i+1.
     }
     // ---- hand the point scores to the next launch (its set-up reads them back through pb) ----
-    if (row_ok) {
-        a.Sp_out[(tile + wave) * N + n0] = scc[lane];
-        a.Sp_out[(tile + wave) * N + n1] = scc[lane + 64];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int row = wave + kBRows * j;
+        if (row_ok[j]) {
+            a.Sp_out[(tile + row) * N + n0] = scc[j * kBRows * kScPitch + lane];
+            a.Sp_out[(tile + row) * N + n1] = scc[j * kBRows * kScPitch + lane + 64];
+        }
     }
 }
 
@@ -895,7 +926,9 @@ static hipError_t chain_batch_attr() {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel),
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel<1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel<2>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -912,14 +945,29 @@ bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q)
     return want_v2 && draw_mode == 1 && points_ok && 2 * rows <= 64 * kB2Ld && S <= 512 && S % 2 == 0 && Q % 4 == 0;
 }
 
+// Query rows per wave of chain_batch2_kernel for this shape: 2 (16-row tiles, half the workgroups -- each of which owns a
+// whole CU by its registers -- and half the arrivals per exchange) when the loader's register tile holds 16 scores per new
+// row; INFV_CHAIN_RPW=1 restores 8-row tiles.
+int chain_batch2_rpw(int rows, int Q) {
+    static const int want = [] { const char* e = getenv("INFV_CHAIN_RPW"); return e ? atoi(e) : 2; }();
+    if (want >= 2 && 4 * rows <= 64 * kB2Ld && Q > kBRows) return 2;
+    return 1;
+}
+
 bool chain_batch2_applies(const ChainBatchArgs& a) {
     return chain_batch2_shape_ok(a.draw_mode, a.st.points_ok, a.op.rows, a.S, a.Q) && a.crit_ring != nullptr;
 }
 
-static size_t chain_batch2_launch_lds(int N, int S, int rows, int tabw) {
+// Workgroups of the persistent role-S launch for this shape (the kernel launch_chain_batch will choose).
+int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int rows, int S) {
+    const int rpw = chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q) ? chain_batch2_rpw(rows, Q) : 1;
+    return H * ((Q + kBRows * rpw - 1) / (kBRows * rpw)) * L;
+}
+
+static size_t chain_batch2_launch_lds(int N, int S, int rows, int tabw, int rpw) {
     // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
     static const int pad = [] { const char* e = getenv("INFV_S_LDS"); return e ? atoi(e) : 0; }();
-    size_t lds = (size_t)batch2_smem(N, S, rows, tabw).total * sizeof(float);
+    size_t lds = (size_t)batch2_smem(N, S, rows, tabw, rpw).total * sizeof(float);
     if ((size_t)pad > lds) lds = pad;
     return lds;
 }
@@ -931,25 +979,34 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     hipError_t e;
-    if (chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q))
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel, kBNT, chain_batch2_launch_lds(N, S, rows, tabw));
-    else
+    if (chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q)) {
+        const int rpw = chain_batch2_rpw(rows, Q);
+        const size_t lds = chain_batch2_launch_lds(N, S, rows, tabw, rpw);
+        e = rpw == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel<2>, kBNT, lds)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel<1>, kBNT, lds);
+    } else {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch_kernel, kBNT, chain_batch_lds_bytes(N, S, rows, tabw));
+    }
     if (e != hipSuccess) return false;
     const int safe = per_cu > 1 ? per_cu - 1 : per_cu;
     return (long)safe * cus >= n_blocks;
 }
 
-hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream) {
+hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
     if (hipError_t e = chain_batch_attr()) return e;
-    if (a.n_steps <= 0) return hipSuccess;
-    const int blocks = a.H * a.QS * a.L;
-    if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, blocks)) return hipErrorInvalidValue;
+    if (a_in.n_steps <= 0) return hipSuccess;
+    ChainBatchArgs a = a_in;
+    if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, a.H * a.QS * a.L)) return hipErrorInvalidValue;
     if (chain_batch2_applies(a)) {
-        hipLaunchKernelGGL(chain_batch2_kernel, dim3(blocks), dim3(kBNT), chain_batch2_launch_lds(a.N, a.S, a.op.rows, a.op.tabw), stream, a);
+        const int rpw = chain_batch2_rpw(a.op.rows, a.Q);
+        a.QS = (a.Q + kBRows * rpw - 1) / (kBRows * rpw);             // tiles of 8 * rpw query rows
+        const int blocks = a.H * a.QS * a.L;
+        const size_t lds = chain_batch2_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
+        if (rpw == 2) hipLaunchKernelGGL(chain_batch2_kernel<2>, dim3(blocks), dim3(kBNT), lds, stream, a);
+        else hipLaunchKernelGGL(chain_batch2_kernel<1>, dim3(blocks), dim3(kBNT), lds, stream, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(chain_batch_kernel, dim3(blocks), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
+    hipLaunchKernelGGL(chain_batch_kernel, dim3(a.H * a.QS * a.L), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
                        stream, a);
     return hipGetLastError();
 }

@@ -61,7 +61,7 @@ hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames,
 // u: 1-KiB loads per group (two groups in flight per wave), nt: threads per workgroup (256 / 512), lds_pad: occupancy cap.
 bool pool_rows_supported(int P, int d);
 hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                            hipStream_t stream, int u, int nt, int lds_pad);
+                            hipStream_t stream, int u, int nt, int lds_pad, int max_wgs = 0);
 int project_splitk(int M, int K);
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream);
@@ -168,6 +168,7 @@ struct ChainBatchArgs {
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
 bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);
 bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch2_kernel (scores rebuilt by alpha_rows2)
+int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int rows, int S);   // workgroups of the launch for this shape
 // the chunk-parallel half of chain_batch2_kernel: full score rows from the published point scores + drawn bins, then alpha
 struct AlphaRows2Args {
     int N, H, Q, L, rows, tabw, n_steps;

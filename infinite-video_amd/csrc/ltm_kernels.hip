@@ -182,14 +182,15 @@ __global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ 
                                                        float* __restrict__ R) {
     typedef typename Tok::vec tvec;
     const int lane = threadIdx.x & 63;
-    const long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (unit >= n_units) return;
+    // grid-stride over units: a full grid gives every wave one unit; a smaller grid (launch_pool_rows' max_wgs) bounds the
+    // kernel's footprint on the chip for the whole launch
+    for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
     const int s = (int)(unit % slices);
     const long cr = unit / slices;
     const int r = (int)(cr % op.rows);
     const long c = cr / op.rows;
     const int c4 = s * 64 + lane;
-    if (c4 >= d4) return;
+    if (c4 >= d4) continue;
     const int fb = op.row_begin[r], fe = op.row_end[r];
     const float val = op.box_val[op.row_box[r]];
     const tvec* src = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)fb * P * d4 + c4;
@@ -233,13 +234,14 @@ __global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ 
         consume(va);
     }
     __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + (c * op.rows + r) * (long)d4 + c4);
+    }
 }
 
 bool pool_rows_supported(int P, int d) { return P % 4 == 0 && d % 4 == 0; }
 
 template <int U, int NT, class Tok>
 static hipError_t launch_pool_rows_v(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                     hipStream_t stream, int lds_pad) {
+                                     hipStream_t stream, int lds_pad, int max_wgs) {
     const int d4 = d / 4, slices = (d4 + 63) / 64;
     const long n_units = (long)n_chunks * op.rows * slices;
     if (lds_pad > 0) {
@@ -251,31 +253,33 @@ static hipError_t launch_pool_rows_v(const void* k, int n_chunks, int T, int P, 
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((pool_rows_kernel<U, NT, Tok>), dim3((unsigned)((n_units + NT / 64 - 1) / (NT / 64))), dim3(NT), lds_pad, stream,
+    unsigned grid = (unsigned)((n_units + NT / 64 - 1) / (NT / 64));
+    if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
+    hipLaunchKernelGGL((pool_rows_kernel<U, NT, Tok>), dim3(grid), dim3(NT), lds_pad, stream,
                        k, (long)T * P * d4, P, d4, slices, op, n_units, R);
     return hipGetLastError();
 }
 
 template <class Tok>
 static hipError_t launch_pool_rows_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                     hipStream_t stream, int u, int nt, int lds_pad) {
+                                     hipStream_t stream, int u, int nt, int lds_pad, int max_wgs) {
     if (P % 8 != 0 && u > 4) u = 4;
     if (nt == 512) {
-        if (u >= 8) return launch_pool_rows_v<8, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
-        if (u >= 4) return launch_pool_rows_v<4, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
-        return launch_pool_rows_v<2, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+        if (u >= 8) return launch_pool_rows_v<8, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
+        if (u >= 4) return launch_pool_rows_v<4, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
+        return launch_pool_rows_v<2, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
     }
-    if (u >= 8) return launch_pool_rows_v<8, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
-    if (u >= 4) return launch_pool_rows_v<4, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
-    return launch_pool_rows_v<2, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad);
+    if (u >= 8) return launch_pool_rows_v<8, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
+    if (u >= 4) return launch_pool_rows_v<4, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
+    return launch_pool_rows_v<2, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
 }
 
 hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                            hipStream_t stream, int u, int nt, int lds_pad) {
+                            hipStream_t stream, int u, int nt, int lds_pad, int max_wgs) {
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
     if (!pool_rows_supported(P, d)) return hipErrorInvalidValue;
-    return k_bf16 ? launch_pool_rows_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad)
-                  : launch_pool_rows_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad);
+    return k_bf16 ? launch_pool_rows_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad, max_wgs)
+                  : launch_pool_rows_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad, max_wgs);
 }
 
 // ======================================================================================
@@ -416,10 +420,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 //     10.3 -> 7.1 ms busy, 111 k -> 115 k chunks/s (with the pooling kernel's padding LDS at 84 KB, so that a 74 KB
 //     workgroup of this kernel still fits beside a pooling workgroup).
 // ======================================================================================
+#ifndef INFV_LW_WAVES
+#define INFV_LW_WAVES 2
+#endif
 __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BM, int BN, int NT>
-__global__ __launch_bounds__(512) void gemm_nt_lw_kernel(const float* __restrict__ A, int M, int K, WSegs segs,
+__global__ __launch_bounds__(512, INFV_LW_WAVES) void gemm_nt_lw_kernel(const float* __restrict__ A, int M, int K, WSegs segs,
                                                          float* __restrict__ C, int ldc, long split_stride) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32, BR = BN / 32;

@@ -1,0 +1,3 @@
+export INFV_HOST_TRACE=1
+echo "== new 256/8"; INFV_PR_NT=256 INFV_PR_U=8 python tools/one_pass.py 2048 3 2>&1 | tail -4
+echo "== old"; INFV_POOL_ROWS=0 python tools/one_pass.py 2048 3 2>&1 | tail -4
