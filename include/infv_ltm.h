@@ -119,6 +119,26 @@ int infv_ltm_destroy(infv_ltm_handle h);
 int infv_ltm_set_plan(infv_ltm_handle h, const infv_ltm_plan* plan);
 int infv_ltm_has_plan(infv_ltm_handle h, int32_t T);          /* 1 / 0 */
 
+/* Dense form of the operators of one chunk length, for num_basis values whose fp32 box bounds
+ * (basis_functions.py:248-250) overlap or leave gaps at a sample position, histogram edge or resampling point: psi(t)
+ * then has two ones, F F^T is not diagonal and G (long_term_attention_gibbs.py:68-84) has two non-zeros in some rows.
+ * The host computes G with the reference's own fp32 sequence (F^T (F F^T + ridge I)^-1 via LAPACK, trimmed) and hands
+ * it over transposed, together with the (up to two) boxes of every point the step evaluates psi at.  Registered IN
+ * ADDITION to infv_ltm_set_plan for the same T (whose readout_w / edge_dx / n_bins stay in force; its one-box tables
+ * are ignored).  With a dense plan every entry point runs the per-call step with dense kernels (update = x . G on fp32
+ * MFMA); infv_ltm_consolidate loops over chunks.  All pointers are HOST pointers. */
+typedef struct {
+    int32_t T;
+    int32_t first_K;                  /* rows of the first-chunk operator (= T)                       */
+    const float*   first_GT;          /* [N][first_K]  G_first transposed                             */
+    int32_t inf_K;                    /* rows of the infinite-memory operator (= S + T)               */
+    const float*   inf_GT;            /* [N][inf_K]    G_inf transposed; rows 0..S-1 = resampled, then the T frames */
+    const int32_t* bin_box2;          /* [n_bins][2]   boxes containing the unmodified left edge of bin b, -1 = none (:207-208) */
+    const int32_t* edge_box2;         /* [n_bins+1][2] boxes containing each modified histogram edge (:197-200)      */
+    const int32_t* uniform_box2;      /* [S][2]        boxes of the non-sticky resample positions (:153-157,212)     */
+} infv_ltm_dense_plan;
+int infv_ltm_set_dense_plan(infv_ltm_handle h, const infv_ltm_dense_plan* plan);
+
 /* new_doc=True (long_term_attention_gibbs.py:300-302): forget the memory. */
 int infv_ltm_reset(infv_ltm_handle h);
 int infv_ltm_has_memory(infv_ltm_handle h);                    /* 1 / 0 */

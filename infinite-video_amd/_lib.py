@@ -46,6 +46,15 @@ class PlanStruct(C.Structure):
     ]
 
 
+class DensePlanStruct(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32),
+        ("first_K", C.c_int32), ("first_GT", f32p),
+        ("inf_K", C.c_int32), ("inf_GT", f32p),
+        ("bin_box2", i32p), ("edge_box2", i32p), ("uniform_box2", i32p),
+    ]
+
+
 class Proj(C.Structure):
     _fields_ = [("wk", C.c_void_p), ("bk", C.c_void_p), ("wv", C.c_void_p), ("bv", C.c_void_p)]
 
@@ -87,6 +96,7 @@ _SIGNATURES = {
     "infv_ltm_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "infv_ltm_destroy": (C.c_int, [C.c_void_p]),
     "infv_ltm_set_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanStruct)]),
+    "infv_ltm_set_dense_plan": (C.c_int, [C.c_void_p, C.POINTER(DensePlanStruct)]),
     "infv_ltm_has_plan": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_reset": (C.c_int, [C.c_void_p]),
     "infv_ltm_has_memory": (C.c_int, [C.c_void_p]),

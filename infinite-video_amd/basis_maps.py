@@ -40,6 +40,11 @@ def _box_bounds(N: int):
     return mu - width / 2, mu + width / 2
 
 
+class OverlappingBoxes(UnsupportedBasis):
+    """A point the step evaluates psi at lies in two fp32 boxes: the sparse (one non-zero per row) form does not apply;
+    ``build_plan`` then builds the dense form."""
+
+
 def box_of(t: torch.Tensor, N: int) -> np.ndarray:
     """Index of the box containing each fp32 point, -1 for none."""
     lo, hi = _box_bounds(N)
@@ -47,10 +52,44 @@ def box_of(t: torch.Tensor, N: int) -> np.ndarray:
     inside = (t >= lo) & (t < hi)
     n_hit = inside.sum(1)
     if int(n_hit.max()) > 1:
-        raise UnsupportedBasis(f"a sample position lies in two boxes for num_basis={N}")
+        raise OverlappingBoxes(f"a sample position lies in two boxes for num_basis={N}")
     idx = inside.float().argmax(1).to(torch.int32)
     idx[n_hit == 0] = -1
     return idx.numpy()
+
+
+def boxes2_of(t: torch.Tensor, N: int) -> np.ndarray:
+    """[M, 2] int32: the (at most two, adjacent) boxes containing each fp32 point, -1 padded, ascending."""
+    lo, hi = _box_bounds(N)
+    t = t.to(torch.float32).reshape(-1, 1)
+    inside = ((t >= lo) & (t < hi)).numpy()
+    if int(inside.sum(1).max(initial=0)) > 2:
+        raise UnsupportedBasis(f"a point lies in more than two boxes for num_basis={N}")
+    out = np.full((inside.shape[0], 2), -1, dtype=np.int32)
+    for i, row in enumerate(inside):
+        hit = np.flatnonzero(row)
+        out[i, :len(hit)] = hit
+    return out
+
+
+def membership(t: torch.Tensor, N: int) -> torch.Tensor:
+    """psi(t) as the reference evaluates it (basis_functions.py:227-250): [M, N] fp32 zeros and ones."""
+    lo, hi = _box_bounds(N)
+    t = t.to(torch.float32).reshape(-1, 1)
+    return ((t >= lo) & (t < hi)).float()
+
+
+def _dense_operator_T(l: int, positions: torch.Tensor, N: int) -> np.ndarray:
+    """G^T [N, l] of compute_G (long_term_attention_gibbs.py:68-84) with the reference's own fp32 ATen sequence:
+    F = psi(positions)^T, G = F^T (F F^T + ridge I)^-1 (``Tensor.inverse`` on the CPU), padding rows trimmed."""
+    F = torch.zeros(N, positions.size(0))
+    F[:, :] = membership(positions, N).t()
+    G = F.t().matmul((F.matmul(F.t()) + RIDGE_PENALTY * torch.eye(N)).inverse())
+    b, e = _trimmed(G.size(0), l)
+    G = G[b:e]
+    if G.size(0) != l:
+        raise UnsupportedBasis("padding trim does not leave one row per sample")
+    return np.ascontiguousarray(G.t().numpy(), dtype=np.float32)
 
 
 def _positions_first(T: int) -> torch.Tensor:          # :104-110
@@ -131,12 +170,69 @@ class Plan:
     edge_dx: np.ndarray
     bin_box: np.ndarray
     uniform_idx: np.ndarray
+    # dense form (num_basis whose fp32 boxes overlap at a point the step evaluates): infv_ltm_set_dense_plan
+    dense: bool = False
+    first_GT: np.ndarray = None       # [N, T]      G_first transposed
+    inf_GT: np.ndarray = None         # [N, S + T]  G_inf transposed
+    bin_box2: np.ndarray = None       # [NB_BINS, 2]
+    edge_box2: np.ndarray = None      # [NB_BINS + 1, 2]
+    uniform_box2: np.ndarray = None   # [S, 2]
+
+
+def _first_box(pairs: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(pairs[:, 0], dtype=np.int32)
+
+
+def _build_dense_plan(T: int, N: int, tau: float, S: int) -> Plan:
+    """Plan for a num_basis whose boxes overlap where the step looks: dense operators from the reference's sequence and
+    two-box tables for the histogram edges and the resampling points.  The 1000-point grid of expected_value()
+    (long_term_attention_gibbs.py:251-286) must still see at most one box per point (true for every multiple of 16 up
+    to 512 except 432): the read-out keeps its closed form."""
+    t = torch.linspace(0, 1, GRID_POINTS)
+    gbox2 = boxes2_of(t, N)
+    if int((gbox2[:, 1] >= 0).sum()):
+        raise UnsupportedBasis(f"a point of the read-out grid lies in two boxes for num_basis={N}")
+    gbox = gbox2[:, 0]
+    dx = (t[1:] - t[:-1]).double().numpy()
+    wt = np.zeros(GRID_POINTS)
+    wt[:-1] += dx / 2
+    wt[1:] += dx / 2
+    w = np.zeros(N)
+    np.add.at(w, gbox[gbox >= 0], wt[gbox >= 0])
+    bins = torch.linspace(0, 1, NB_BINS + 1)
+    mod = bins.clone()
+    mod[0] = -.000001
+    mod[-1] = 1.000001
+    edge_dx = (mod[1:] - mod[:-1]).numpy().astype(np.float32)
+    t_uni = (torch.arange(1, S + 1).float() * tau / S) / tau
+    bin_box2, edge_box2, uniform_box2 = boxes2_of(bins[:-1], N), boxes2_of(mod, N), boxes2_of(t_uni, N)
+    none_i = np.zeros(0, dtype=np.int32)
+    zeros_n = np.zeros(N, dtype=np.float32)
+    return Plan(
+        T=T, N=N, tau=tau, S=S,
+        # the sparse operator tables are unused with a dense plan: empty but valid
+        first_row_box=none_i, first_row_begin=none_i, first_row_end=none_i, first_box_val=zeros_n,
+        inf_row_box=none_i, inf_row_begin=none_i, inf_row_end=none_i, inf_box_val=zeros_n,
+        inf_old_ptr=np.zeros(N + 1, dtype=np.int32), inf_old_slot=none_i,
+        readout_w=w.astype(np.float32), readout_w_out=float(wt[gbox < 0].sum()),
+        edge_box=_first_box(edge_box2), edge_dx=edge_dx, bin_box=_first_box(bin_box2), uniform_idx=_first_box(uniform_box2),
+        dense=True, first_GT=_dense_operator_T(T, _positions_first(T), N),
+        inf_GT=_dense_operator_T(S + T, _positions_inf(T, tau, S), N),
+        bin_box2=np.ascontiguousarray(bin_box2), edge_box2=np.ascontiguousarray(edge_box2),
+        uniform_box2=np.ascontiguousarray(uniform_box2))
 
 
 @lru_cache(maxsize=64)
 def build_plan(T: int, N: int, tau: float, S: int = NB_SAMPLES) -> Plan:
     if T < 2:
         raise UnsupportedBasis("chunks of a single frame are empty in the reference (G[0:-0])")
+    try:
+        return _build_sparse_plan(T, N, tau, S)
+    except OverlappingBoxes:
+        return _build_dense_plan(T, N, tau, S)
+
+
+def _build_sparse_plan(T: int, N: int, tau: float, S: int) -> Plan:
     # first-chunk operator
     frame_box, first_val = _operator(T, _positions_first(T), N)
     f_box, f_beg, f_end = _frame_ranges(frame_box)

@@ -60,8 +60,17 @@ struct Operator {
     }
 };
 
+// Dense form of a plan's operators (infv_ltm_set_dense_plan): num_basis whose fp32 boxes overlap
+struct DensePlan {
+    bool on = false;
+    int first_K = 0, inf_K = 0;
+    DeviceBuf first_GT, inf_GT;        // [N][K]
+    DeviceBuf bin_box2, edge_box2, uniform_box2;
+};
+
 struct Plan {
     int T = 0;
+    DensePlan dense;
     Operator first, inf;
     DeviceBuf w, edge_box, edge_dx, bin_box, uniform_idx;
     float w_out = 0.f;
@@ -300,6 +309,56 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
     return INFV_OK;
 }
 
+// One step with dense operators (ltm_dense.hip): draw -> B = x . G -> project the whole memory -> scores, softmax weights,
+// read-out -> sticky masses with two-box edges.  Same state layout as chain_step; the K'/V' rows are re-projected from B.
+int dense_step(infv_ltm_handle h, const Plan& plan, const float* kbar, int T, const float* q, int Q, const ProjPtrs& pp,
+               const double* u, float* ctx, hipStream_t stream) {
+    const bool inf = h->has_memory;
+    const DensePlan& dp = plan.dense;
+    const int32_t* bins = nullptr;
+    int bins_stride = 0;
+    const int32_t* pos_box2 = dp.uniform_box2.as<int32_t>();
+    if (inf && h->cfg.sticky) {
+        if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
+        if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+        Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
+        HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(), h->override_mask,
+                            plan.sticky(), u, h->S, h->L, h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(),
+                            stream, h->bins_forced.as<int32_t>(), h->forced_mask));
+        h->override_mask = 0;
+        // a forced draw replaces the resampled bins (infv_ltm_set_bins); get_draw still returns the step's own
+        bins = h->forced_mask ? h->bins_forced.as<int32_t>() : h->bins.as<int32_t>();
+        if (h->forced_mask && h->forced_mask != (1u << h->L) - 1u)
+            return fail(INFV_ERR_UNSUPPORTED, "dense plans: infv_ltm_set_bins must force every layer of the handle or none");
+        h->forced_mask = 0;
+        bins_stride = h->S;
+        pos_box2 = dp.bin_box2.as<int32_t>();
+    }
+    const int nxt = h->cur ^ 1;
+    {
+        Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
+        HIP_TRY(launch_dense_update(inf ? dp.inf_GT.as<float>() : dp.first_GT.as<float>(), inf ? dp.inf_K : dp.first_K,
+                                    inf ? dp.inf_K : dp.first_K, inf ? h->S : 0, bins, bins_stride, pos_box2,
+                                    h->B[h->cur].as<float>(), kbar, h->B[nxt].as<float>(), h->N, h->d, h->L, stream));
+    }
+    h->cur = nxt;
+    h->has_memory = true;
+    HIP_TRY(launch_reproject(h->B[h->cur].as<float>(), h->N, h->d, h->dm, h->L, pp, h->KV[h->cur].as<float>(), stream));
+    h->k_stale = false;
+    {
+        Timed t_(h->prof, INFV_KERNEL_ATTEND, stream);
+        HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
+                              plan.sticky(), ctx, h->bin_part[h->pc].as<float>(), h->scores.as<float>(), stream));
+        // the attend kernel's partials assume one box per edge: recompute them from the scores with the two-box table
+        HIP_TRY(launch_dense_masses(h->scores.as<float>(), Q, h->N, h->H, h->L, dp.edge_box2.as<int32_t>(),
+                                    plan.edge_dx.as<float>(), h->bin_part[h->pc].as<float>(), stream));
+    }
+    h->parts = h->H;
+    h->lastQ = Q;
+    h->last_fast = false;
+    return INFV_OK;
+}
+
 int find_plan(infv_ltm_handle h, int T, Plan** out) {
     auto it = h->plans.find(T);
     if (it == h->plans.end()) return fail(INFV_ERR_NO_PLAN, "no plan registered for chunk length T=%d", T);
@@ -455,6 +514,31 @@ int infv_ltm_has_plan(infv_ltm_handle h, int32_t T) {
     return h->plans.count(T) ? 1 : 0;
 }
 
+int infv_ltm_set_dense_plan(infv_ltm_handle h, const infv_ltm_dense_plan* p) {
+    if (int rc = check_handle(h)) return rc;
+    if (!p || !p->first_GT || !p->inf_GT || !p->bin_box2 || !p->edge_box2 || !p->uniform_box2)
+        return fail(INFV_ERR_INVALID, "dense plan: null argument");
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, p->T, &plan)) return rc;          // the regular plan of this T carries readout_w / edge_dx
+    if (p->first_K != p->T || p->inf_K != h->S + p->T)
+        return fail(INFV_ERR_INVALID, "dense plan: first_K=%d inf_K=%d, expected %d and %d", p->first_K, p->inf_K, p->T, h->S + p->T);
+    auto check_pairs = [&](const int32_t* t, int n) {
+        for (int i = 0; i < 2 * n; ++i) if (t[i] < -1 || t[i] >= h->N) return false;
+        return true;
+    };
+    if (!check_pairs(p->bin_box2, h->n_bins) || !check_pairs(p->edge_box2, h->n_bins + 1) || !check_pairs(p->uniform_box2, h->S))
+        return fail(INFV_ERR_INVALID, "dense plan: box index out of range");
+    DensePlan& d = plan->dense;
+    HIP_TRY(upload(d.first_GT, p->first_GT, (size_t)h->N * p->first_K));
+    HIP_TRY(upload(d.inf_GT, p->inf_GT, (size_t)h->N * p->inf_K));
+    HIP_TRY(upload(d.bin_box2, p->bin_box2, (size_t)2 * h->n_bins));
+    HIP_TRY(upload(d.edge_box2, p->edge_box2, (size_t)2 * (h->n_bins + 1)));
+    HIP_TRY(upload(d.uniform_box2, p->uniform_box2, (size_t)2 * h->S));
+    d.first_K = p->first_K; d.inf_K = p->inf_K;
+    d.on = true;
+    return INFV_OK;
+}
+
 int infv_ltm_reset(infv_ltm_handle h) {
     if (int rc = check_handle(h)) return rc;
     h->has_memory = false;
@@ -493,6 +577,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     if (int rc = find_plan(h, T, &plan)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const ProjPtrs pp = make_proj(proj, h->L);
+    if (plan->dense.on) return dense_step(h, *plan, kbar, T, q, Q, pp, u, ctx, stream);
     if (h->k_stale && h->has_memory)
         if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
     int sk = 1; long ss = 0;
@@ -512,6 +597,12 @@ int infv_ltm_steps(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32
     const ProjPtrs pp = make_proj(proj, h->L);
     const size_t chunk_kbar = (size_t)T * h->d, chunk_q = (size_t)h->L * Q * h->dm, chunk_u = (size_t)h->L * h->S;
     int c = 0;
+    if (plan->dense.on) {                                     // dense operators: chunk by chunk
+        for (; c < n_chunks; ++c)
+            if (int rc = infv_ltm_step(h, kbar + c * chunk_kbar, T, q + c * chunk_q, Q, proj, u ? u + c * chunk_u : nullptr,
+                                       ctx + c * chunk_q, stream_)) return rc;
+        return INFV_OK;
+    }
     if (!h->has_memory && n_chunks > 0) {                     // first chunk of a document: its own operator
         if (int rc = infv_ltm_step(h, kbar, T, q, Q, proj, u, ctx, stream_)) return rc;
         c = 1;
@@ -951,7 +1042,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     if (new_doc) infv_ltm_reset(h);
     if (n_chunks == 0) return INFV_OK;
     const int rows_max = plan->first.rows > plan->inf.rows ? plan->first.rows : plan->inf.rows;
-    if (!chain_supported(h->N, h->S, rows_max, plan->inf.tabw) || (h->L * h->H * Q) % 128 != 0 || (h->L * h->dm) % 128 != 0 ||
+    if (plan->dense.on || !chain_supported(h->N, h->S, rows_max, plan->inf.tabw) || (h->L * h->H * Q) % 128 != 0 || (h->L * h->dm) % 128 != 0 ||
         !uc_supported(h->N, h->d, h->dm, plan->inf.tabw, rows_max)) {
         // shapes the fused chain kernel cannot hold in LDS: per-chunk stage kernels
         for (int c = 0; c < n_chunks; ++c) {

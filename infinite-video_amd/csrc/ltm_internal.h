@@ -217,6 +217,16 @@ hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_c
                              long chunk_stride, long row_stride, long layer_stride, int splitk, long split_stride,
                              const ProjPtrs& proj, float* Snew, float* cq, hipStream_t stream);
 
+// ---- dense-operator form of the step (ltm_dense.hip): num_basis whose fp32 boxes overlap ----
+// B_next[l][n] = sum_r GT[n][r] x_l[r];  x_l[r < n_old] = sum of the memory rows of pos_box2[p(l, r)] (p = bins[l][r] for
+// the sticky draw, r itself for the uniform resampling), x_l[r >= n_old] = kbar[r - n_old]
+hipError_t launch_dense_update(const float* GT, int K, int ldg, int n_old, const int32_t* bins, int bins_stride,
+                               const int32_t* pos_box2, const float* B_prev, const float* kbar, float* B_next, int N, int d,
+                               int n_layers, hipStream_t stream);
+// part[l][h][j] = sum_q trapezoid mass of interval j+1 of row (h, q)'s 129-edge density; an edge may lie in two boxes
+hipError_t launch_dense_masses(const float* scores, int Q, int N, int H, int n_layers, const int32_t* edge_box2,
+                               const float* edge_dx, float* part, hipStream_t stream);
+
 // part[l][0][j] = acc[l][j] / 2^40 (fast path -> per-call path hand-over of the sticky histogram)
 hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream);
 // bin_mass[j] = sum over parts of bin_part[layer][p][j]

@@ -104,6 +104,17 @@ class LTMEngine:
             bin_box=ip("bin_box"), uniform_idx=ip("uniform_idx"))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_set_plan(self._h, C.byref(s)))
+            if p.dense:
+                # num_basis whose fp32 boxes overlap where the step looks: dense operators (x . G on fp32 MFMA) and
+                # two-box tables; every entry point then takes the per-call dense step
+                dn = dict(first_GT=_np_f32(p.first_GT), inf_GT=_np_f32(p.inf_GT), bin_box2=_np_i32(p.bin_box2),
+                          edge_box2=_np_i32(p.edge_box2), uniform_box2=_np_i32(p.uniform_box2))
+                ds = _lib.DensePlanStruct(
+                    T=int(T), first_K=int(p.first_GT.shape[1]), first_GT=dn["first_GT"].ctypes.data_as(_lib.f32p),
+                    inf_K=int(p.inf_GT.shape[1]), inf_GT=dn["inf_GT"].ctypes.data_as(_lib.f32p),
+                    bin_box2=dn["bin_box2"].ctypes.data_as(_lib.i32p), edge_box2=dn["edge_box2"].ctypes.data_as(_lib.i32p),
+                    uniform_box2=dn["uniform_box2"].ctypes.data_as(_lib.i32p))
+                _lib.check(self.lib.infv_ltm_set_dense_plan(self._h, C.byref(ds)))
         self._plans[T] = p
         return p
 

@@ -35,6 +35,7 @@ class Case:
     q_scale: float = 1.0
     seed_base: int = 1000
     store_full_B: bool = True      # else: every 16th row + per-row sums
+    dense: bool = False            # num_basis whose fp32 boxes overlap: the reference's operators are stored dense
 
     @property
     def P(self): return 32 if self.variant == "VL" else 196
@@ -60,6 +61,15 @@ CASES = [
     # (For many such values -- 48, 80, 96, 192, ... -- neighbouring fp32 boxes overlap at a sample position, the
     # reference's G is no longer one-non-zero-per-row and basis_maps.build_plan refuses them; 144 is one that works.)
     Case("n144", N=144, chunk_T=[12, 12, 9, 12], seed_base=7000, n_layers=1),
+]
+
+
+# num_basis whose fp32 boxes overlap (or leave a gap) exactly where the step evaluates psi: two non-zeros in some rows of
+# the reference's G, histogram edges and resampling points that lie in two boxes (or in none).  Separate list: the
+# sparse-form tests iterate over CASES.
+DENSE_CASES = [
+    Case("n96_dense", N=96, chunk_T=[16, 16, 12, 16], seed_base=8000, n_layers=2, dense=True),
+    Case("n48_uniform_dense", N=48, sticky=False, chunk_T=[8, 8, 8], seed_base=8500, n_layers=1, dense=True),
 ]
 
 

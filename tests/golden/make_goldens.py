@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from tests.golden.cases import CASES, Case, call_seed, case_inputs, golden_path
+from tests.golden.cases import CASES, DENSE_CASES, Case, call_seed, case_inputs, golden_path
 
 REF = {
     "VL": "/root/reference/infty-Video-LLaMA/InfVideoLLaMA/models",
@@ -123,6 +123,12 @@ def run_case(case: Case):
             # operators of this chunk length, from the first layer (identical across layers)
             if f"T{T}_first_col" not in out:
                 m0 = layers[0]
+                if case.dense:
+                    # operators with two non-zeros in some rows: stored as the reference built them
+                    out[f"T{T}_first_G"] = m0.Gs[T].cpu().numpy().astype(np.float32).copy()
+                    out[f"T{T}_inf_G"] = m0.G_inf.cpu().numpy().astype(np.float32).copy()
+                    out[f"T{T}_uniform_samples"] = m0.samples.cpu().numpy().astype(np.uint8).copy()
+                    continue
                 fc, fv, fn = sparse_rows(m0.Gs[T].cpu())
                 ic, iv, inn = sparse_rows(m0.G_inf.cpu())
                 assert fn <= 1 and inn <= 1, "reference operator is not one-nonzero-per-row"
@@ -138,7 +144,7 @@ def main(argv):
     names = set(argv[1:])
     work = tempfile.mkdtemp()       # the VL reference pickles ./alphas_uniform on every call
     os.chdir(work)
-    for case in CASES:
+    for case in CASES + DENSE_CASES:
         if names and case.name not in names:
             continue
         out = run_case(case)

@@ -10,7 +10,7 @@ import pytest
 
 from infinite_video_amd import _lib, basis_maps
 from oracle import ltm_oracle as O
-from tests.golden.cases import CASES, load_golden
+from tests.golden.cases import CASES, DENSE_CASES, load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -75,7 +75,7 @@ def test_library_exports_every_declared_symbol():
     """include/infv_ltm.h <-> libinfv_ltm.so <-> the ctypes table, without touching a GPU."""
     header = open(os.path.join(ROOT, "include", "infv_ltm.h")).read()
     header += open(os.path.join(ROOT, "include", "infv_vqf.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(infv_(?:ltm|vqf)_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(infv_(?:ltm|vqf)_[a-z_0-9]+)\s*\(", header, re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = _lib.load()
@@ -113,15 +113,38 @@ def test_memory_file_format_rejects_foreign_files(tmp_path):
         load_memory(p, [], "cpu")
 
 
-def test_plan_refuses_num_basis_whose_fp32_boxes_overlap():
-    """For many non-power-of-two num_basis values neighbouring boxes (fp32 mu +/- width/2, BASIS.py:248-250) overlap at a
-    sample position: the reference's ridge operator then has two non-zeros in a row and the sparse closed form does
-    not apply.  The plan builder must refuse them loudly instead of computing something else."""
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: c.name)
+def test_dense_plan_matches_reference_operators(case):
+    """num_basis whose fp32 boxes (mu +/- width/2, BASIS.py:248-250) overlap at a sample position: the reference's ridge
+    operator has two non-zeros in some rows.  ``build_plan`` then returns the DENSE form -- G from the reference's own ATen
+    sequence, two-box tables for the resampling points -- and it must equal what the real reference built
+    (tests/golden/make_goldens.py stores ``Gs[T]``, ``G_inf`` and ``samples`` of such cases as they are)."""
+    g = load_golden(case)
+    for T in sorted(set(case.chunk_T)):
+        p = basis_maps.build_plan(T, case.N, case.tau)
+        assert p.dense and p.first_GT.shape == (case.N, T) and p.inf_GT.shape == (case.N, 512 + T)
+        # (Tensor.inverse is LAPACK: allow the last bits to depend on the host's BLAS kernels)
+        np.testing.assert_allclose(p.first_GT.T, g[f"T{T}_first_G"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(p.inf_GT.T, g[f"T{T}_inf_G"], rtol=0, atol=1e-6)
+        assert int((p.inf_GT != 0).sum(0).max()) == 2            # the reason the sparse form does not apply
+        smp = g[f"T{T}_uniform_samples"]                          # [S, N] psi of the uniform resampling positions
+        for s_, (a, b) in enumerate(p.uniform_box2):
+            assert sorted(np.flatnonzero(smp[s_]).tolist()) == sorted(x for x in (int(a), int(b)) if x >= 0)
+
+
+def test_every_multiple_of_16_has_a_plan_and_sparse_ones_stay_sparse():
+    """``UnsupportedBasis`` is gone for the multiples of 16 the kernels accept (N <= 256); values whose boxes partition
+    the samples keep the sparse closed form."""
+    for N in range(16, 257, 16):
+        for T in (8, 255, 256):
+            p = basis_maps.build_plan(T, N, .75)
+            assert p.N == N
+    for N in (64, 128, 144, 256):
+        assert not basis_maps.build_plan(256, N, .75).dense
     for N in (48, 96, 192):
-        with pytest.raises(basis_maps.UnsupportedBasis):
-            basis_maps.build_plan(256, N, .75)
-    for N in (144, 272):                                   # non-power-of-two values whose boxes do partition the samples
-        basis_maps.build_plan(256, N, .75)
+        assert basis_maps.build_plan(256, N, .75).dense
+    with pytest.raises(basis_maps.UnsupportedBasis):             # a read-out grid point in two boxes: no closed form
+        basis_maps.build_plan(16, 432, .75)
 
 
 def test_bench_gpus_flag_spawns_ranks_without_touching_the_gpu(monkeypatch):

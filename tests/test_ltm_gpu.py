@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import ltm_oracle as O
-from tests.golden.cases import CASES, call_uniforms, case_inputs, load_golden
+from tests.golden.cases import CASES, DENSE_CASES, call_uniforms, case_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +81,42 @@ def test_chain_free_running_matches_oracle_and_reference(dev, case):
             np.testing.assert_allclose(ctx[l], g[tag + "_ctx"], rtol=0, atol=CTX_TOL)
             sc = eng.last_scores(l, case.Q)
             np.testing.assert_allclose(sc, orc[l].S_prev, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: c.name)
+def test_dense_operator_chain_matches_the_reference(dev, case):
+    """num_basis whose fp32 boxes overlap (N = 96 sticky, N = 48 uniform resampling): the plan is the dense form (x . G on
+    fp32 MFMA with the reference's own G, resampled rows and histogram edges that lie in two boxes).  The free-running HIP
+    chain must reproduce the REAL reference's run (goldens): every drawn bin, probabilities, B, contexts, scores; and
+    ``consolidate`` (which loops over chunks for such plans) must equal the per-chunk chain bit for bit."""
+    g = load_golden(case)
+    ks, qs, ws = case_inputs(case)
+    eng = _engine(case, dev)
+    assert eng.ensure_plan(case.chunk_T[0]).dense
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    q = torch.from_numpy(np.stack(qs)).to(dev)
+    outs = []
+    for c in range(len(case.chunk_T)):
+        new_doc = c in case.new_doc_at
+        u = np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)])
+        ctx = eng.forward(torch.from_numpy(ks[c]).to(dev), q, projs, torch.from_numpy(u).to(dev), new_doc=new_doc)
+        outs.append(ctx.clone())
+        ctx = ctx.cpu().numpy()
+        for l in range(case.n_layers):
+            tag = f"c{c}_l{l}"
+            if case.sticky and not new_doc:
+                bins, _, probs = eng.last_draw(l)
+                np.testing.assert_allclose(probs, g[tag + "_probs"], rtol=2e-5, atol=1e-9)
+                np.testing.assert_array_equal(bins, g[tag + "_bins"])      # == the reference's own draw
+            B, _ = eng.export_state(l)
+            _golden_B_check(case, g, tag, B.cpu().numpy())
+            np.testing.assert_allclose(ctx[l], g[tag + "_ctx"], rtol=0, atol=CTX_TOL)
+            np.testing.assert_allclose(eng.last_scores(l, case.Q), g[tag + "_scores"], rtol=1e-4, atol=2e-5)
+    if len(set(case.chunk_T)) == 1:
+        eng2 = _engine(case, dev)
+        us = np.stack([[call_uniforms(case, c, l) for l in range(case.n_layers)] for c in range(len(case.chunk_T))])
+        whole = eng2.consolidate(torch.from_numpy(np.stack(ks)).to(dev), q, projs, torch.from_numpy(us).to(dev), new_doc=True)
+        assert torch.equal(whole, torch.stack(outs))
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c.sticky], ids=lambda c: c.name)
