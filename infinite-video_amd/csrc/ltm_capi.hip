@@ -433,7 +433,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
     }
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        e = h->mass_acc[i].reserve((size_t)h->L * 128 * kAccStride * sizeof(unsigned long long));
+        e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
     if (e == hipSuccess) e = h->wc_flags.reserve(8 * sizeof(unsigned long long));

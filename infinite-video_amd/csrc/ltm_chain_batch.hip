@@ -52,6 +52,27 @@ __host__ __device__ inline BatchSmem batch_smem(int N, int S, int rows, int tabw
 
 __device__ inline unsigned long long coherent_read(unsigned long long* p) { return atomicAdd(p, 0ull); }
 
+// Poll of a layer's accumulator words by one wave: lane i reads words (2 i, 2 i + 1) = bins (i, i + 64) (acc_word) with ONE
+// 16-byte buffer load that bypasses the vector L1 and is served past the XCD's L2 (sc1).  The words are only ever written
+// by device-scope atomics, which execute at the memory side and leave no line behind in any L2, so the load sees every add
+// that has completed; an aligned 8-byte half never tears.  (Round 2 polled with returning atomicAdd(p, 0): correct too,
+// but every poll then serialises at the memory side with the deposits and the other workgroups' polls of the same word --
+// ~12 ns each, 24-48 workgroups, several polls per step.)  A stale or torn read could only delay the arrival count: the
+// waits are bounded and report through the error word.
+typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
+__device__ inline void poll_pair(const unsigned long long* layer_words, int lane, unsigned long long& w0, unsigned long long& w1) {
+#ifdef INFV_POLL_ATOMIC                                      /* A/B builds only: round 2's returning-atomic poll */
+    unsigned long long* p = const_cast<unsigned long long*>(layer_words);
+    w0 = atomicAdd(p + 2 * lane, 0ull);
+    w1 = atomicAdd(p + 2 * lane + 1, 0ull);
+    return;
+#endif
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(layer_words), 0, kBins * 8, 0x00020000);
+    const uintx4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 16 /* sc1 */);
+    w0 = ((unsigned long long)v.y << 32) | v.x;
+    w1 = ((unsigned long long)v.w << 32) | v.z;
+}
+
 __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __builtin_amdgcn_s_setprio(3);
@@ -135,9 +156,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     const int ring_n = (int)a.ring;
     for (int i = 0; i < a.n_steps; ++i) {
         BSTAMP(0);
-        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;      // (g + 2) % 3
-        unsigned long long* acc_cur = a.acc[g3] + l * kBins * kAccStride;
-        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins * kAccStride;      // (g + 1) % 3
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;      // (g + 2) % 3
+        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;      // (g + 1) % 3
         const long slot = slot_run;
         if (++g3 == 3) g3 = 0;
         if (++slot_run == ring_n) slot_run = 0;
@@ -151,20 +172,20 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
         double mass_prev = 0.0;
         const bool steady = a.draw_mode == 1 && !((i == 0) && (((a.override_mask >> l) & 1u) || a.first_from_parts));
         if (steady && tid < kBins - 1) {
-            unsigned long long v = coherent_read(acc_prev + tid * kAccStride);
+            unsigned long long v = coherent_read(acc_prev + acc_word(tid));
             if (i > 0) {
                 int spins = 0;
                 while ((v >> kArriveShift) < (unsigned long long)(blocks_per_layer + a.expect_extra)) {
                     __builtin_amdgcn_s_sleep(1);
                     // give up loudly: the word lives in host-visible memory, every later call on the handle reports it
                     if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                    v = coherent_read(acc_prev + tid * kAccStride);
+                    v = coherent_read(acc_prev + acc_word(tid));
                 }
             }
             mass_prev = mass_of(v);
         }
         BSTAMP(1);
-        if (writer && tid < kBins) atomicExch(acc_clr + tid * kAccStride, 0ull);      // slot of the NEXT step: idle until then
+        if (writer && tid < kBins) atomicExch(acc_clr + acc_word(tid), 0ull);      // slot of the NEXT step: idle until then
         // ---- draw ----
         if (a.draw_mode == 1) {
             const bool ovr = (i == 0) && ((a.override_mask >> l) & 1u);
@@ -488,18 +509,16 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     const bool ovr0 = ((a.override_mask >> l) & 1u) != 0;
     const bool special0 = ovr0 || a.first_from_parts;                 // step 0 takes its probabilities from elsewhere
     if (wave == 0 && !special0) {
-        unsigned long long* ap = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;
-        pv0 = coherent_read(ap + lane * kAccStride);
-        pv1 = (lane + 64 < kBins - 1) ? coherent_read(ap + (lane + 64) * kAccStride) : 0ull;
+        poll_pair(a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins, lane, pv0, pv1);
     }
     __syncthreads();
 
 #define B2STAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
     for (int i = 0; i < a.n_steps; ++i) {
         B2STAMP(0);
-        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins * kAccStride;
-        unsigned long long* acc_cur = a.acc[g3] + l * kBins * kAccStride;
-        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins * kAccStride;
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;
+        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;
         const long slot = slot_run;
         if (++g3 == 3) g3 = 0;
         if (++slot_run == ring_n) slot_run = 0;
@@ -527,8 +546,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                     while ((pv0 >> kArriveShift) < need || (j1 < nb && (pv1 >> kArriveShift) < need)) {
                         if (a.exp_flags & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
                         if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                        pv0 = coherent_read(acc_prev + lane * kAccStride);
-                        if (j1 < nb) pv1 = coherent_read(acc_prev + j1 * kAccStride);
+                        poll_pair(acc_prev, lane, pv0, pv1);
                     }
                     a0 = mass_of(pv0);
                     a1 = (j1 < nb) ? mass_of(pv1) : 0.0;
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         // more; nobody adds to it before having seen all arrivals of step i, this workgroup's included -- and that arrival
         // (behind barrier 3) is held back until the clear has been acknowledged: the clearing waves drain vmcnt before
         // they join barrier 3.  (Round 2 issued the clear behind barrier 3, beside the arrival, with nothing ordering the two.)
-        if (writer && tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + (tid - 128) * kAccStride, 0ull);
+        if (writer && tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + acc_word(tid - 128), 0ull);
         if (tid < a.S) {
             // ---- lower bound of this thread's uniform in the cdf == number of entries below it ----
             const float my_uf = (lds + m.uf + (i & 1) * a.S)[tid];
@@ -626,6 +644,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                     if (s1.w >= 0) acc1[j] = fmaf(val1, w3, acc1[j]);
                 }
             }
+            // the rows of a wave are independent dependency chains: written phase by phase so that their LDS reads, DPP
+            // reductions and transcendentals interleave (same arithmetic per row as one row at a time)
+            float es0[RPW], es1[RPW], mx[RPW];
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int row = wave + kBRows * j;
@@ -634,19 +655,33 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                 scn[j * kBRows * kScPitch + lane] = acc0[j];
                 scn[j * kBRows * kScPitch + lane + 64] = acc1[j];
                 // densities at the 129 edges: edge j (1..127) sits in the box of point j, edges 0 and 128 in none (score 0)
-                const float s0 = e0ok ? acc0[j] + cqr[j] : 0.f, s1 = e1ok ? acc1[j] + cqr[j] : 0.f;
-                const float md = fmaxf(wave_max(fmaxf(e0ok ? s0 : -INFINITY, e1ok ? s1 : -INFINITY)), 0.f);
-                const float d0 = expf(s0 - md), d1 = expf(s1 - md);
-                const float d128 = expf(0.f - md);
-                const float d0n = wave_shl1(d0, readlane_f32(d1, 0));               // D[lane + 1]
-                const float d1n = wave_shl1(d1, d128);                              // D[lane + 65]
-                const float d0nn = wave_shl1(d0n, readlane_f32(d1, 1));             // D[lane + 2]
-                const float d1nn = wave_shl1(d1n, 0.f);                             // D[lane + 66]  (lane 63: unused)
-                const float z = wave_sum((d0 + d0n) * dx0 + (d1 + d1n) * dx1) * 0.5f;
-                const float inv_z = 1.0f / z;
+                es0[j] = e0ok ? acc0[j] + cqr[j] : 0.f;
+                es1[j] = e1ok ? acc1[j] + cqr[j] : 0.f;
+                mx[j] = fmaxf(e0ok ? es0[j] : -INFINITY, e1ok ? es1[j] : -INFINITY);
+            }
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) mx[j] = fmaxf(wave_max(mx[j]), 0.f);
+            float d0[RPW], d1[RPW], d128[RPW];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) { d0[j] = expf(es0[j] - mx[j]); d1[j] = expf(es1[j] - mx[j]); d128[j] = expf(0.f - mx[j]); }
+            float d0n[RPW], d1n[RPW], d0nn[RPW], d1nn[RPW], zz[RPW];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                d0n[j] = wave_shl1(d0[j], readlane_f32(d1[j], 0));                  // D[lane + 1]
+                d1n[j] = wave_shl1(d1[j], d128[j]);                                 // D[lane + 65]
+                d0nn[j] = wave_shl1(d0n[j], readlane_f32(d1[j], 1));                // D[lane + 2]
+                d1nn[j] = wave_shl1(d1n[j], 0.f);                                   // D[lane + 66]  (lane 63: unused)
+                zz[j] = (d0[j] + d0n[j]) * dx0 + (d1[j] + d1n[j]) * dx1;
+            }
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) zz[j] = wave_sum(zz[j]) * 0.5f;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int row = wave + kBRows * j;
+                const float inv_z = 1.0f / zz[j];
                 // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
-                Msm[row * kMPitch + lane] = row_ok[j] ? ((d0n * inv_z + d0nn * inv_z) * dxa) * 0.5f : 0.f;
-                if (lane + 64 < kBins - 1) Msm[row * kMPitch + lane + 64] = row_ok[j] ? ((d1n * inv_z + d1nn * inv_z) * dxb) * 0.5f : 0.f;
+                Msm[row * kMPitch + lane] = row_ok[j] ? ((d0n[j] * inv_z + d0nn[j] * inv_z) * dxa) * 0.5f : 0.f;
+                if (lane + 64 < kBins - 1) Msm[row * kMPitch + lane + 64] = row_ok[j] ? ((d1n[j] * inv_z + d1nn[j] * inv_z) * dxb) * 0.5f : 0.f;
             }
         }
         if (writer && (wave == 2 || wave == 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clear above is complete
@@ -656,7 +691,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < TR; ++r) t += Msm[r * kMPitch + tid];
-            if (!(a.exp_flags & 16)) atomicAdd(&acc_cur[tid * kAccStride], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
+            if (!(a.exp_flags & 16)) atomicAdd(&acc_cur[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
         }
         if (loader) {
             // request the inputs of step i+3 (set of its parity: parked during this step) in the shadow of wave 0's poll
@@ -664,8 +699,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         } else if (wave == 0) {
             // re-arm the poll right behind the deposit and go round: this wave issues nothing else until it has read it
             if (!last && !(a.exp_flags & 16)) {
-                pv0 = coherent_read(acc_cur + lane * kAccStride);
-                pv1 = (lane + 64 < kBins - 1) ? coherent_read(acc_cur + (lane + 64) * kAccStride) : 0ull;
+                poll_pair(acc_cur, lane, pv0, pv1);
             }
             B2STAMP(5);
         } else {

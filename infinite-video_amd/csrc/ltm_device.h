@@ -122,7 +122,7 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
             if (tid + 64 < nb) r.ovr[1] = probs_override[tid + 64];
         }
     } else if (mass_acc != nullptr) {
-        if (tid < kBins - 1) r.acc = mass_of(mass_acc[tid * kAccStride]);           // group 0 holds the totals
+        if (tid < kBins - 1) r.acc = mass_of(mass_acc[acc_word(tid)]);           // group 0 holds the totals
     } else {
         constexpr int G = NT / kBins;                   // thread groups that split the partial rows
         const int j = tid & (kBins - 1), grp = tid / kBins;
@@ -347,7 +347,7 @@ __device__ inline void row_phase_wave(float* Ssm, int sstride, int N, int valid_
         float t = 0.f;
         for (int r = 0; r < rows_in_tile; ++r) t += Msm[r * kMPitch + tid];
         if (part_out != nullptr) part_out[tid] = t;
-        if (mass_acc != nullptr) atomicAdd(&mass_acc[tid * kAccStride], (unsigned long long)((double)t * kMassScale + 0.5) + arrive_inc);
+        if (mass_acc != nullptr) atomicAdd(&mass_acc[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + arrive_inc);
     }
 }
 

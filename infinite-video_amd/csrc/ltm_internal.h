@@ -8,13 +8,10 @@ namespace infv {
 constexpr int kMaxLayers = 8;
 constexpr int kHeadSize = 64;      // dh the attend kernel is written for
 constexpr int kQTile = 16;         // query rows per attend workgroup (one MFMA row tile)
-// Spacing (in 8-byte words) of the fixed-point sticky bin-mass accumulators: word j of layer l lives at
-// (l * 128 + j) * kAccStride.  The memory-side atomics of all workgroups of a layer serialise per word; packed
-// words share a few memory channels with each other (and with every streaming load interleaved onto them).
-#ifndef INFV_ACC_STRIDE
-#define INFV_ACC_STRIDE 1
-#endif
-constexpr int kAccStride = INFV_ACC_STRIDE;
+// Layout of the fixed-point sticky bin-mass accumulators (u64 words, 128 per layer): bin j lives at word acc_word(j), which
+// interleaves the two halves of the histogram -- words (2 i, 2 i + 1) = bins (i, i + 64) -- so that ONE 16-byte load per
+// lane hands lane i exactly the two bins it owns in the draw (the poll of the persistent chain kernel).
+__host__ __device__ inline int acc_word(int j) { return j < 64 ? 2 * j : 2 * (j - 64) + 1; }
 
 // Device-side view of one ridge operator (first-chunk or infinite-memory) of a plan.
 struct OperatorView {

@@ -72,6 +72,54 @@ __global__ __launch_bounds__(NT) void pool_frames_kernel(const void* __restrict_
     }
 }
 
+// The same kernel with a rolling register double buffer (round 3): the U loads of group g+1 are issued before group g is
+// summed, so a wave keeps U..2U KiB in flight all the time instead of issuing a burst, waiting for all of it and starting
+// over (in situ, where a load takes ~2 us, the burst form leaves the wave with nothing in flight about half the time).
+// Same unit (one wave per frame and 256-float slice: short-lived workgroups, which is what lets the persistent chain
+// kernel find empty CUs at every sub-batch launch), same summation order, same bits.  Needs P % U == 0.
+template <int U, int NT, class Tok = TokF32>
+__global__ __launch_bounds__(NT) void pool_frames_db_kernel(const void* __restrict__ k_, float* __restrict__ kbar,
+                                                             long n_units, int P, int d4, int slices) {
+    typedef typename Tok::vec tvec;
+    const int lane = threadIdx.x & 63;
+    for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
+        const long frame = unit / slices;
+        const int c4 = (int)(unit - frame * slices) * 64 + lane;
+        if (c4 >= d4) continue;
+        const tvec* src = reinterpret_cast<const tvec*>(k_) + frame * (long)P * d4 + c4;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        tvec va[U], vb[U];
+        const int n_groups = P / U;
+#pragma unroll
+        for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)i * d4);
+        int g = 0;
+        for (; g + 2 < n_groups; g += 2) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(src + (long)((g + 1) * U + i) * d4);
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
+#pragma unroll
+            for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)((g + 2) * U + i) * d4);
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += Tok::widen(vb[i]);
+        }
+        if (g + 1 < n_groups) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(src + (long)((g + 1) * U + i) * d4);
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += Tok::widen(vb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
+        }
+        const float fp = (float)P;
+        acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;
+        __builtin_nontemporal_store(acc, reinterpret_cast<floatx4*>(kbar) + frame * d4 + c4);
+    }
+}
+
 // `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
 // latency-critical kernel on another stream always finds wave slots and LDS (see consolidate()).
 template <class Tok>
@@ -129,6 +177,22 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
         }
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
+        // INFV_POOL_DB=<U>: the rolling double-buffered form with U loads per group (U | P)
+        static const int db = [] { const char* e = getenv("INFV_POOL_DB"); return e ? atoi(e) : 0; }();
+        if (db > 0 && P % db == 0 && (db == 1 || db == 2 || db == 4)) {
+            static bool attr_db = false;
+            if (!attr_db) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<1, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<2, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<4, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_db = true;
+            }
+            if (db == 1) hipLaunchKernelGGL((pool_frames_db_kernel<1, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            else if (db == 2) hipLaunchKernelGGL((pool_frames_db_kernel<2, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            else hipLaunchKernelGGL((pool_frames_db_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            return hipGetLastError();
+        }
         if (unroll <= 2)
             hipLaunchKernelGGL((pool_frames_kernel<2, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
         else if (unroll <= 4)
