@@ -31,6 +31,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md), the graded roofline
+SELFCHECK_MAX_ABS_ERR = 1e-3   # north-star tolerance of the contexts (fp32)
+SELFCHECK_MAX_FLIPS = 8        # draws (of 25 chunks x 2 layers x 512) allowed to land in the adjacent bin
 T, P, D, N, H, DH, Q, L, TAU, S = 256, 32, 768, 256, 12, 64, 32, 2, 0.75, 512
 DM = H * DH
 BYTES_K = 4 * T * P * D                                            # 25 165 824
@@ -233,6 +235,10 @@ def selfcheck(eng_cls, dev, k, q, projs, u, ctx_timed, trace, batch_chunks):
         out["last_chunk_draw_flips"] = int(sum((ref.last_draw(l)[0] != last_bins[l]).sum() for l in range(L)))
         worst = max(worst, out["last_chunk_max_abs_err"])
     out["max_abs_err"] = worst
+    # gate: the north star's fp32 budget is 1e-3 (the tests hold the path to 1e-4); a handful of adjacent-bin flips between
+    # the two HIP paths is expected over millions of draws (different fp32 association of the probabilities)
+    flips_total = out["head_draw_flips"] + out.get("last_chunk_draw_flips", 0)
+    out["ok"] = bool(worst <= SELFCHECK_MAX_ABS_ERR and flips_total <= SELFCHECK_MAX_FLIPS)
     del ref
     return out
 
@@ -241,6 +247,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON of rank 0.  Libraries write there too (RCCL prints a version banner into
+    # the C-level stdout buffer, which is flushed at exit, i.e. AFTER a Python print): point fd 1 at stderr for the whole
+    # run and keep the real stdout for the final line.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -358,19 +370,36 @@ def main():
                        "max_abs_diff_vs_f32_tokens": float((ctx3 - ctx).abs().max())}
         del eng3, ctx3, k16
 
-    # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing ----
-    shard256_ms = None
+    # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing AND the collective: a
+    #      world-of-one "nccl" (= RCCL) group is initialised for this leg, so all_gather_into_tensor really runs ----
+    shard256_ms, shard256_rccl = None, False
     if world == 1 and c_local >= 256:
-        for _ in range(2):
-            consolidate_video(eng, k[:256], q, projs, u[:256])
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(7):
-            t1 = time.perf_counter()
-            consolidate_video(eng, k[:256], q, projs, u[:256])
+        own_group = False
+        if not dist.is_initialized():
+            try:
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    port = s_.getsockname()[1]
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                own_group = True
+            except Exception as exc:                      # the leg still runs, without the collective
+                print(f"[bench] RCCL world-of-one group not available: {exc}", file=sys.stderr)
+        shard256_rccl = dist.is_initialized()
+        try:
+            for _ in range(2):
+                consolidate_video(eng, k[:256], q, projs, u[:256])
             torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        shard256_ms = 1e3 * sorted(ts)[len(ts) // 2]
+            ts = []
+            for _ in range(7):
+                t1 = time.perf_counter()
+                consolidate_video(eng, k[:256], q, projs, u[:256])
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            shard256_ms = 1e3 * sorted(ts)[len(ts) // 2]
+        finally:
+            if own_group:
+                dist.destroy_process_group()
 
     # ---- the HBM-bound kernel on its own (no other stream running): 5 launches of one sub-batch ----
     nb = min(args.batch_chunks if c_local >= 768 else min(args.batch_chunks, 32), c_local)
@@ -395,7 +424,7 @@ def main():
     traffic, traffic_src = pmc_traffic_per_full_launch()
     roofline = {
         "kernel": "pool_frames_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_from_committed_profile": True,
         "achieved_alone": alone_gbs, "frac_alone": alone_gbs / HBM_PEAK_GBS,
         "note": "achieved = in situ, while the pool shares the chip with the chain and update/read-out streams; "
                 "achieved_alone = same launch size through infv_ltm_pool, nothing else running",
@@ -425,6 +454,7 @@ def main():
         dt = time.perf_counter() - t1
         flop = L * 2 * (2 * H * Q * D * T * P)                       # two [H*Q x d x T*P] contractions per layer
         encode_video = {"what": "per-chunk encode_video counterpart (2-layer video Q-former + LTM + llama_proj), alpha=0.9",
+                        "dtype": "f32 (short-term attention contractions as 3 bf16 MFMA products, ~1e-5 relative; LTM exact f32)",
                         "chunks_per_s": n_enc / dt, "ms_per_chunk": 1e3 * dt / n_enc, "chunks": n_enc,
                         "short_attention_gflop_per_chunk": flop / 1e9,
                         "short_attention_tflops_over_whole_chunk_time": flop * n_enc / dt / 1e12}
@@ -442,6 +472,23 @@ def main():
         dt = sorted(ts)[1]
         encode_video["layer_major"] = {"chunks": n_lm, "chunks_per_s": n_lm / dt, "ms_per_chunk": 1e3 * dt / n_lm,
                                        "short_attention_tflops_over_whole_chunk_time": flop * n_lm / dt / 1e12}
+        # the same two schedules with exact-fp32 MFMA contractions (infv_vqf_set_precision(h, 1))
+        model.exact_fp32 = True
+        for c in range(2):
+            model.encode_frames(k[c % c_local].unsqueeze(0), new_video=(c == 0), u=uu[c])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for c in range(n_enc):
+            model.encode_frames(k[c % c_local].unsqueeze(0), new_video=False, u=uu[2 + c])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        model.encode_frames_batch(k[:n_lm], new_video=True, u=u_lm)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.encode_frames_batch(k[:n_lm], new_video=True, u=u_lm)
+        torch.cuda.synchronize()
+        dt_lm = time.perf_counter() - t1
+        encode_video["exact_f32"] = {"dtype": "f32", "ms_per_chunk": 1e3 * dt / n_enc, "layer_major_ms_per_chunk": 1e3 * dt_lm / n_lm}
         del model
 
     if rank == 0:
@@ -460,11 +507,16 @@ def main():
                        "parallelism": f"chunk-block sharding x{world} + 1 all-gather of consolidated memory"},
             "roofline": roofline,
         }
+        # every knob of the library / runtime that was set for this run (an empty list = the shipped defaults)
+        out["env_overrides"] = sorted(f"{k_}={v_}" for k_, v_ in os.environ.items()
+                                      if k_.startswith("INFV_") or k_ in ("GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES"))
         if check is not None:
             out["selfcheck"] = check
             out["selfcheck_max_abs_err"] = check["max_abs_err"]
+            out["selfcheck_ok"] = check["ok"]
         if shard256_ms is not None:
             out["shard256_ms"] = shard256_ms
+            out["shard256_includes_rccl_all_gather"] = shard256_rccl
         if vsplit is not None:
             out["secondary_vproj_bf16x3"] = vsplit
         if bf16_tokens is not None:
@@ -474,9 +526,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_closed_form"] = cpu_baselines(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+            out["speedup_vs_cpu_closed_form"] = value / out["cpu_closed_form"]["value"]
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check["ok"]:
+        raise SystemExit(f"bench.py: selfcheck failed ({check})")
 
 
 if __name__ == "__main__":

@@ -15,7 +15,11 @@ import os
 import torch  # noqa: F401  (side effect: loads torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinfv_ltm.so")
+# INFV_LTM_LIBRARY=exp selects the experiments build of the same sources (-DINFV_EXPERIMENTS: timing, fault-injection and A/B
+# knobs compiled in, csrc/knobs.h) -- development tools and the tests of non-default variants only; a path selects that file.
+_WHICH = os.environ.get("INFV_LTM_LIBRARY", "")
+LIB_PATH = (os.path.join(_HERE, "libinfv_ltm_exp.so") if _WHICH == "exp" else
+            (_WHICH if _WHICH else os.path.join(_HERE, "libinfv_ltm.so")))
 ABI_VERSION = 2
 MAX_LAYERS = 8
 

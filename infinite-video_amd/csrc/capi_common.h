@@ -1,5 +1,6 @@
 // Shared by the C-ABI translation units (ltm_capi.hip, vqf_capi.hip): error reporting and device buffers.
 #pragma once
+#include "knobs.h"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 

@@ -1,0 +1,22 @@
+// Environment knobs of libinfv_ltm.so.
+//
+// The shipped library reads four documented options from the environment (all parity-tested; see README.md):
+//   INFV_VPROJ_SPLIT, INFV_VQF_FP32, INFV_VQF_FUSE, INFV_VQF_SPLIT_CACHE_GB          -> plain getenv at their call sites.
+// Everything else -- timing experiments that produce garbage (INFV_SKIP, INFV_S_FLAGS), in-kernel stamps, fault
+// injection, occupancy pads, stream priorities and the A/B selectors of variants that are not the default -- goes through
+// exp_env(), which only looks at the environment in the experiments build (-DINFV_EXPERIMENTS:
+// libinfv_ltm_exp.so, what tools/ and the variant / fault-injection tests load through INFV_LTM_LIBRARY=exp).  In the
+// shipped library exp_env() is a constant nullptr: no hidden work-skipping or tuning switch can change what it runs.
+#pragma once
+#include <cstdlib>
+
+namespace infv {
+inline const char* exp_env(const char* name) {
+#ifdef INFV_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+}  // namespace infv

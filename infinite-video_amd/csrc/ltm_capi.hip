@@ -37,7 +37,7 @@ namespace {
 // before that kernel -- the side stream stops being the longest of the three.
 // (the per-handle choice: infv_ltm_s::vproj_on_uc)
 
-int skip_mask() { static const int m = [] { const char* e = getenv("INFV_SKIP"); return e ? atoi(e) : 0; }(); return m; }
+int skip_mask() { static const int m = [] { const char* e = exp_env("INFV_SKIP"); return e ? atoi(e) : 0; }(); return m; }
 
 struct Operator {
     int rows = 0;
@@ -139,8 +139,6 @@ struct infv_ltm_s {
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
-    hipStream_t aux = nullptr;          // V' projection + softmax weights of a sub-batch (feeds the UC kernel)
-    hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_r[kRSets] = {};      // the UC kernel that read R set i is done
     hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
@@ -150,7 +148,6 @@ struct infv_ltm_s {
     DeviceBuf qt_buf;                  // fast path: pre-multiplied queries qt[(l*H+h)*Q+q][d] of the current call
     DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
     DeviceBuf crit_ring, tabb_ring;              // chain_batch2_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
-    DeviceBuf wc_flags;                          // whole-call chain kernel: gemm_ready / uc_done / progress counters (u64 x 8)
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
@@ -181,8 +178,6 @@ struct infv_ltm_s {
         if (side) (void)hipStreamSynchronize(side);
         if (ucs) (void)hipStreamSynchronize(ucs);
         if (pools) (void)hipStreamSynchronize(pools);
-        if (aux) (void)hipStreamSynchronize(aux);
-        for (int i = 0; i < 3; ++i) if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
         for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < kRSets; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
         for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
@@ -436,16 +431,14 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
-    if (e == hipSuccess) e = h->wc_flags.reserve(8 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->wc_flags.p, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(h->sync_words.p, 0, 16 * sizeof(unsigned int));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocMapped);
     if (e == hipSuccess) { memset(h->err_host, 0, 64); e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->err_dev), h->err_host, 0); }
     if (e == hipSuccess) e = h->bins_forced.reserve((size_t)h->L * h->S * sizeof(int32_t));
-    if (const char* f = getenv("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
+    if (const char* f = exp_env("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
     if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
-    if (const char* f = getenv("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
+    if (const char* f = exp_env("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
     h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
@@ -710,7 +703,7 @@ struct FastPipe {
         s.alpha_out = h->alpha_ring.as<float>() + slot * alpha_slot();
         s.asum_out = h->asum_ring.as<float>() + slot * asum_slot();
         {
-            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
+            static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
             a.dbg = dbg;
             static int stamp_calls = 0;
             if (dbg && (++stamp_calls % 300) == 0) {
@@ -734,19 +727,10 @@ struct FastPipe {
         return INFV_OK;
     }
 
-    // whole-call mode of launch_s_batch (wc.sub > 0): one launch for every sub-batch of the call, see ChainBatchArgs
-    struct WholeCall { int sub = 0, n_sub = 0; const float* snew[3] = {nullptr, nullptr, nullptr}; int last_sk = 1; long last_ss = 0; };
-
     // role S of `n` consecutive infinite-memory chunks in one persistent launch
-    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u, const WholeCall* wc = nullptr) {
+    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u) {
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
-        if (wc != nullptr) {
-            b.wc_sub = wc->sub; b.wc_n_sub = wc->n_sub; b.wc_set0 = 0;
-            for (int i = 0; i < 3; ++i) b.wc_snew[i] = wc->snew[i];
-            b.wc_last_splitk = wc->last_sk; b.wc_last_split_stride = wc->last_ss;
-            b.wc_flags = h->wc_flags.as<unsigned long long>();
-        }
         const int QS = chain_s_tiles(Q);
         b.N = h->N; b.H = h->H; b.Q = Q; b.QS = QS; b.L = h->L; b.S = h->S;
         b.st = plan.sticky();
@@ -762,7 +746,7 @@ struct FastPipe {
         for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
         b.arrive = h->sync_words.as<unsigned int>(); b.error = h->err_dev;
         b.spin_limit = h->spin_limit; b.expect_extra = h->expect_extra;
-        { static const int fl = [] { const char* e = getenv("INFV_S_FLAGS"); return e ? atoi(e) : 0; }(); b.exp_flags = fl; }
+        { static const int fl = [] { const char* e = exp_env("INFV_S_FLAGS"); return e ? atoi(e) : 0; }(); b.exp_flags = fl; }
         if (h->trace_cap > counter) {
             b.trace_steps = (int)((h->trace_cap - counter < n) ? h->trace_cap - counter : n);
             b.probs_tr = h->trace_probs ? h->trace_probs + (size_t)counter * h->L * h->n_bins : nullptr;
@@ -781,7 +765,7 @@ struct FastPipe {
         b.Snew = Snew; b.snew_ld = h->L * h->dm + h->L * h->H * Q; b.snew_splitk = sk; b.snew_split_stride = ss;
         b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
         {
-            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
+            static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
             b.dbg = dbg;
             static int calls = 0;
             if (dbg && (++calls % 8) == 0) {
@@ -853,7 +837,7 @@ struct FastPipe {
         for (int l = 0; l < h->L; ++l) u.bv[l] = pp.bv[l];
         u.ctx = ctx;
         {
-            static long long* dbg = [] { long long* p = nullptr; if (getenv("INFV_UC_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
+            static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_UC_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
             u.dbg = dbg;
             static int calls = 0;
             if (dbg && (++calls % 8) == 0) {
@@ -891,40 +875,9 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
         HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[rset].as<float>(), stream));
     }
-    // INFV_LTM_SPLIT=1 (experiment, off by default): the V' half of a sub-batch's projection only feeds the read-out, so
-    // it can run as a split-bf16 contraction (three bf16 MFMA products, ~1e-5 relative) while the score half stays on
-    // the exact fp32 MFMA kernel (its rounding feeds the bit-exact draw).  Measured: no gain (95 k vs 95-100 k
-    // chunks/s) -- the two launches (168 + 84 workgroups) serialise on the side stream and each under-fills the chip,
-    // where the single fp32 launch runs its 252 workgroups side by side.
-    static const bool want_split = [] { const char* e = getenv("INFV_LTM_SPLIT"); return e && atoi(e) != 0; }();
     const int v_cols = h->L * h->dm;
     if (skip_mask() & 2) {
         *splitk = project_splitk((int)M, h->d);
-    } else if (want_split && M >= 1024 && h->d % 32 == 0 && v_cols % 128 == 0) {
-        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-        const size_t szW = (size_t)v_cols * h->d * 2, szR = (size_t)M * h->d * 2;
-        if (szW > h->wv_hi.bytes || szR > h->R_hi.bytes) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(h->wv_hi.reserve(szW)); HIP_TRY(h->wv_lo.reserve(szW));
-            HIP_TRY(h->R_hi.reserve(szR)); HIP_TRY(h->R_lo.reserve(szR));
-            h->wv_split_valid = false;
-        }
-        if (!h->wv_split_valid) {
-            for (int l = 0; l < h->L; ++l)
-                HIP_TRY(launch_split_rows(pp.wv[l], h->d, h->dm, h->d, h->wv_hi.as<__bf16>() + (size_t)l * h->dm * h->d,
-                                          h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, stream));
-            h->wv_split_valid = true;
-        }
-        HIP_TRY(launch_split_rows(h->R_ws[rset].as<float>(), h->d, M, h->d, h->R_hi.p, h->R_lo.p, h->d, stream));
-        SplitGemm g{};
-        g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
-        g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
-        g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.strideC = 0; g.split_stride = 0;
-        g.M = (int)M; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
-        HIP_TRY(launch_split_gemm(g, stream, gemm_pad));
-        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
-                                      h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
-        *splitk = 1;
     } else if (defer_values && M >= 1024) {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
@@ -958,7 +911,7 @@ int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const floa
 // the first one's and its pipeline ran 12 % slower (107 k against 120 k chunks/s for the second engine of bench.py).
 // Handles are not re-entrant and their calls are issued from one host thread at a time, so FIFO order within a shared
 // stream is the order the host issued the work in; cross-stream dependencies are events, as before.
-struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr, aux = nullptr; };
+struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr; };
 int shared_streams(int dev, SharedStreams** out) {
     static std::mutex mu;
     static SharedStreams pool[64];
@@ -969,11 +922,9 @@ int shared_streams(int dev, SharedStreams** out) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent
         // INFV_PRIO_UCS / _POOL / _SIDE (experiments): -1 most urgent, 0 normal, 1 least urgent
-        auto prio = [&](const char* name, int dflt) { const char* e = getenv(name); int v = e ? atoi(e) : dflt; return v < hi ? hi : (v > lo ? lo : v); };
+        auto prio = [&](const char* name, int dflt) { const char* e = exp_env(name); int v = e ? atoi(e) : dflt; return v < hi ? hi : (v > lo ? lo : v); };
         HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio("INFV_PRIO_UCS", 0)));
         HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio("INFV_PRIO_POOL", lo)));
-        static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
-        if (use_aux) HIP_TRY(hipStreamCreateWithPriority(&p.aux, hipStreamNonBlocking, lo));
         HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio("INFV_PRIO_SIDE", lo)));   // last: marks the set complete
     }
     *out = &p;
@@ -1002,13 +953,12 @@ int ensure_side_stream(infv_ltm_handle h) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));                              // (the caller's current device: where the handle was created)
     if (int rc = shared_streams(dev, &sh)) return rc;
-    h->ucs = sh->ucs; h->pools = sh->pools; h->aux = sh->aux;
+    h->ucs = sh->ucs; h->pools = sh->pools;
     for (int i = 0; i < 3; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_s[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
     }
     for (int i = 0; i < kRSets; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_r[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
@@ -1060,8 +1010,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // always finds LDS and wave slots and the pool's bytes in flight stay bounded.  The GEMMs carry no padding any more
     // (INFV_GEMM_PAD): their workgroups (36 KB, one wave per SIMD) co-reside with a pooling workgroup -- MFMA work beside
     // memory work -- instead of taking the CU away from it.
-    static const int kPoolPad = [] { const char* e = getenv("INFV_POOL_PAD"); return e ? atoi(e) : 84 * 1024; }();
-    static const int kGemmPad = [] { const char* e = getenv("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
+    static const int kPoolPad = [] { const char* e = exp_env("INFV_POOL_PAD"); return e ? atoi(e) : 84 * 1024; }();
+    static const int kGemmPad = [] { const char* e = exp_env("INFV_GEMM_PAD"); return e ? atoi(e) : 0; }();
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
@@ -1122,7 +1072,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // ---- sub-batches.  Streams: `side` = chunk-parallel stage of batch b+1, caller's stream = role S of
     //      batch b (one launch per chunk), `ucs` = memory update + read-out of batch b-1 ----
     // INFV_PERSISTENT=0 falls back to one role-S launch per chunk
-    static const bool want_persistent = [] { const char* e = getenv("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
+    static const bool want_persistent = [] { const char* e = exp_env("INFV_PERSISTENT"); return !e || atoi(e) != 0; }();
     const bool persistent = want_persistent &&
         chain_batch_supported(h->N, h->S, plan->inf.rows, plan->inf.tabw, h->H * chain_s_tiles(Q) * h->L) &&
         chain_batch_resident(h->N, h->S, plan->inf.rows, plan->inf.tabw,
@@ -1132,7 +1082,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // sub-batch size: long calls amortise the per-launch gap of role S over more chunks (42 x 64 new rows = 21 row tiles:
     // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 32 so that the
     // pipeline fills and drains quickly.  INFV_SUB_BATCH overrides.
-    static const int sub_env = [] { const char* e = getenv("INFV_SUB_BATCH"); return e ? atoi(e) : 0; }();
+    static const int sub_env = [] { const char* e = exp_env("INFV_SUB_BATCH"); return e ? atoi(e) : 0; }();
     int sub = h->maxC;
     if (sub_env > 0) sub = sub_env < h->maxC ? sub_env : h->maxC;
     else if (n_chunks < 768 && sub > 32) sub = 32;             // (28 while the V' GEMM ran on the UC stream; 2.84 -> 2.68 ms per 256 chunks)
@@ -1144,40 +1094,11 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         *c0 = first_c + b * sub;
         *nb = (n_chunks - *c0 < sub) ? n_chunks - *c0 : sub;
     };
-    // Whole-call chain (INFV_WHOLE_CALL=1, off by default): ONE launch of chain_batch2_kernel runs every sub-batch.  It
-    // gates itself on the score GEMMs (counter bumped on the side stream) and on the consumption of its ring slots (counter
-    // bumped on the UC stream); the consumers of sub-batch b are gated on its progress counter.  The chain then never
-    // waits to become resident again and its launch gaps disappear.  Measured (headline video): 21.2 ms against 18.3 ms
-    // with one launch per sub-batch -- the permanently resident chain costs the co-resident pooling workgroups more
-    // (pool stream 19.7 ms instead of 15.8) than the launch gaps were worth, the three other streams being the longer
-    // ones either way.  Kept as an option (parity-tested) for configurations where role S is the longest stream.
-    static const bool want_wc = [] { const char* e = getenv("INFV_WHOLE_CALL"); return e && atoi(e) != 0; }();
-    const int s_blocks = chain_batch_blocks(h->H, Q, h->L, h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S);
-    const bool wc = persistent && want_wc && n_batches > 0 && sub >= 4 && !(skip_mask() & 8) &&
-                    chain_batch2_shape_ok(h->cfg.sticky ? 1 : 2, plan->sticky().points_ok, plan->inf.rows, h->S, Q);
-    if (wc) {
-        // the kernel holds the addresses of all three workspace sets: size them before it is launched
-        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
-        const size_t M = (size_t)sub * rows;
-        int c0l_, nbl_; batch_range(n_batches - 1, &c0l_, &nbl_);
-        const size_t Ml = (size_t)nbl_ * rows;                     // the final sub-batch may be short enough for split-K slabs
-        const size_t needP_reg = M * ld * (M < 1024 ? 8 : 1), needP_last = Ml * ld * (Ml < 1024 ? 8 : 1);
-        const size_t needR = M * h->d * sizeof(float), needP = (needP_reg > needP_last ? needP_reg : needP_last) * sizeof(float);
-        bool grow = false;
-        for (int i = 0; i < 3; ++i) grow = grow || needP > h->P_ws[i].bytes;
-        for (int i = 0; i < kRSets; ++i) grow = grow || needR > h->R_ws[i].bytes;
-        if (grow) {
-            HIP_TRY(hipDeviceSynchronize());
-            for (int i = 0; i < 3; ++i) HIP_TRY(h->P_ws[i].reserve(needP));
-            for (int i = 0; i < kRSets; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
-        }
-        HIP_TRY(hipMemsetAsync(h->wc_flags.p, 0, 8 * sizeof(unsigned long long), stream));
-    }
     // The pooling has its own stream so that the HBM-bound pooling of batch b+2 overlaps the MFMA-bound projection of
     // batch b+1 (pooled frames are triple-buffered either way); INFV_SPLIT_POOL=0 puts it back on the side stream.
     // (Round 1 measured this worse, 87 k vs 95 k chunks/s, because role S was then sensitive to every concurrent
     // kernel; with chain_batch2_kernel and no padding LDS on the GEMMs it is better: 112 k vs 102 k.)
-    static const bool split_pool_env = [] { const char* e = getenv("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
+    static const bool split_pool_env = [] { const char* e = exp_env("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
     const bool split_pool = split_pool_env && !kbar_pre;      // (frame means handed in: there is no pooling stage)
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
@@ -1187,12 +1108,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // same bits.  Measured in situ (round 3, tools/sweep_r03*.sh): the fused kernel streams faster (218-270 us per 42-chunk
     // launch against 304) but its longer-lived workgroups cost the chain launches their CUs -- chain 13.5-15.7 ms per video
     // against 12.6 -- and the call ends up slower (116-121 k against 130 k chunks/s); the two-kernel form stays the default.
-    static const bool pr_env = [] { const char* e = getenv("INFV_POOL_ROWS"); return e && atoi(e) != 0; }();
+    static const bool pr_env = [] { const char* e = exp_env("INFV_POOL_ROWS"); return e && atoi(e) != 0; }();
     const bool use_pr = pr_env && !kbar_pre && pool_rows_supported(h->P, h->d);
-    static const int pr_u = [] { const char* e = getenv("INFV_PR_U"); return e ? atoi(e) : 4; }();
-    static const int pr_nt = [] { const char* e = getenv("INFV_PR_NT"); return e ? atoi(e) : 512; }();
-    static const int pr_pad = [] { const char* e = getenv("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
-    static const int pr_wgs = [] { const char* e = getenv("INFV_PR_WGS"); return e ? atoi(e) : 0; }();
+    static const int pr_u = [] { const char* e = exp_env("INFV_PR_U"); return e ? atoi(e) : 4; }();
+    static const int pr_nt = [] { const char* e = exp_env("INFV_PR_NT"); return e ? atoi(e) : 512; }();
+    static const int pr_pad = [] { const char* e = exp_env("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
+    static const int pr_wgs = [] { const char* e = exp_env("INFV_PR_WGS"); return e ? atoi(e) : 0; }();
     if (!kbar_pre && !use_pr) {
         const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
         if (need > h->kbar_side[0].bytes) {
@@ -1242,18 +1163,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
                                          h->vproj_on_uc(n_chunks), rset, use_pr)) return rc;
-        // gemm_ready: the chain may enter batch b.  Before the event, so that whoever waits for this batch's projection
-        // (the UC stream, and through it the join of the call) also waits for the counter update: the next call resets it
-        if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 0, side));
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         return INFV_OK;
     };
     if (n_batches > 0) {
         HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
-        HIP_TRY(hipStreamWaitEvent(side, wc ? h->ev_in : h->ev_q, 0));   // (whole-call mode: also after the counters' reset)
+        HIP_TRY(hipStreamWaitEvent(side, h->ev_q, 0));
         if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_start, 0));
-        if (wc) HIP_TRY(hipStreamWaitEvent(ucs, h->ev_in, 0));   // its gate kernels must not read the counters before their reset
         if (int rc = stage_pool(0)) return rc;
         if (n_batches > 1)
             if (int rc = stage_pool(1)) return rc;
@@ -1264,39 +1181,20 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (int rc = stage_pool(b + 1)) return rc;
         return stage_project(b);
     };
-    const long wc_slot_base = pipe.counter;                   // ring slot of the call's first sub-batch step
-    if (wc) {
-        FastPipe::WholeCall w;
-        w.sub = sub; w.n_sub = n_batches;
-        for (int i = 0; i < 3; ++i) w.snew[i] = h->P_ws[i].as<float>() + (size_t)h->L * h->dm;
-        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
-        int c0l, nbl; batch_range(n_batches - 1, &c0l, &nbl);
-        const long M_reg = (long)sub * rows, M_last = (long)nbl * rows;
-        w.last_sk = M_last >= 1024 ? 1 : project_splitk((int)M_last, h->d);
-        w.last_ss = M_last * ld;
-        if (int rc = pipe.launch_s_batch(n_chunks - first_c, nullptr, M_reg >= 1024 ? 1 : project_splitk((int)M_reg, h->d), M_reg * ld,
-                                         u ? u + (size_t)first_c * chunk_u : nullptr, &w)) return rc;
-    }
-    static const bool host_trace = getenv("INFV_HOST_TRACE") != nullptr;   // host time of every loop iteration (is the host ahead of the device?)
+    static const bool host_trace = exp_env("INFV_HOST_TRACE") != nullptr;   // host time of every loop iteration (is the host ahead of the device?)
     std::vector<double> host_us;
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int b = 0; b < n_batches; ++b) {
         if (host_trace) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % 3, rset = b % kRSets;
-        if (!wc) {
-            HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
-            // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
-            if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
-        }
-        const long slot0 = wc ? wc_slot_base + (long)b * sub : pipe.counter;
-        static const bool serial = getenv("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
-        if (serial && !wc) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
-        if (wc) {
-            if (b + 1 < n_batches)
-                if (int rc = stage_parallel(b + 1)) return rc;
-            pipe.last_snew = h->P_ws[set].as<float>() + (size_t)h->L * h->dm; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
-        } else if (persistent) {
+        HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
+        // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
+        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
+        const long slot0 = pipe.counter;
+        static const bool serial = exp_env("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
+        if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
+        if (persistent) {
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
@@ -1314,11 +1212,10 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                     if (int rc = stage_parallel(b + 1)) return rc;
             }
         }
-        // What the UC kernel needs besides role S's tables -- the V' half of the projection and the softmax weights --
-        // runs on the UC stream itself.  INFV_AUX_STREAM=1 moves it to a stream of its own: measured much WORSE (23.6 vs
-        // 18.0 ms per video): a fifth concurrent kernel slows role S and the GEMMs more than the shorter chain gains.
-        static const bool use_aux = [] { const char* e = getenv("INFV_AUX_STREAM"); return e && atoi(e) != 0; }();
-        hipStream_t vs = use_aux ? h->aux : ucs;
+        // What the UC kernel needs besides role S's tables -- the softmax weights, and the V' half of the projection when it
+        // is not part of the side stream's GEMM -- runs on the UC stream itself (a stream of its own for it was measured much
+        // worse in rounds 1 and 2: every extra concurrent kernel slows role S and the GEMMs more than the shorter stream gains).
+        hipStream_t vs = ucs;
         if (h->vproj_on_uc(n_chunks) && (long)nb * plan->inf.rows >= 1024 && !(skip_mask() & 2)) {
             // V' half of this sub-batch's projection: needs the new rows (ev_p), feeds only the UC kernel below
             HIP_TRY(hipStreamWaitEvent(vs, h->ev_p[set], 0));
@@ -1353,24 +1250,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
-        if (wc) {
-            // consumers of batch b's ring slots: every workgroup of the chain has published and counted the batch
-            HIP_TRY(launch_gate(h->wc_flags.as<unsigned long long>() + 2, (unsigned long long)(b + 1) * s_blocks, h->err_dev, vs));
-            if (vs != ucs) { HIP_TRY(hipEventRecord(h->ev_s[set], vs)); HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0)); }
-        } else {
-            HIP_TRY(hipEventRecord(h->ev_s[set], stream));
-            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
-            if (vs != ucs) HIP_TRY(hipStreamWaitEvent(vs, h->ev_s[set], 0));
-        }
+        HIP_TRY(hipEventRecord(h->ev_s[set], stream));
+        HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
         if (persistent)
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
-        if (vs != ucs) {
-            HIP_TRY(hipEventRecord(h->ev_aux[set], vs));
-            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_aux[set], 0));
-        }
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[rset].as<float>(), h->P_ws[set].as<float>(),
                                     sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
-        if (wc) HIP_TRY(launch_signal_add(h->wc_flags.as<unsigned long long>() + 1, ucs));   // uc_done: batch b's ring slots are free
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
         HIP_TRY(hipEventRecord(h->ev_r[rset], ucs));

@@ -427,30 +427,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     // row e4 / PPR, piece e4 % PPR;   uniforms: S float64 -> double2 per lane
     struct LdSet { floatx4 sn[kB2Ld]; double2 u[4]; };
     LdSet ldA, ldB;
-    // whole-call mode: before the first input of sub-batch `sbi` is requested, its new-row scores must be complete and the
-    // ring slots it will write must have been consumed (loader wave only; everybody else meets it at the next barrier)
-    auto wc_gate = [&](int sbi) {
-        const unsigned long long need_g = (unsigned long long)sbi + 1ull;
-        const unsigned long long need_u = sbi >= 3 ? (unsigned long long)(sbi - 2) : 0ull;
-        int spins = 0;
-        while (coherent_read(a.wc_flags + 0) < need_g || coherent_read(a.wc_flags + 1) < need_u) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the GEMM's rows were written by another kernel
-    };
     auto ld_request = [&](int i, LdSet& r) {
-        const float* sb;
-        int splitk = a.snew_splitk;
-        long split_stride = a.snew_split_stride;
-        if (a.wc_sub > 0) {
-            const int sbi = i / a.wc_sub, ri = i - sbi * a.wc_sub;
-            if (ri == 0) wc_gate(sbi);
-            sb = a.wc_snew[(a.wc_set0 + sbi) % 3] + (long)ri * tile_snew + tile;
-            if (sbi == a.wc_n_sub - 1) { splitk = a.wc_last_splitk; split_stride = a.wc_last_split_stride; }
-        } else {
-            sb = a.Snew + (long)i * tile_snew + tile;
-        }
+        const float* sb = a.Snew + (long)i * tile_snew + tile;
+        const int splitk = a.snew_splitk;
+        const long split_stride = a.snew_split_stride;
 #pragma unroll
         for (int k = 0; k < kB2Ld; ++k) {
             const int e4 = lane + 64 * k;
@@ -737,16 +717,6 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         }
         { float* t = scc; scc = scn; scn = t; }
         B2STAMP(6);
-        if (a.wc_sub > 0 && ((i + 1) % a.wc_sub == 0 || last)) {
-            // end of a sub-batch: make this workgroup's ring rows visible to other kernels, then count it in `progress`
-            if (wave >= 1 && wave <= 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 64) {                                                   // a storing wave: never wave 0, whose poll is armed
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                atomicAdd(a.wc_flags + 2, 1ull);
-            }
-        }
         B2STAMP(7);
         // LDS reuse: cdf / coarse are rewritten by wave 0 after barrier 3, i.e. after every search of this step; the
         // S'new / uniform tiles of parity i are rewritten by wave 7 behind barrier 1 of step i+1; tabb and the bins parked in
@@ -867,27 +837,6 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     }
 }
 
-__global__ void signal_add_kernel(unsigned long long* counter) { atomicAdd(counter, 1ull); }
-
-__global__ void gate_kernel(unsigned long long* counter, unsigned long long target, unsigned int* error) {
-    // one lane spins (bounded) until the counter, which only device-scope atomics touch, reaches the target
-    long spins = 0;
-    while (coherent_read(counter) < target) {
-        __builtin_amdgcn_s_sleep(32);
-        if (++spins > (1L << 26)) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-}
-
-hipError_t launch_signal_add(unsigned long long* counter, hipStream_t stream) {
-    hipLaunchKernelGGL(signal_add_kernel, dim3(1), dim3(1), 0, stream, counter);
-    return hipGetLastError();
-}
-
-hipError_t launch_gate(unsigned long long* counter, unsigned long long target, unsigned int* error, hipStream_t stream) {
-    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(1), 0, stream, counter, target, error);
-    return hipGetLastError();
-}
-
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream) {
     if (a.n_steps <= 0) return hipSuccess;
     if (a.N > 256 || (a.N * a.tabw) % 4) return hipErrorInvalidValue;
@@ -975,7 +924,7 @@ static hipError_t chain_batch_attr() {
 // bounded and report through the error word).  One workgroup per CU less than the API's answer: the occupancy
 // query reads one high for some SGPR counts (MI355X_MICROARCH.md, residency).
 bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q) {
-    static const bool want_v2 = [] { const char* e = getenv("INFV_CHAIN_V1"); return !e || atoi(e) == 0; }();
+    static const bool want_v2 = [] { const char* e = exp_env("INFV_CHAIN_V1"); return !e || atoi(e) == 0; }();
     return want_v2 && draw_mode == 1 && points_ok && 2 * rows <= 64 * kB2Ld && S <= 512 && S % 2 == 0 && Q % 4 == 0;
 }
 
@@ -983,7 +932,7 @@ bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q)
 // whole CU by its registers -- and half the arrivals per exchange) when the loader's register tile holds 16 scores per new
 // row; INFV_CHAIN_RPW=1 restores 8-row tiles.
 int chain_batch2_rpw(int rows, int Q) {
-    static const int want = [] { const char* e = getenv("INFV_CHAIN_RPW"); return e ? atoi(e) : 2; }();
+    static const int want = [] { const char* e = exp_env("INFV_CHAIN_RPW"); return e ? atoi(e) : 2; }();
     if (want >= 2 && 4 * rows <= 64 * kB2Ld && Q > kBRows) return 2;
     return 1;
 }
@@ -1000,7 +949,7 @@ int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int ro
 
 static size_t chain_batch2_launch_lds(int N, int S, int rows, int tabw, int rpw) {
     // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
-    static const int pad = [] { const char* e = getenv("INFV_S_LDS"); return e ? atoi(e) : 0; }();
+    static const int pad = [] { const char* e = exp_env("INFV_S_LDS"); return e ? atoi(e) : 0; }();
     size_t lds = (size_t)batch2_smem(N, S, rows, tabw, rpw).total * sizeof(float);
     if ((size_t)pad > lds) lds = pad;
     return lds;

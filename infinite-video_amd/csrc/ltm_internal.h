@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "knobs.h"
+
 namespace infv {
 
 constexpr int kMaxLayers = 8;
@@ -147,15 +149,6 @@ struct ChainBatchArgs {
     int32_t* tabb_ring;             // chain_batch2_kernel: drawn bin of every (box, slot), same slot layout as tab_ring
     float* crit_ring; long crit_slot;   // chain_batch2_kernel: point scores after every step, [ring][L][H][Q][128]
     int publish_init;               // chain_batch2_kernel: also write the state BEFORE step 0 to the slot before slot0's
-    // whole-call mode (wc_sub > 0): ONE launch runs every sub-batch of a consolidate call.  The kernel then gates itself on
-    // its inputs and publishes its progress through counters that only device-scope atomics touch:
-    //   wc_flags[0] gemm_ready  sub-batches whose new-row scores are complete (side stream, after the score GEMM)
-    //   wc_flags[1] uc_done     sub-batches whose ring slots have been consumed (UC stream, after the UC kernel)
-    //   wc_flags[2] progress    += 1 per workgroup and finished sub-batch (gates the consumers of this kernel's rings)
-    int wc_sub, wc_n_sub, wc_set0;  // chunks per sub-batch, sub-batches, workspace set of the first one (sets rotate mod 3)
-    const float* wc_snew[3];        // S'new base of the three workspace sets
-    int wc_last_splitk; long wc_last_split_stride;   // the final (possibly short) sub-batch may come as split-K slabs
-    unsigned long long* wc_flags;
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
     const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // [n_steps][rows] rows of pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
@@ -179,9 +172,6 @@ struct AlphaRows2Args {
     float* Sp_out;                  // full bias-free score rows of the LAST step [L][H][Q][N], or nullptr
 };
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
-// stream-ordered counter arithmetic for the whole-call chain kernel: add 1 / spin until the counter reaches `target`
-hipError_t launch_signal_add(unsigned long long* counter, hipStream_t stream);
-hipError_t launch_gate(unsigned long long* counter, unsigned long long target, unsigned int* error, hipStream_t stream);
 bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int draw_mode, int points_ok, int Q);   // all workgroups of the kernel the launch will use fit on the device at once
 hipError_t launch_chain_batch(const ChainBatchArgs& a, hipStream_t stream);
 

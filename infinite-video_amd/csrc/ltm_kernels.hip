@@ -149,15 +149,15 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        static const int max_wgs = [] { const char* e = getenv("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
+        static const int max_wgs = [] { const char* e = exp_env("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
         // loads in flight per wave (KiB).  The pool's outstanding bytes set the queueing delay that every other kernel's
         // memory operation sees while it runs (role S's atomics and stores: all of its phases stretch 1.5-2x during
         // pooling).  4 KiB per wave (8 MiB chip-wide) keeps ~95 % of the in-situ pooling rate and gives role S back
         // ~0.5 ms per video; 16 is fastest for the pool alone.
-        static const int unroll = [] { const char* e = getenv("INFV_POOL_UNROLL"); return e ? atoi(e) : 4; }();
+        static const int unroll = [] { const char* e = exp_env("INFV_POOL_UNROLL"); return e ? atoi(e) : 4; }();
         // INFV_POOL_NT=1024: sixteen waves per workgroup (still one workgroup per CU by the padding LDS): the pooling rate
         // follows the number of resident pooling waves, and other kernels hold part of the CUs
-        static const int nt1024 = [] { const char* e = getenv("INFV_POOL_NT"); return e && atoi(e) == 1024; }();
+        static const int nt1024 = [] { const char* e = exp_env("INFV_POOL_NT"); return e && atoi(e) == 1024; }();
         if (nt1024) {
             static bool attr_big = false;
             if (!attr_big) {
@@ -178,7 +178,7 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
         // INFV_POOL_DB=<U>: the rolling double-buffered form with U loads per group (U | P)
-        static const int db = [] { const char* e = getenv("INFV_POOL_DB"); return e ? atoi(e) : 0; }();
+        static const int db = [] { const char* e = exp_env("INFV_POOL_DB"); return e ? atoi(e) : 0; }();
         if (db > 0 && P % db == 0 && (db == 1 || db == 2 || db == 4)) {
             static bool attr_db = false;
             if (!attr_db) {
@@ -636,7 +636,7 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static const bool want_lw = [] { const char* e = getenv("INFV_GEMM_LW"); return !e || atoi(e) != 0; }();   // default on
+    static const bool want_lw = [] { const char* e = exp_env("INFV_GEMM_LW"); return !e || atoi(e) != 0; }();   // default on
     if (want_lw && M >= 1024 && lds_pad <= 0 && k_per_split == 24 * kBK) {
         static bool attr_lw = false;
         if (!attr_lw) {
@@ -1190,7 +1190,7 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static const bool want_small = [] { const char* e = getenv("INFV_ATTEND_SMALL"); return !e || atoi(e) != 0; }();
+    static const bool want_small = [] { const char* e = exp_env("INFV_ATTEND_SMALL"); return !e || atoi(e) != 0; }();
     if (want_small && N <= 256 && N % 16 == 0) {
         static bool attr2 = false;
         if (!attr2) {

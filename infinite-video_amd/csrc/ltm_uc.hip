@@ -550,8 +550,6 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel<false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(uc_fast_kernel<true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -560,21 +558,17 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
     if (a.n_chunks <= 0) return hipSuccess;
     if (!uc_supported(a.N, a.d, a.dm, a.tabw, a.op.rows)) return hipErrorInvalidValue;
     const int blocks = a.L * (a.d / kUcCols + a.dm / kUcCols);
-    static const bool want_fast = [] { const char* e = getenv("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
+    static const bool want_fast = [] { const char* e = exp_env("INFV_UC_FAST"); return !e || atoi(e) != 0; }();
     if (want_fast && uc_fast_supported(a.N, a.Q, a.tabw)) {
-        // 16-column V' slices by default (INFV_UC_V16=0: 32-column slices as in round 1): twice the read-out workgroups with
-        // half the MFMA work each, 73 KB of LDS: the UC kernel 10.0 -> 7.8 ms per video in situ, the call 17.9 -> 16.9 ms
-        static const bool v16 = [] { const char* e = getenv("INFV_UC_V16"); return !e || atoi(e) != 0; }();
+        // 16-column V' slices (32-column B slices): twice the read-out workgroups of round 1's 32-column form with half the
+        // MFMA work each, 73 KB of LDS (the 32-column instantiation measured 10.0 against 7.8 ms per video and is gone;
+        // dm is a multiple of the head size 64, so the narrow slices always apply)
         UcArgs b = a;
-        b.v16 = (v16 && a.dm % 16 == 0) ? 1 : 0;
-        const int nblk = b.v16 ? a.L * (a.d / kUcCols + a.dm / 16) : blocks;
-        size_t lds_floats = (size_t)2 * a.N * 32 + 8 * 64 * 4 + kUcQ * (a.N + 4);
-        if (b.v16) {
-            const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
-            lds_floats = vfl > bfl ? vfl : bfl;
-        }
-        if (b.v16) hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
-        else hipLaunchKernelGGL(uc_fast_kernel<false>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
+        b.v16 = 1;
+        const int nblk = a.L * (a.d / kUcCols + a.dm / 16);
+        const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
+        const size_t lds_floats = vfl > bfl ? vfl : bfl;
+        hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // the wide tiles need whole 384 x 128 tiles and enough of them to fill the chip
 bool split_gemm_wide_applies(const SplitGemm& g) {
-    static const int mode = [] { const char* e = getenv("INFV_SPLIT_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char* e = exp_env("INFV_SPLIT_GEMM_WIDE"); return e ? atoi(e) : 1; }();
     if (!mode) return false;
     if (g.M % kWRowsA || g.N % kWRowsB) return false;               // whole tiles only (unconditional loads and stores)
     const long mt = g.M / kWRowsA;

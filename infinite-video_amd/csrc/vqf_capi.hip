@@ -347,8 +347,11 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
         if (int rc = prepare_split(h, frames, 1, n_tokens, use_ltm && fused_pool ? h->kbar.as<float>() : nullptr, false, &sref, stream)) return rc;
         pre = &sref;
     }
-    if (use_ltm && !fused_pool)
+    if (use_ltm && !fused_pool) {
+        // (the frames of this entry point are fp32: the handle's token dtype is sticky state an earlier bf16 caller may have set)
+        if (int rc = infv_ltm_set_token_dtype(ltm[0], INFV_TOKENS_F32)) return rc;
         if (int rc = infv_ltm_pool(ltm[0], frames, T, h->kbar.as<float>(), stream_)) return rc;   // shared by all layers
+    }
 
     for (int l = 0; l < c.n_layers; ++l) {
         const infv_vqf_layer& L = w->layer[l];
@@ -435,7 +438,7 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
         }
     }
     {
-        static const int nb_env = [] { const char* e = getenv("INFV_VQF_NB"); return e ? atoi(e) : 0; }();   // (sweeps)
+        static const int nb_env = [] { const char* e = exp_env("INFV_VQF_NB"); return e ? atoi(e) : 0; }();   // (sweeps)
         if (nb_env > 0) NB = nb_env < C ? nb_env : C;
     }
     {
@@ -520,6 +523,8 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                 if (have_kbar) {
                     if (int rc = infv_ltm_consolidate_pooled(ltm[l], h->vkbar.as<float>(), C, T, h->v_xqs.as<float>(), Q, &pr,
                                                              u ? h->vu.as<double>() : nullptr, new_video, valong, stream_)) return rc;
+                } else if (int rc = infv_ltm_set_token_dtype(ltm[l], INFV_TOKENS_F32)) {
+                    return rc;
                 } else if (int rc = infv_ltm_consolidate(ltm[l], frames, C, T, h->v_xqs.as<float>(), Q, &pr,
                                                          u ? h->vu.as<double>() : nullptr, new_video, valong, stream_)) return rc;
             }
@@ -556,8 +561,10 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
                 HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
                 if (new_video)
                     if (int rc = infv_ltm_reset(ltm[l])) return rc;
-                if (!have_kbar)
+                if (!have_kbar) {
+                    if (int rc = infv_ltm_set_token_dtype(ltm[l], INFV_TOKENS_F32)) return rc;
                     if (int rc = infv_ltm_pool(ltm[l], frames, (int64_t)C * T, h->vkbar.as<float>(), h->side)) return rc;
+                }
                 // per-chunk queries: new-row projections of all chunks in one GEMM, then the chain chunk by chunk
                 if (int rc = infv_ltm_steps(ltm[l], h->vkbar.as<float>(), C, T, vxq, Q, &pr, u ? h->vu.as<double>() : nullptr,
                                             valong, h->side)) return rc;

@@ -1,5 +1,6 @@
 // Internal interface between the video Q-former C ABI (vqf_capi.hip) and its gfx950 kernels (vqf_kernels.hip).
 #pragma once
+#include "knobs.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -123,7 +123,7 @@ class LTMEngine:
         if len(projs) != self.L:
             raise ValueError(f"expected projections for {self.L} layers, got {len(projs)}")
         # the same weight tensors call after call (the per-chunk loop): validated once, the ctypes array is reused
-        key = tuple((t.data_ptr(), t.shape[0]) for p in projs for t in p)
+        key = tuple((t.data_ptr(), tuple(t.shape), t.stride(), t.dtype, t.device) for p in projs for t in p)
         cached = getattr(self, "_proj_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -166,9 +166,10 @@ class LTMEngine:
         if k.dtype not in TOKEN_DTYPES:
             raise TypeError(f"frame tokens must be float32 or bfloat16, got {k.dtype}")
         _check_dev(k, self.device, "k", k.dtype)
-        if k.dtype != self._token_dtype:
-            _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, TOKEN_DTYPES[k.dtype]))
-            self._token_dtype = k.dtype
+        # always: the dtype is sticky state of the handle and other users of the handle (the video Q-former's C path) set it
+        # too, so a Python-side cache of it could go stale
+        _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, TOKEN_DTYPES[k.dtype]))
+        self._token_dtype = k.dtype
 
     # ------------------------------------------------------------------ operators
     def pool(self, k: torch.Tensor) -> torch.Tensor:

@@ -116,7 +116,11 @@ class LongTermAttention(nn.Module):
         if cached is not None and cached[0] == stamp:
             return cached[1]
         views = self._proj_build(device)
-        self._proj_views = (stamp, views)
+        # cache only views that ALIAS the parameters (fp32, contiguous, on the device): a converted copy would go stale when
+        # the parameter is rewritten through ``.data`` (which does not bump ``_version``)
+        params = [t for t in (pk.weight, pk.bias, pv.weight, pv.bias) if t is not None]
+        aliased = all(any(v.data_ptr() == t.data_ptr() for t in params) for v in views) and len(params) == 4
+        self._proj_views = (stamp, views) if aliased else None
         return views
 
     def _proj_build(self, device):

@@ -181,29 +181,55 @@ def test_split_bf16_value_projection_stays_inside_tolerance(dev, monkeypatch):
         np.testing.assert_array_equal(exact.export_state(l)[0].cpu().numpy(), split.export_state(l)[0].cpu().numpy())
 
 
-def test_chain_timeout_is_reported_not_swallowed(dev, monkeypatch):
-    """Fault injection: the persistent chain kernel is told to expect one arrival more than its workgroups can deliver,
-    so every wait times out.  The failure must surface as INFV_ERR_STATE at sync() (and at the next entry point),
-    once, and a fresh engine must be unaffected."""
-    from infinite_video_amd import _lib
-    k, q, projs, u, _, _ = _video(dev, 8)
-    monkeypatch.setenv("INFV_CHAIN_FAULT", "1")
-    bad = _engine(dev, max_batch_chunks=4)
-    monkeypatch.delenv("INFV_CHAIN_FAULT")
-    bad.consolidate(k, q, projs, u, new_doc=True)
-    with pytest.raises(_lib.LTMError) as ei:
-        bad.sync()
-    assert ei.value.code == -4 and "timed out" in str(ei.value)
-    assert not bad.has_memory                                   # the invalid memory was dropped
-    bad.sync()                                                  # reported once
-    bad.consolidate(k, q, projs, u, new_doc=True)
-    torch.cuda.synchronize()
-    with pytest.raises(_lib.LTMError):                          # ... and caught by whatever entry point comes next
-        bad.export_state(0)
-    good = _engine(dev, max_batch_chunks=4)
-    ctx = good.consolidate(k, q, projs, u, new_doc=True)
-    good.sync()
-    assert bool(torch.isfinite(ctx).all())
+_FAULT_CHILD = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from infinite_video_amd import _lib
+from tests.test_timed_path_gpu import _engine, _video
+dev = torch.device("cuda:0")
+k, q, projs, u, _, _ = _video(dev, 8)
+os.environ["INFV_CHAIN_FAULT"] = "1"                          # read when a handle is created (experiments build only)
+bad = _engine(dev, max_batch_chunks=4)
+del os.environ["INFV_CHAIN_FAULT"]
+bad.consolidate(k, q, projs, u, new_doc=True)
+try:
+    bad.sync()
+    raise SystemExit("the time-out was swallowed")
+except _lib.LTMError as e:
+    assert e.code == -4 and "timed out" in str(e), str(e)
+assert not bad.has_memory                                   # the invalid memory was dropped
+bad.sync()                                                  # reported once
+bad.consolidate(k, q, projs, u, new_doc=True)
+torch.cuda.synchronize()
+try:
+    bad.export_state(0)                                     # ... and caught by whatever entry point comes next
+    raise SystemExit("the second time-out was swallowed")
+except _lib.LTMError:
+    pass
+good = _engine(dev, max_batch_chunks=4)
+ctx = good.consolidate(k, q, projs, u, new_doc=True)
+good.sync()
+assert bool(torch.isfinite(ctx).all())
+print("FAULT_CHILD_OK")
+'''
+
+
+def _run_child(code, env_add, *args, timeout=900):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_add)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code, *args], check=True, env=env, cwd=root, timeout=timeout,
+                          capture_output=True, text=True)
+
+
+def test_chain_timeout_is_reported_not_swallowed(dev):
+    """Fault injection (experiments build of the library, INFV_LTM_LIBRARY=exp: the shipped one has no such switch): the
+    persistent chain kernel is told to expect one arrival more than its workgroups can deliver, so every wait times out.
+    The failure must surface as INFV_ERR_STATE at sync() (and at the next entry point), once, and a fresh engine must be
+    unaffected.  Runs in a child process: a process loads one build of the library."""
+    r = _run_child(_FAULT_CHILD, {"INFV_LTM_LIBRARY": "exp"})
+    assert "FAULT_CHILD_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_consolidate_video_through_rccl_world_of_one(dev):
@@ -232,13 +258,7 @@ def test_consolidate_video_through_rccl_world_of_one(dev):
     torch.testing.assert_close(mem1.mean_embedding(), ctx1.mean(0), rtol=1e-5, atol=1e-6)
 
 
-def test_whole_call_chain_launch_matches_the_default(dev, monkeypatch):
-    """INFV_WHOLE_CALL=1: ONE launch of the chain kernel for every sub-batch of a call, gated on device-side counters
-    (score GEMMs done / ring slots consumed / progress).  Same arithmetic, so the outputs must equal the default path's
-    bit for bit -- including a short final sub-batch (split-K slabs) and a second call that continues the memory."""
-    import subprocess
-    import sys
-    code = r'''
+_VARIANT_CHILD = r'''
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from tests.test_timed_path_gpu import _engine, _video
@@ -251,22 +271,32 @@ e.sync()
 B = [e.export_state(l)[0].cpu().numpy() for l in range(2)]
 np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bins=e.last_draw(0)[0])
 '''
-    import tempfile
-    outs = []
-    for env_add in ({"INFV_WHOLE_CALL": "0"}, {"INFV_WHOLE_CALL": "1"}, {"INFV_UC_V16": "0"}):
-        with tempfile.NamedTemporaryFile(suffix=".npz") as f:
-            env = dict(os.environ, **env_add)
-            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
-            outs.append({k_: v for k_, v in np.load(f.name).items()})
-    for key in outs[0]:
-        np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=key)
-    # INFV_UC_V16=0 (32-column V' slices in the UC kernel: two k-partials per read-out tile instead of the default four): same
-    # memory and draws bit for bit, contexts equal up to the association of the read-out sum
-    for key in ("B0", "B1", "bins"):
-        np.testing.assert_array_equal(outs[0][key], outs[2][key], err_msg=key)
-    for key in ("a", "b"):
-        np.testing.assert_allclose(outs[0][key], outs[2][key], rtol=0, atol=2e-6, err_msg=key)
-        assert np.abs(outs[0][key] - outs[2][key]).max() > 0, "the 32-column variant did not run"
+
+# non-default variants kept in the sources (A/B material, experiments build only): each must reproduce the shipped default
+_VARIANTS = [
+    {},                                                        # the experiments build with no knob set
+    {"INFV_POOL_ROWS": "1"},                                   # fused pool + rows kernel (R straight from the tokens)
+    {"INFV_POOL_ROWS": "1", "INFV_PR_NT": "256", "INFV_PR_U": "8", "INFV_PR_WGS": "300"},   # ... grid-stride, 4-wave workgroups
+    {"INFV_POOL_DB": "2"},                                     # rolling double-buffered pooling kernel
+    {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
+    {"INFV_VPROJ_ON_UC": "1"},                                 # V' half of the projection as its own GEMM on the UC stream
+    {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
+    {"INFV_GEMM_LW": "0"},                                     # projection GEMM without loader waves
+]
+
+
+def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
+    """A 70-chunk call (two 32-chunk sub-batches + a short one: split-K slabs) and a 5-chunk continuation, once with the
+    shipped library and once per variant with the experiments build: contexts, memory and draws identical bit for bit."""
+    def run(env_add, name):
+        path = str(tmp_path / name)
+        _run_child(_VARIANT_CHILD, env_add, path)
+        return {k_: v for k_, v in np.load(path).items()}
+    base = run({}, "base.npz")
+    for i, v in enumerate(_VARIANTS):
+        got = run(dict(v, INFV_LTM_LIBRARY="exp"), f"v{i}.npz")
+        for key in base:
+            np.testing.assert_array_equal(base[key], got[key], err_msg=f"{v}: {key}")
 
 
 @pytest.mark.parametrize("n_chunks,max_batch,split", [(33, 42, 0), (45, 7, 0), (70, 28, 37), (129, 42, 1), (97, 13, 50),

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # one isolation run: ./tools/iso_one.sh <INFV_SKIP mask> [extra VAR=value ...]
 # (plain timing run: `env VAR=... python` is fine HERE because nothing has touched the GPU before the exec.  Do NOT copy
 #  this pattern behind rocprofv3: there the program after `--` must be python3 itself, see tools/pmc_mfma.sh)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # FETCH_SIZE of the video Q-former path per chunk, with the single token pass (INFV_VQF_FUSE=1, default) and with the
 # round-1 arrangement (separate pooling + one split pass per layer).  One PMC pass each, nothing else traced.
 # usage (GPU box): tools/pmc_qformer.sh <tag>  -> gpurun_out/pmcq_<tag>/summary.json

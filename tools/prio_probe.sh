@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # stream-priority experiments on the fused pooling kernel (ms of the last of three passes)
 run() { echo "== $*"; env "$@" python tools/one_pass.py 2048 3 2>&1 | tail -1; }
 B="INFV_PR_NT=256 INFV_PR_U=8"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # rocprofv3 passes of the headline bench: kernel-trace stats, then PMC passes (each on its own, as gpurun requires)
 # usage (GPU box): tools/profile_round.sh <tag>    -> gpurun_out/prof_<tag>/ (copy the summaries to profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

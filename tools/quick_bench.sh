@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # experiment knobs passed in by the caller only exist in the experiments build (csrc/knobs.h)
 # usage (on the GPU box): tools/quick_bench.sh <tag> [steps]  -- short headline bench line + per-kernel ms, no CPU legs
 tag=$1; steps=${2:-10}
 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-encode-video --no-secondary > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err

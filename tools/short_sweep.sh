@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # experiment knobs passed in by the caller only exist in the experiments build (csrc/knobs.h)
 # usage (GPU box): tools/short_sweep.sh "<ENV=V ...>" ...   -- ms per 256-chunk call (the 8-GPU shard) under each env set
 for envs in "$@"; do
   ( for kv in $envs; do export "$kv"; done

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # usage (GPU box): tools/skip_probe.sh  -- headline pass with subsets of the streams launched (INFV_SKIP bit mask:
 # 1 pooling, 2 projection GEMMs, 4 UC + alpha, 8 role S; results are garbage, timing only): who slows whom
 for mask in 0 4 6 2 8 12 14; do

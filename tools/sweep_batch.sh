@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # experiment knobs passed in by the caller only exist in the experiments build (csrc/knobs.h)
 # sub-batch size sweep of the headline bench: ./tools/sweep_batch.sh <chunks> <batch sizes...>
 chunks=$1; shift
 for b in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # round-3 sweep b: the fused pool+rows kernel, its footprint (threads / loads per group / padding LDS) and who may sit beside it
 tools/env_sweep.sh \
  "INFV_POOL_ROWS=0" \

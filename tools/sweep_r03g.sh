@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 export INFV_VPROJ_ON_UC=0 INFV_POOL_ROWS=0
 tools/env_sweep.sh \
  "INFV_NONE=0" \

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # experiment knobs passed in by the caller only exist in the experiments build (csrc/knobs.h)
 # usage (GPU box): tools/trace_short.sh <tag> [chunks=256]  -- full kernel timeline of the last pass of a SHORT call
 # (the 8-GPU shard of the headline video): where the fill / drain / packing time goes
 tag=$1; chunks=${2:-256}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # experiment knobs passed in by the caller only exist in the experiments build (csrc/knobs.h)
 # usage (GPU box): tools/trace_window.sh <tag> [chunks]   -- kernel timeline of the last pass: per-stream busy time,
 # per-kernel totals, and a window of three sub-batches from the middle (start / end / duration per kernel and stream)
 tag=$1; chunks=${2:-2048}
