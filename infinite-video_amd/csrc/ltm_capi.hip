@@ -258,22 +258,26 @@ int upload_operator(Operator& op, int N, int rows, const int32_t* row_box, const
 }
 
 // draw (if the memory exists) -> update -> attend, for all layers, on one chunk's new rows.
+// kbar_rows != nullptr (single-chunk step): R is null and the update builds the new rows of B from the pooled frames;
+// draw_done: the draw already ran inside the projection launch (launch_step_project).
 int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float* Pnew, int splitk,
                long split_stride, const float* q, int Q, const ProjPtrs& pp, const double* u, float* ctx,
-               hipStream_t stream) {
+               hipStream_t stream, const float* kbar_rows = nullptr, bool draw_done = false) {
     const bool inf = h->has_memory;
     const Operator& op = inf ? plan.inf : plan.first;
     const int32_t* idx = nullptr;
     int idx_stride = 0;
     if (inf) {
         if (h->cfg.sticky) {
-            if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
-            if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
-            Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
-            HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(),
-                                h->override_mask, plan.sticky(), u, h->S, h->L,
-                                h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream,
-                                h->bins_forced.as<int32_t>(), h->forced_mask));
+            if (!draw_done) {
+                if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
+                if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+                Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
+                HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(),
+                                    h->override_mask, plan.sticky(), u, h->S, h->L,
+                                    h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(), stream,
+                                    h->bins_forced.as<int32_t>(), h->forced_mask));
+            }
             h->override_mask = 0;
             h->forced_mask = 0;
             idx = h->idx.as<int32_t>();
@@ -288,7 +292,7 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
     Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
     HIP_TRY(launch_update(op.view(), h->N, h->d, h->dm, h->L, h->S, idx, idx_stride, R, Pnew, splitk, split_stride,
                           h->B[h->cur].as<float>(), h->KV[h->cur].as<float>(), h->B[nxt].as<float>(),
-                          h->KV[nxt].as<float>(), stream));
+                          h->KV[nxt].as<float>(), stream, kbar_rows));
     }
     h->cur = nxt;
     h->has_memory = true;
@@ -573,9 +577,31 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
     if (plan->dense.on) return dense_step(h, *plan, kbar, T, q, Q, pp, u, ctx, stream);
     if (h->k_stale && h->has_memory)
         if (int rc = infv_ltm_reproject(h, proj, stream_)) return rc;
-    int sk = 1; long ss = 0;
-    if (int rc = project_chunks(h, *plan, h->has_memory, kbar, 1, T, pp, 0, &sk, &ss, stream)) return rc;
-    return chain_step(h, *plan, h->R_ws[0].as<float>(), h->P_ws[0].as<float>(), sk, ss, q, Q, pp, u, ctx, stream);
+    // Three launches per step (six in round 2): [new-row projection with the rows built on the fly + the draw] -> update
+    // (its new B rows built from the pooled frames too) -> attend.  Same arithmetic in the same order as the batched path.
+    const bool inf = h->has_memory;
+    const Operator& op = inf ? plan->inf : plan->first;
+    const long n_cols = (long)h->L * 2 * h->dm;
+    const int sk_max = project_splitk(op.rows > 0 ? op.rows : 1, h->d);
+    const size_t needP = (size_t)(op.rows ? op.rows : 1) * n_cols * sk_max * sizeof(float);
+    if (needP > h->P_ws[0].bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->P_ws[0].reserve(needP)); }
+    StepDraw dr;
+    memset(&dr, 0, sizeof(dr));
+    if (inf && h->cfg.sticky) {
+        if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
+        if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+        dr.n_layers = h->L; dr.bin_part = h->bin_part[h->pc].as<float>(); dr.parts = h->parts;
+        dr.probs_override = h->probs_override.as<float>(); dr.override_mask = h->override_mask; dr.sticky = plan->sticky();
+        dr.u = u; dr.S = h->S; dr.probs_out = h->probs.as<float>(); dr.bins_out = h->bins.as<int32_t>(); dr.idx_out = h->idx.as<int32_t>();
+        dr.bins_forced = h->bins_forced.as<int32_t>(); dr.forced_mask = h->forced_mask;
+    }
+    int sk = 1;
+    {
+        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
+        HIP_TRY(launch_step_project(kbar, h->d, h->dm, h->L, op.view(), pp, h->P_ws[0].as<float>(), &sk, dr, stream));
+    }
+    return chain_step(h, *plan, nullptr, h->P_ws[0].as<float>(), sk, (long)op.rows * n_cols, q, Q, pp, u, ctx, stream, kbar,
+                      dr.n_layers > 0);
 }
 
 int infv_ltm_steps(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T, const float* q, int32_t Q,

@@ -81,6 +81,11 @@ hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, cons
 hipError_t launch_reproject(const float* B, int N, int d, int dm, int n_layers, const ProjPtrs& proj, float* KV,
                             hipStream_t stream);
 
+struct StepDraw {
+    int n_layers;                   // 0: no draw (first chunk of a document / uniform resampling)
+    const float* bin_part; int parts; const float* probs_override; unsigned override_mask; StickyView sticky;
+    const double* u; int S; float* probs_out; int32_t* bins_out; int32_t* idx_out; const int32_t* bins_forced; unsigned forced_mask;
+};
 hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
                        int32_t* bins, int32_t* idx, hipStream_t stream, const int32_t* bins_forced = nullptr,
@@ -90,7 +95,11 @@ hipError_t launch_draw(const float* bin_part, int parts, const float* probs_over
 hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
                          int idx_layer_stride, const float* R, const float* Pnew, int splitk,
                          long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
-                         float* KV_next, hipStream_t stream);
+                         float* KV_next, hipStream_t stream, const float* kbar = nullptr /* R == nullptr: rows built from kbar */);
+
+// per-call step, first launch: new-row projection with the rows built on the fly + the draw of every layer (one launch)
+hipError_t launch_step_project(const float* kbar, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
+                               float* Pnew, int* splitk, const StepDraw& draw, hipStream_t stream);
 
 // scores, count-weighted softmax, read-out and the next sticky histogram partials.
 int attend_parts(int Q, int H);

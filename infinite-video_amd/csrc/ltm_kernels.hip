@@ -355,15 +355,18 @@ hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int 
 constexpr int kBK = 32;
 constexpr int kLdsStride = kBK + 4;   // +1 access width (16 B) against ds_read_b128 conflicts
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
-                                                      WSegs segs,
-                                                      float* __restrict__ C, int ldc, long split_stride,
-                                                      int k_per_split, int y_off) {
+// A operand of the per-call step (ROWS): row m of A is not read but built on the fly from the chunk's pooled frames,
+//   A[m][:] = sum_{f in [row_begin[m], row_end[m])} val_m * kbar[f][:]      (build_rows_kernel's fma chain, same bits)
+struct RowsA {
+    const float* kbar; const int32_t* row_begin; const int32_t* row_end; const int32_t* row_box; const float* box_val;
+};
+
+template <int BM, int BN, bool ROWS>
+__device__ inline void gemm_nt_tile(const float* __restrict__ A, const RowsA& ra, int M, int K, const WSegs& segs,
+                                    float* __restrict__ C, int ldc, long split_stride, int k_per_split, int y_off,
+                                    float* As, float* Bs) {
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave in each dim
     constexpr int AR = BM / 32, BR = BN / 32;          // rows staged per thread
-    __shared__ float As[BM * kLdsStride];
-    __shared__ float Bs[BN * kLdsStride];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -376,10 +379,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     const int c4 = tid & 7, row0 = tid >> 3;
     const float* a_src[AR];
     const float* b_src[BR];
+    int fb[AR], fe[AR]; float aval[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + row0 + 32 * i;
-        a_src[i] = (m < M) ? A + (long)m * K + kbeg + c4 * 4 : nullptr;
+        fb[i] = fe[i] = 0; aval[i] = 0.f;
+        if (ROWS) {
+            a_src[i] = ra.kbar + kbeg + c4 * 4;
+            if (m < M) { fb[i] = ra.row_begin[m]; fe[i] = ra.row_end[m]; aval[i] = ra.box_val[ra.row_box[m]]; }
+        } else {
+            a_src[i] = (m < M) ? A + (long)m * K + kbeg + c4 * 4 : nullptr;
+        }
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
@@ -396,9 +406,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     floatx4 a_reg[2][AR], b_reg[2][BR];
     auto load_tile = [&](int t, floatx4 (&ar)[AR], floatx4 (&br)[BR]) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i)
-            ar[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + t * kBK)
-                             : floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < AR; ++i) {
+            if (ROWS) {
+                // four frames per trip, loaded unconditionally (index clamped into the row's range) so that the loads are in
+                // flight together; a frame past the end contributes fma(0, v, acc) = acc: build_rows_kernel's chain, same bits
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int f0 = fb[i]; f0 < fe[i]; f0 += 4) {
+                    floatx4 v[4]; float w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = min(f0 + j, fe[i] - 1);
+                        v[j] = *reinterpret_cast<const floatx4*>(a_src[i] + (long)f * K + t * kBK);
+                        w[j] = (f0 + j < fe[i]) ? aval[i] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc.x = fmaf(w[j], v[j].x, acc.x); acc.y = fmaf(w[j], v[j].y, acc.y);
+                        acc.z = fmaf(w[j], v[j].z, acc.z); acc.w = fmaf(w[j], v[j].w, acc.w);
+                    }
+                }
+                ar[i] = acc;
+            } else {
+                ar[i] = a_src[i] ? *reinterpret_cast<const floatx4*>(a_src[i] + t * kBK)
+                                 : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BR; ++i) br[i] = *reinterpret_cast<const floatx4*>(b_src[i] + t * kBK);
     };
@@ -472,6 +504,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                 const int o = n0 + wn * (BN / 2) + j * 32 + li;
                 if (m < M) __builtin_nontemporal_store(acc[i][j][r], &C[(long)m * ldc + o]);
             }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int M, int K,
+                                                      WSegs segs,
+                                                      float* __restrict__ C, int ldc, long split_stride,
+                                                      int k_per_split, int y_off) {
+    __shared__ float As[BM * kLdsStride];
+    __shared__ float Bs[BN * kLdsStride];
+    gemm_nt_tile<BM, BN, false>(A, RowsA{}, M, K, segs, C, ldc, split_stride, k_per_split, y_off, As, Bs);
+}
+
+// Per-call step, first launch: the new-row projection with the rows built on the fly (no rows kernel, no R buffer) on the
+// planes z < splitk, and -- independent of it -- the Gibbs draw of every layer on the extra plane z == splitk (one workgroup
+// per layer; the other workgroups of that plane exit at once).  Two launches and two kernel boundaries fewer per forward.
+__global__ __launch_bounds__(256) void step_project_kernel(RowsA ra, int M, int K, WSegs segs, float* __restrict__ C, int ldc,
+                                                           long split_stride, int k_per_split, int splitk, StepDraw dr) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * kLdsStride];
+    if ((int)blockIdx.z == splitk) {
+        const int l = blockIdx.y;
+        if (blockIdx.x != 0 || l >= dr.n_layers) return;
+        static_assert(2 * 64 * kLdsStride * sizeof(float) >= kBins * sizeof(float) + 256 * sizeof(double) + 1024 * sizeof(int32_t),
+                      "draw scratch fits in the GEMM's tiles");
+        double* gsum = reinterpret_cast<double*>(smem);                  // [256]
+        int32_t* sidx = reinterpret_cast<int32_t*>(smem + 512);          // [1024]
+        float* cdf = smem + 512 + 1024;                                  // [kBins]
+        const bool ovr = (dr.override_mask >> l) & 1u;
+        const DrawRegs<4> r = draw_load<256, 4>(dr.bin_part + (long)l * dr.parts * kBins, dr.parts, nullptr,
+                                                dr.probs_override + l * kBins, ovr, dr.u + (long)l * dr.S, dr.S);
+        draw_finish<256, 4>(r, ovr, dr.sticky.bin_box, dr.S, cdf, sidx, gsum, dr.probs_out + l * kBins, dr.bins_out + (long)l * dr.S,
+                            dr.idx_out + (long)l * dr.S, nullptr, ((dr.forced_mask >> l) & 1u) ? dr.bins_forced + (long)l * dr.S : nullptr);
+        return;
+    }
+    gemm_nt_tile<64, 64, true>(nullptr, ra, M, K, segs, C, ldc, split_stride, k_per_split, 0, smem, smem + 64 * kLdsStride);
 }
 
 // ======================================================================================
@@ -722,6 +788,24 @@ hipError_t launch_project(int n_chunks, int d, int dm, int n_layers, const Opera
     return launch_gemm(R, M, d, kv_segs(proj, 0, n_layers, dm), n_cols, Pnew, n_cols, sk, (long)M * n_cols, stream, lds_pad);
 }
 
+// Per-call step: Pnew[sk][r][l][kv][dm] for the rows of ONE chunk straight from its pooled frames (+ the draw, see
+// step_project_kernel).  Same split-K slabs as launch_project.
+hipError_t launch_step_project(const float* kbar, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
+                               float* Pnew, int* splitk, const StepDraw& draw, hipStream_t stream) {
+    const int M = op.rows, n_cols = n_layers * 2 * dm;
+    const int sk = project_splitk(M > 0 ? M : 1, d);
+    *splitk = sk;
+    if (M == 0 && draw.n_layers == 0) return hipSuccess;
+    if (n_cols % 64 || (d / sk) % kBK) return hipErrorInvalidValue;
+    RowsA ra{kbar, op.row_begin, op.row_end, op.row_box, op.box_val};
+    int gy = n_cols / 64;
+    if (gy < draw.n_layers) gy = draw.n_layers;
+    dim3 grid((M + 63) / 64 > 0 ? (M + 63) / 64 : 1, gy, sk + 1);
+    hipLaunchKernelGGL(step_project_kernel, grid, dim3(256), 0, stream, ra, M, d, kv_segs(proj, 0, n_layers, dm), Pnew, n_cols,
+                       (long)M * n_cols, d / sk, sk, draw);
+    return hipGetLastError();
+}
+
 // Fast path: ONE GEMM for the V' half of the new rows and their scores under the pre-multiplied queries qt:
 //   C[sk][m][0 : L*dm)           = R[m] . Wv[l]^T                       (projection of the new rows, V' half only)
 //   C[sk][m][L*dm : L*dm + n_out) = R[m] . qt[o],  o = (l*H + h)*Q + q   (new-row scores; the K half is never formed)
@@ -843,10 +927,14 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
                                                      long split_stride4,
                                                      const float* __restrict__ B_prev,
                                                      const float* __restrict__ KV_prev,
-                                                     float* __restrict__ B_next, float* __restrict__ KV_next) {
+                                                     float* __restrict__ B_next, float* __restrict__ KV_next,
+                                                     const float* __restrict__ kbar) {
     const int n = blockIdx.x, l = blockIdx.y;
     const float val = op.box_val[n];
     const int row = op.box_row[n];
+    int fb = 0, fe = 0;                                         // R == nullptr: the new row of B is built here from the pooled frames
+    if (R == nullptr && row >= 0) { fb = op.row_begin[row]; fe = op.row_end[row]; }
+    const floatx4* kb4 = reinterpret_cast<const floatx4*>(kbar);
     int sb = 0, se = 0;
     if (op.old_ptr != nullptr && idx != nullptr) { sb = op.old_ptr[n]; se = op.old_ptr[n + 1]; }
     const int32_t* my_idx = idx ? idx + (long)l * idx_layer_stride : nullptr;
@@ -881,7 +969,25 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
         }
         if (row >= 0) {
             if (isB) {
-                acc += R4[(long)row * d4 + cc];
+                if (R != nullptr) {
+                    acc += R4[(long)row * d4 + cc];
+                } else {                                        // build_rows_kernel's fma chain, same bits
+                    floatx4 rr = {0.f, 0.f, 0.f, 0.f};
+                    for (int f0 = fb; f0 < fe; f0 += 4) {       // four frames in flight (clamped index, zero weight past the end)
+                        floatx4 v[4]; float w[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = kb4[(long)min(f0 + j, fe - 1) * d4 + cc];
+                            w[j] = (f0 + j < fe) ? val : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            rr.x = fmaf(w[j], v[j].x, rr.x); rr.y = fmaf(w[j], v[j].y, rr.y);
+                            rr.z = fmaf(w[j], v[j].z, rr.z); rr.w = fmaf(w[j], v[j].w, rr.w);
+                        }
+                    }
+                    acc += rr;
+                }
             } else {
                 const long off = ((long)row * n_layers + l) * kv4 + cc;
                 for (int k = 0; k < splitk; ++k) acc += P4[off + k * split_stride4];
@@ -894,10 +1000,10 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
 hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
                          int idx_layer_stride, const float* R, const float* Pnew, int splitk,
                          long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
-                         float* KV_next, hipStream_t stream) {
+                         float* KV_next, hipStream_t stream, const float* kbar) {
     hipLaunchKernelGGL(update_kernel, dim3(N, n_layers), dim3(256), 0, stream, op, N, d / 4, dm / 4, n_layers, S,
                        idx, idx_layer_stride, R, Pnew, splitk, split_stride / 4, B_prev, KV_prev, B_next,
-                       KV_next);
+                       KV_next, kbar);
     return hipGetLastError();
 }
 

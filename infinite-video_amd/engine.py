@@ -170,6 +170,7 @@ class LTMEngine:
         # too, so a Python-side cache of it could go stale
         _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, TOKEN_DTYPES[k.dtype]))
         self._token_dtype = k.dtype
+        self._token_code = TOKEN_DTYPES[k.dtype]
 
     # ------------------------------------------------------------------ operators
     def pool(self, k: torch.Tensor) -> torch.Tensor:
@@ -196,6 +197,23 @@ class LTMEngine:
             _lib.check(self.lib.infv_ltm_step(self._h, _ptr(kbar), T, _ptr(q), Q, self._proj_array(projs),
                                                _ptr(u), _ptr(ctx), _stream(self.device)))
         return ctx
+
+    # -- lean entry points of the drop-in module's per-call path: the caller has validated shapes / dtypes / devices once for
+    #    this call signature; nothing is re-checked here, no context manager is entered (the caller's device is current)
+    def pool_into(self, k: torch.Tensor, kbar: torch.Tensor, n_frames: int, token_code: int, stream: C.c_void_p):
+        if token_code != getattr(self, "_token_code", -1):
+            _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, token_code))
+            self._token_code = token_code
+        rc = self.lib.infv_ltm_pool(self._h, C.c_void_p(k.data_ptr()), n_frames, C.c_void_p(kbar.data_ptr()), stream)
+        if rc < 0:
+            _lib.check(rc)
+
+    def step_raw(self, kbar_ptr: int, T: int, q_ptr: int, Q: int, proj_arr, u_ptr: int, ctx_ptr: int, stream: C.c_void_p):
+        """infv_ltm_step on raw addresses; ``u_ptr`` may be pinned host memory (the draw reads its 4 KB through the mapping)."""
+        rc = self.lib.infv_ltm_step(self._h, C.c_void_p(kbar_ptr), T, C.c_void_p(q_ptr), Q, proj_arr,
+                                    C.c_void_p(u_ptr) if u_ptr else None, C.c_void_p(ctx_ptr), stream)
+        if rc < 0:
+            _lib.check(rc)
 
     def forward(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
                 u: Optional[torch.Tensor] = None, new_doc: bool = False) -> torch.Tensor:

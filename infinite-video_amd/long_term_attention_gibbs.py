@@ -29,7 +29,9 @@ import torch
 import torch.nn as nn
 
 from .basis_maps import NB_SAMPLES
-from .engine import LTMEngine
+import ctypes as C
+
+from .engine import TOKEN_DTYPES, LTMEngine
 
 # one-entry cache of pooled frames: the Q-former calls every layer's LTM with the same
 # encoder_hidden_states tensor OBJECT, so the frame tokens (25 MB at the headline shape) are read once per
@@ -185,74 +187,107 @@ class LongTermAttention(nn.Module):
         eng.import_state(0, state["B_past"].to(device=device, dtype=torch.float32).contiguous(),
                          state["bin_mass"].to(device=device, dtype=torch.float32).contiguous(), self._proj(device))
 
-    _U_RING = 8
+    _U_RING = 64            # pinned slots of Gibbs uniforms; an event every _U_GROUP calls guards their reuse
+    _U_GROUP = 16
+    _U_VIA_COPY = False     # True: H2D copy of the 512 uniforms per call instead of letting the draw read the pinned slot
 
-    def _draw_uniforms(self, device) -> torch.Tensor:
-        """512 float64 uniforms for the bin draw + 512 for the degenerate in-bin draw (:204-206) from the global CPU generator,
-        staged through a small ring of pinned buffers so that the host never waits for the copy (a slot is reused only after
-        the copy that read it has completed)."""
+    def _draw_uniforms(self, device) -> int:
+        """512 float64 uniforms for the bin draw + 512 for the degenerate in-bin draw (:204-206) from the global CPU generator
+        (one ``torch.rand(1024)``: the same stream of draws as the reference's two calls), written into a slot of a pinned
+        ring.  Returns the HOST address of the first 512: the draw kernel reads them through the pinned mapping, so there is
+        no copy to issue; a slot is only rewritten after the event of the group that last used it has completed."""
         ring = getattr(self, "_u_ring", None)
         if ring is None or ring["device"] != device:
             S = self.nb_samples
-            ring = {"device": device, "i": 0,
-                    "pin": [torch.empty(2, S, dtype=torch.float64).pin_memory() for _ in range(self._U_RING)],
-                    "dev": [torch.empty(1, S, dtype=torch.float64, device=device) for _ in range(self._U_RING)],
-                    "ev": [None] * self._U_RING}
+            pin = torch.empty(self._U_RING, 2 * S, dtype=torch.float64).pin_memory()
+            ring = {"device": device, "i": 0, "pin": pin, "rows": [pin[j] for j in range(self._U_RING)],
+                    "addr": [pin[j].data_ptr() for j in range(self._U_RING)],
+                    "ev": [None] * (self._U_RING // self._U_GROUP)}
             self._u_ring = ring
         i = ring["i"]
         ring["i"] = (i + 1) % self._U_RING
-        if ring["ev"][i] is not None:
-            ring["ev"][i].synchronize()
-        pin, dev = ring["pin"][i], ring["dev"][i]
-        torch.rand(self.nb_samples, dtype=torch.float64, out=pin[0])
-        torch.rand(self.nb_samples, dtype=torch.float64, out=pin[1])      # consumed like the reference's second draw
-        dev.copy_(pin[0:1], non_blocking=True)
-        ev = ring["ev"][i] or torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        ring["ev"][i] = ev
-        return dev
+        g = i // self._U_GROUP
+        if i % self._U_GROUP == 0 and ring["ev"][g] is not None:
+            ring["ev"][g].synchronize()                   # the steps that read this group's slots have finished
+        torch.rand(2 * self.nb_samples, dtype=torch.float64, out=ring["rows"][i])
+        if self._U_VIA_COPY:
+            # staged into a device slot of the same ring: the draw then reads HBM instead of crossing PCIe inside the kernel
+            dev = ring.get("dev")
+            if dev is None:
+                dev = ring["dev"] = torch.empty(self._U_RING, self.nb_samples, dtype=torch.float64, device=device)
+                ring["dev_rows"] = [dev[j] for j in range(self._U_RING)]
+                ring["dev_addr"] = [dev[j].data_ptr() for j in range(self._U_RING)]
+                ring["pin_first"] = [ring["rows"][j][:self.nb_samples] for j in range(self._U_RING)]
+            ring["dev_rows"][i].copy_(ring["pin_first"][i], non_blocking=True)
+            return ring["dev_addr"][i]
+        return ring["addr"][i]
+
+    def _uniforms_used(self, device):
+        """Call after the step that reads the slot handed out last: every _U_GROUP-th slot records the group's event."""
+        ring = self._u_ring
+        last = (ring["i"] - 1) % self._U_RING
+        if last % self._U_GROUP == self._U_GROUP - 1:
+            g = last // self._U_GROUP
+            ev = ring["ev"][g] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            ring["ev"][g] = ev
 
     # ------------------------------------------------------------------ forward
     def forward(self, k, q, new_doc, layer_n):
         """k [1, T*P, d] frame tokens, q [1, Q, H*dh] -> [1, Q, H*dh]   (reference :288-346)."""
-        if not self._callable:
-            raise RuntimeError("this LongTermAttention was built with num_basis/tau = None (image Q-former) "
-                               "and must not be called")
-        if not k.is_cuda:
-            raise RuntimeError("LongTermAttention runs on the HIP device only (no CPU fallback)")
-        if k.size(0) != 1 or q.size(0) != 1:
-            raise ValueError("batch size must be 1 (reference :208,346)")
+        # validation runs once per call signature; the steady-state call (same shapes / dtypes / device) skips it
+        sig = (k.shape, k.dtype, k.device, q.shape, q.dtype, q.device)
+        if sig != getattr(self, "_sig", None):
+            if not self._callable:
+                raise RuntimeError("this LongTermAttention was built with num_basis/tau = None (image Q-former) "
+                                   "and must not be called")
+            if not k.is_cuda:
+                raise RuntimeError("LongTermAttention runs on the HIP device only (no CPU fallback)")
+            if k.size(0) != 1 or q.size(0) != 1:
+                raise ValueError("batch size must be 1 (reference :208,346)")
+            P, d = self.tokens_per_frame, self.encoder_width
+            if k.size(2) != d or k.size(1) % P:
+                raise ValueError(f"k must be [1, T*{P}, {d}]")
+            if q.device != k.device or q.size(2) != self.n_head * self.head_size:
+                raise ValueError(f"q must be [1, Q, {self.n_head * self.head_size}] on {k.device}")
+            self._get_engine(k.device, q.size(1)).ensure_plan(k.size(1) // P)
+            self._sig = sig
         self.device = k.device
-        P, d = self.tokens_per_frame, self.encoder_width
-        if k.size(2) != d or k.size(1) % P:
-            raise ValueError(f"k must be [1, T*{P}, {d}]")
+        P = self.tokens_per_frame
         klen = k.size(1) // P
         self.length = klen
         qlen = q.size(1)
         eng = self._get_engine(k.device, qlen)
         if new_doc or not self.infinite_memory:
             eng.reset()                                   # :300-302 (and the non-infinite branch :310)
-        kf = k[0]
-        if kf.dtype not in (torch.float32, torch.bfloat16):       # bf16 tokens are pooled as they are (engine._tokens)
-            kf = kf.float()
-        if not kf.is_contiguous():
-            kf = kf.contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(k.device).cuda_stream)
         ref = _pool_cache["ref"]
         if ref is not None and ref() is k and _pool_cache["version"] == k._version:
             kbar = _pool_cache["kbar"]
         else:
-            kbar = eng.pool(kf)                           # :304
+            kf = k
+            if kf.dtype not in TOKEN_DTYPES:                      # bf16 tokens are pooled as they are
+                kf = kf.float()
+            if not kf.is_contiguous():
+                kf = kf.contiguous()
+            kbar = torch.empty(klen, self.encoder_width, device=k.device, dtype=torch.float32)
+            with torch.cuda.device(k.device):
+                eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)           # :304
             _pool_cache["ref"], _pool_cache["version"], _pool_cache["kbar"] = weakref.ref(k), k._version, kbar
-        u = None
-        if eng.has_memory and self.sticky_memories:
-            # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
-            u = self._draw_uniforms(k.device)
+        sticky_step = eng.has_memory and self.sticky_memories
+        # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
+        u_addr = self._draw_uniforms(k.device) if sticky_step else 0
         qf = q.detach()
         if qf.dtype != torch.float32 or not qf.is_contiguous():
             qf = qf.float().contiguous()
-        ctx = eng.step(kbar, qf, [self._proj(k.device)], u)           # [1, Q, dm]
+        ctx = torch.empty(1, qlen, self.n_head * self.head_size, device=k.device, dtype=torch.float32)
+        with torch.cuda.device(k.device):
+            eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, eng._proj_array([self._proj(k.device)]), u_addr,
+                         ctx.data_ptr(), stream)
+        if sticky_step:
+            self._uniforms_used(k.device)
         self.count += 1
-        return ctx.to(q.dtype).reshape(1, qlen, -1)
+        return ctx if q.dtype == torch.float32 else ctx.to(q.dtype)
 
 
 class LongTermAttentionVC(LongTermAttention):

@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 from infinite_video_amd import synth
 from infinite_video_amd.long_term_attention_gibbs import LongTermAttention
+if "--u-copy" in sys.argv:
+    LongTermAttention._U_VIA_COPY = True
 
 dev = torch.device("cuda:0")
 wk, bk, wv, bv = synth.layer_projections(0, 768, 768)

@@ -1,15 +1,16 @@
 #!/bin/bash
-export INFV_LTM_LIBRARY=${INFV_LTM_LIBRARY:-exp}   # the INFV_* knobs below only exist in the experiments build (csrc/knobs.h)
 # rocprofv3 passes of the headline bench: kernel-trace stats, then PMC passes (each on its own, as gpurun requires)
 # usage (GPU box): tools/profile_round.sh <tag>    -> gpurun_out/prof_<tag>/ (copy the summaries to profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encode-video --no-secondary > $out/bench_trace.json 2> $out/trace.err
-export INFV_SUB_BATCH=42   # the PMC passes run a 252-chunk video: force the 42-chunk launches of the full-length run (6 full launches)
+# (the kernel-trace pass above runs the SHIPPED library with nothing set; the PMC passes run a 252-chunk video and force the
+# 42-chunk launches of the full-length run -- 6 full launches -- through a knob that only the experiments build reads)
+export INFV_LTM_LIBRARY=exp INFV_SUB_BATCH=42
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_fetch.json 2> $out/fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_write.json 2> $out/write.err
-unset INFV_SUB_BATCH
+unset INFV_SUB_BATCH INFV_LTM_LIBRARY
 python3 - <<PY
 import csv,glob,collections,json
 out="$out"
