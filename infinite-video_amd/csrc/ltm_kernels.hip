@@ -175,6 +175,24 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
                 hipLaunchKernelGGL((pool_frames_kernel<4, 1024, Tok>), dim3(g16), dim3(1024), lds_pad, stream, k, kbar, n_units, P, d4, slices);
             return hipGetLastError();
         }
+        // INFV_POOL_NT=256: four-wave workgroups (one wave per SIMD, <= 72 registers): small enough to sit beside a role-S
+        // workgroup (432 of 512 registers per SIMD), which then no longer needs an EMPTY CU at its launches
+        static const int nt256 = [] { const char* e = exp_env("INFV_POOL_NT"); return e && atoi(e) == 256; }();
+        if (nt256) {
+            static bool attr_256 = false;
+            if (!attr_256) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_256 = true;
+            }
+            const unsigned g4 = (unsigned)((n_units + 3) / 4);
+            if (unroll <= 4) hipLaunchKernelGGL((pool_frames_kernel<4, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            else if (unroll <= 8) hipLaunchKernelGGL((pool_frames_kernel<8, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            else hipLaunchKernelGGL((pool_frames_kernel<16, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+            return hipGetLastError();
+        }
         unsigned grid = (unsigned)((n_units + 7) / 8);
         if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
         // INFV_POOL_DB=<U>: the rolling double-buffered form with U loads per group (U | P)
