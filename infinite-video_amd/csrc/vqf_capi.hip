@@ -127,7 +127,8 @@ static int prepare_split(infv_vqf_s* h, const float* frames, int nb, int n_token
 
 int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, const float* xq, bool shared_q,
                     const infv_linear* key, const infv_linear* value, const float* along, float* merged,
-                    hipStream_t stream, bool use_cache = false, const SplitRef* pre = nullptr) {
+                    hipStream_t stream, bool use_cache = false, const SplitRef* pre = nullptr,
+                    hipEvent_t along_ready = nullptr /* `along` is produced on another stream: wait here, before the merge */) {
     const infv_vqf_config& c = h->cfg;
     const int Q = c.n_query, H = c.n_heads, d = c.enc_width, rows = H * Q;
     if (n_tokens < 32 || n_tokens % 32) return fail(INFV_ERR_INVALID, "n_tokens must be a positive multiple of 32");
@@ -230,6 +231,7 @@ int short_attention(infv_vqf_s* h, const float* frames, int nb, int n_tokens, co
     e.scale = along ? c.alpha : 1.f; e.res_scale = (float)(1.0 - (double)c.alpha);
     e.residual = along; e.ld_res = hidden; e.res_rows = M2;
     e.out = merged; e.ld_out = hidden; e.M = M2; e.width = hidden; e.eps = c.ln_eps;
+    if (along_ready) HIP_TRY(hipStreamWaitEvent(stream, along_ready, 0));
     HIP_TRY(launch_qf_epilogue(e, stream));
     return INFV_OK;
 }
@@ -312,6 +314,8 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     if (T < 1) return fail(INFV_ERR_INVALID, "T must be >= 1");
     if (llama_out && (c.proj_out <= 0 || !w->llama_proj.w)) return fail(INFV_ERR_INVALID, "llama_out without llama_proj");
     const int Q = c.n_query, Hd = c.hidden, n_tokens = T * c.tokens_per_frame;
+    if (use_ltm)
+        if (int rc = ensure_streams(h)) return rc;
 
     // The prefix of layer 0 (embedding LayerNorm -> self-attention block -> cross query) depends on the weights only,
     // not on the chunk: with a non-zero weights epoch it is computed once and reused until the epoch changes.
@@ -374,16 +378,24 @@ int infv_vqf_encode_chunk(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
             if (l0c) { h->c_valid = true; h->c_epoch = h->epoch; }
         }
         const float* along = nullptr;
+        hipEvent_t along_ready = nullptr;
         if (use_ltm) {
+            // The memory step and the short-term attention both start from the cross query and meet only in the merge
+            // (Qformer.py:216-223 vs :225-302, :303-304): the step's three launches go to the shared worker stream and run
+            // beside the attention's contractions; the merge epilogue waits for them.
             infv_ltm_proj pr{};
             pr.wk = L.x_k.w; pr.bk = L.x_k.b; pr.wv = L.x_v.w; pr.bv = L.x_v.b;
             const double* ul = u ? u + (size_t)l * c.nb_samples : nullptr;
+            HIP_TRY(hipEventRecord(h->ev_main, stream));              // cross query, pooled frames, the previous layer's merge
+            HIP_TRY(hipStreamWaitEvent(h->side, h->ev_main, 0));
             if (int rc = infv_ltm_step(ltm[l], h->kbar.as<float>(), T, xqb, Q, &pr, ul,
-                                       h->along.as<float>(), stream_)) return rc;
+                                       h->along.as<float>(), h->side)) return rc;
+            HIP_TRY(hipEventRecord(h->ev_side, h->side));
             along = h->along.as<float>();
+            along_ready = h->ev_side;
         }
         if (int rc = short_attention(h, frames, 1, n_tokens, xqb, false, &L.x_k, &L.x_v, along,
-                                     h->merged.as<float>(), stream, l0c, pre)) return rc;
+                                     h->merged.as<float>(), stream, l0c, pre, along_ready)) return rc;
         LinearCall xo{h->merged.as<float>(), Q, Hd, {&L.x_o}, 1, Hd};
         xo.residual = h1; xo.res_rows = Q; xo.ln = &L.x_ln; xo.y = h->h2.as<float>();
         if (int rc = run_linear(h, xo, stream)) return rc;
