@@ -179,6 +179,31 @@ class Plan:
     uniform_box2: np.ndarray = None   # [S, 2]
 
 
+def gaussian_operator_T(l: int, positions: torch.Tensor, N: int, sigmas) -> np.ndarray:
+    """G^T [N, l] of compute_G (long_term_attention_gibbs.py:68-84) for the GAUSSIAN basis family of the reference
+    (``add_gaussian_basis_functions``, :167-174: centres ``linspace(0, 1, N // len(sigmas))`` x widths ``sigmas``;
+    ``GaussianBasisFunctions.evaluate``, basis_functions.py:135-160), with the reference's own fp32 ATen sequence.  No caller of
+    the active module reaches this family; it exists here so that the dense ``x . G`` kernel is pinned on a second, fully
+    dense operator (operator-level goldens: tests/golden/make_gaussian_goldens.py)."""
+    import math
+    mu, sigma = torch.meshgrid(torch.linspace(0, 1, N // len(sigmas)), torch.Tensor(list(sigmas)), indexing="ij")
+    mu, sigma = mu.flatten().unsqueeze(0), sigma.flatten().unsqueeze(0)
+    if mu.size(1) != N:
+        raise UnsupportedBasis("num_basis must be a multiple of len(sigmas)")
+    t = positions.unsqueeze(1)
+    z = (t - mu) / sigma
+    psi = (1. / math.sqrt(2 * math.pi) * torch.exp(-.5 * z ** 2)) / sigma         # evaluate(): [l', N]
+    F = torch.zeros(N, positions.size(0))
+    F[:, :] = psi.t()
+    G = F.t().matmul((F.matmul(F.t()) + RIDGE_PENALTY * torch.eye(N)).inverse())
+    b, e = _trimmed(G.size(0), l)
+    return np.ascontiguousarray(G[b:e].t().numpy(), dtype=np.float32)
+
+
+def gaussian_first_operator_T(T: int, N: int, sigmas) -> np.ndarray:
+    return gaussian_operator_T(T, _positions_first(T), N, sigmas)
+
+
 def _first_box(pairs: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(pairs[:, 0], dtype=np.int32)
 

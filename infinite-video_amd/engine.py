@@ -118,6 +118,30 @@ class LTMEngine:
         self._plans[T] = p
         return p
 
+    def set_dense_operators(self, T: int, first_GT: np.ndarray, inf_GT: Optional[np.ndarray] = None):
+        """Replace the operators of chunk length ``T`` by caller-supplied DENSE ones (``first_GT`` [N, T], ``inf_GT`` [N, S + T],
+        transposed ``G`` of long_term_attention_gibbs.py:68-84): every step of that length then runs the dense kernels
+        (``B = x . G`` on fp32 MFMA).  The resampling / histogram tables stay those of the rectangular basis -- this is the
+        operator-level hook for another basis family (e.g. ``basis_maps.gaussian_first_operator_T``), not a second model."""
+        from .basis_maps import NB_BINS as _NB, boxes2_of
+        self.ensure_plan(T)
+        first = _np_f32(first_GT)
+        inf = _np_f32(inf_GT) if inf_GT is not None else np.zeros((self.N, self.S + T), np.float32)
+        if first.shape != (self.N, T) or inf.shape != (self.N, self.S + T):
+            raise ValueError(f"operators must be [{self.N}, {T}] and [{self.N}, {self.S + T}]")
+        bins = torch.linspace(0, 1, _NB + 1)
+        mod = bins.clone()
+        mod[0] = -.000001
+        mod[-1] = 1.000001
+        t_uni = (torch.arange(1, self.S + 1).float() * self.tau / self.S) / self.tau
+        tabs = [_np_i32(boxes2_of(x, self.N)) for x in (bins[:-1], mod, t_uni)]
+        ds = _lib.DensePlanStruct(
+            T=int(T), first_K=int(T), first_GT=first.ctypes.data_as(_lib.f32p), inf_K=int(self.S + T),
+            inf_GT=inf.ctypes.data_as(_lib.f32p), bin_box2=tabs[0].ctypes.data_as(_lib.i32p),
+            edge_box2=tabs[1].ctypes.data_as(_lib.i32p), uniform_box2=tabs[2].ctypes.data_as(_lib.i32p))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_set_dense_plan(self._h, C.byref(ds)))
+
     # ------------------------------------------------------------------ helpers
     def _proj_array(self, projs: Sequence[ProjTensors]):
         if len(projs) != self.L:

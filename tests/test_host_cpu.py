@@ -132,6 +132,17 @@ def test_dense_plan_matches_reference_operators(case):
             assert sorted(np.flatnonzero(smp[s_]).tolist()) == sorted(x for x in (int(a), int(b)) if x >= 0)
 
 
+def test_gaussian_operator_matches_the_reference_family():
+    """Second basis family at operator level: ``compute_G`` of the reference with its own ``GaussianBasisFunctions`` (the golden
+    comes from the real module with its builder hook pointed at ``add_gaussian_basis_functions``,
+    tests/golden/make_gaussian_goldens.py) -- a fully dense ridge operator."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gauss_operator.npz"))
+    GT = basis_maps.gaussian_first_operator_T(int(g["T"]), int(g["N"]), [float(x) for x in g["sigmas"]])
+    assert GT.shape == (int(g["N"]), int(g["T"]))
+    assert float((g["G_first"] != 0).mean()) > 0.9                       # dense, unlike the box operators
+    np.testing.assert_allclose(GT.T, g["G_first"], rtol=0, atol=1e-4 * float(np.abs(g["G_first"]).max()))   # LAPACK-dependent
+
+
 def test_every_multiple_of_16_has_a_plan_and_sparse_ones_stay_sparse():
     """``UnsupportedBasis`` is gone for the multiples of 16 the kernels accept (N <= 256); values whose boxes partition
     the samples keep the sparse closed form."""

@@ -119,6 +119,32 @@ def test_dense_operator_chain_matches_the_reference(dev, case):
         assert torch.equal(whole, torch.stack(outs))
 
 
+def test_dense_update_with_the_gaussian_family_operator(dev):
+    """Operator level, second basis family: the dense ``x . G`` kernel (fp32 MFMA) with the reference's GAUSSIAN ridge operator
+    (every entry non-zero) reproduces the coefficients the REAL reference computes for a first chunk
+    (``value_function(kbar)`` with ``GaussianBasisFunctions``; golden from tests/golden/make_gaussian_goldens.py).  Only ``B`` is
+    compared: the rest of the step keeps the rectangular family's read-out, which no Gaussian caller exists to pin."""
+    import os
+    from infinite_video_amd import basis_maps, synth
+    from infinite_video_amd.engine import LTMEngine
+    from tests.golden.cases import GOLDEN_DIR, Case
+    g = np.load(os.path.join(GOLDEN_DIR, "gauss_operator.npz"))
+    T, N = int(g["T"]), int(g["N"])
+    case = Case("gauss_operator", N=N, chunk_T=[T], seed_base=9000, n_layers=1)
+    eng = LTMEngine(N, case.H, case.dh, case.d, case.P, tau=case.tau, sticky=True, n_layers=1, max_q=case.Q, device=dev)
+    # (the host builder basis_maps.gaussian_first_operator_T is pinned to this G in tests/test_host_cpu.py; the inverse of the
+    # ill-conditioned Gaussian Gram matrix depends on the host's LAPACK in the 5th digit, so the device test takes the golden G)
+    eng.set_dense_operators(T, g["G_first"].T.copy())                       # the reference's own G
+    k = synth.frame_tokens(0, T, case.P, case.d, seed=synth.SEED_K + case.seed_base)
+    q = synth.layer_query(0, case.Q, case.dm, seed=synth.SEED_Q + case.seed_base)
+    w = synth.layer_projections(0, case.d, case.dm, seed=synth.SEED_W + case.seed_base)
+    projs = [tuple(_to(dev, *w))]
+    eng.forward(torch.from_numpy(k).to(dev), torch.from_numpy(q[None]).to(dev), projs, None, new_doc=True)
+    B = eng.export_state(0)[0].cpu().numpy()
+    np.testing.assert_allclose(B, g["B"], rtol=0, atol=2e-6)
+    assert float(np.abs(g["B"]).max()) > 1e-2
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c.sticky], ids=lambda c: c.name)
 def test_gibbs_draw_bit_exact_when_teacher_forced(dev, case):
     """Given the oracle's probabilities, the drawn bins must equal torch.multinomial's exactly."""
