@@ -204,8 +204,7 @@ int check_chain_error(infv_ltm_handle h) {
         h->has_memory = false; h->parts = 0; h->k_stale = false;
         return fail(INFV_ERR_STATE, "the persistent chain kernel of an earlier infv_ltm_consolidate timed out waiting for the "
                                     "other workgroups of its layer (not all co-resident: partitioned or shared GPU?); "
-                                    "its outputs and the memory are invalid, the memory has been reset "
-                                    "(INFV_PERSISTENT=0 selects one launch per chunk)");
+                                    "its outputs and the memory are invalid, the memory has been reset");
     }
     return INFV_OK;
 }
@@ -949,9 +948,10 @@ int shared_streams(int dev, SharedStreams** out) {
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent
         // INFV_PRIO_UCS / _POOL / _SIDE (experiments): -1 most urgent, 0 normal, 1 least urgent
         auto prio = [&](const char* name, int dflt) { const char* e = exp_env(name); int v = e ? atoi(e) : dflt; return v < hi ? hi : (v > lo ? lo : v); };
-        HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio("INFV_PRIO_UCS", 0)));
-        HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio("INFV_PRIO_POOL", lo)));
-        HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio("INFV_PRIO_SIDE", lo)));   // last: marks the set complete
+        const int prio_ucs = prio("INFV_PRIO_UCS", 0), prio_pool = prio("INFV_PRIO_POOL", lo), prio_side = prio("INFV_PRIO_SIDE", lo);
+        HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio_ucs));
+        HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio_pool));
+        HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio_side));   // last: marks the set complete
     }
     *out = &p;
     return INFV_OK;

@@ -94,6 +94,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.infv_vqf_create(ctypes.byref(vcfg), ctypes.byref(h)) == -2
 
 
+def test_shipped_library_reads_only_the_documented_environment_options():
+    """Experiment / A-B / fault-injection knobs go through ``exp_env`` (csrc/knobs.h): a constant nullptr in the shipped build, so
+    their names are not even in the binary; the experiments build has them."""
+    import subprocess
+    def knobs(path):
+        out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout.split("\n")
+        return {w for line in out for w in re.findall(r"INFV_[A-Z0-9_]+", line)}
+    documented = {"INFV_VPROJ_SPLIT", "INFV_VQF_FP32", "INFV_VQF_FUSE", "INFV_VQF_SPLIT_CACHE_GB"}
+    shipped = knobs(_lib.LIB_PATH if "exp" not in os.path.basename(_lib.LIB_PATH) else os.path.join(os.path.dirname(_lib.LIB_PATH), "libinfv_ltm.so"))
+    assert shipped == documented, sorted(shipped - documented)
+    exp = knobs(os.path.join(os.path.dirname(_lib.LIB_PATH), "libinfv_ltm_exp.so"))
+    assert documented < exp and {"INFV_SKIP", "INFV_CHAIN_FAULT", "INFV_POOL_ROWS"} <= exp
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "infinite-video_amd")
     for dirpath, _, files in os.walk(pkg):
