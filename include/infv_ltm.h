@@ -154,6 +154,14 @@ int infv_ltm_set_token_dtype(infv_ltm_handle h, int32_t dtype);
 /* Frame mean-pool, long_term_attention_gibbs.py:304:  k [n_frames, P, d] -> kbar [n_frames, d] (fp32). */
 int infv_ltm_pool(infv_ltm_handle h, const void* k, int64_t n_frames, float* kbar, void* stream);
 
+/* Frame mean-pool and the memory's new rows in one pass (what infv_ltm_consolidate runs per sub-batch): for each of
+ * n_chunks chunks of T frames, R[c][r] = sum over the frames f of box row r of val_r * mean_P(k[c][f]) -- the rows
+ * `G_inf^T`'s new-signal half contributes in update_inf (long_term_attention_gibbs.py:216 applied to the means of :304);
+ * k [n_chunks, T*P, d], R [n_chunks, rows, d] fp32 with rows = infv_ltm_new_rows(h, T).  Same bits as infv_ltm_pool
+ * followed by the per-row sums of infv_ltm_step.  Needs infv_ltm_set_plan(T) (sparse plans only). */
+int infv_ltm_pool_rows(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T, float* R, void* stream);
+int infv_ltm_new_rows(infv_ltm_handle h, int32_t T);           /* rows per chunk of the plan for T, or a negative error */
+
 /* One consolidation step of all n_layers instances on one chunk, from pooled frames:
  * update_inf + proj_key/proj_value + expected_value (long_term_attention_gibbs.py:194-222,
  * 312-318).  kbar [T,d]; q [L,Q,dm]; proj[L]; u [L,S] float64 Gibbs uniforms (device;

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "infv_ltm_has_memory": (C.c_int, [C.c_void_p]),
     "infv_ltm_set_token_dtype": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "infv_ltm_pool_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_new_rows": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),
     "infv_ltm_steps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

@@ -563,6 +563,34 @@ int infv_ltm_pool(infv_ltm_handle h, const void* k, int64_t n_frames, float* kba
     return INFV_OK;
 }
 
+int infv_ltm_new_rows(infv_ltm_handle h, int32_t T) {
+    if (int rc = check_handle(h)) return rc;
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, T, &plan)) return rc;
+    if (plan->dense.on) return fail(INFV_ERR_UNSUPPORTED, "new_rows: the plan for T = %d is dense (no box rows)", T);
+    return plan->inf.rows;
+}
+
+int infv_ltm_pool_rows(infv_ltm_handle h, const void* k, int32_t n_chunks, int32_t T, float* R, void* stream_) {
+    if (int rc = check_handle(h)) return rc;
+    if (!k || !R || n_chunks < 0) return fail(INFV_ERR_INVALID, "pool_rows: bad arguments");
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, T, &plan)) return rc;
+    if (plan->dense.on) return fail(INFV_ERR_UNSUPPORTED, "pool_rows: the plan for T = %d is dense (no box rows)", T);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Timed t_(h->prof, INFV_KERNEL_POOL, stream);
+    if (pool_rows2_supported(h->d)) {
+        HIP_TRY(launch_pool_rows2(k, h->k_bf16, n_chunks, T, h->P, h->d, plan->inf.view(), R, stream, 8, 84 * 1024, 0));
+        return INFV_OK;
+    }
+    // widths without a pool_rows2 shape: the two kernels, one chunk group at a time through the pooled-frame workspace
+    const size_t need = (size_t)n_chunks * T * h->d * sizeof(float);
+    if (need > h->kbar_side[0].bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->kbar_side[0].reserve(need)); }
+    HIP_TRY(launch_pool(k, h->k_bf16, h->kbar_side[0].as<float>(), (int64_t)n_chunks * T, h->P, h->d, stream));
+    HIP_TRY(launch_rows(h->kbar_side[0].as<float>(), n_chunks, T, h->d, plan->inf.view(), R, stream));
+    return INFV_OK;
+}
+
 int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* q, int32_t Q,
                   const infv_ltm_proj* proj, const double* u, float* ctx, void* stream_) {
     if (int rc = check_handle(h)) return rc;
@@ -1129,14 +1157,18 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     hipStream_t pools = split_pool ? h->pools : side;
     bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
     bool r_pending[kRSets] = {};                              // ev_r[rset] has been recorded in this call
-    // Pool + rows in one kernel (INFV_POOL_ROWS=1, off by default): the pooling stream writes the sub-batch's new rows R
-    // straight from the tokens -- in this path the frame means are consumed by the rows kernel only (see pool_rows_kernel);
-    // same bits.  Measured in situ (round 3, tools/sweep_r03*.sh): the fused kernel streams faster (218-270 us per 42-chunk
-    // launch against 304) but its longer-lived workgroups cost the chain launches their CUs -- chain 13.5-15.7 ms per video
-    // against 12.6 -- and the call ends up slower (116-121 k against 130 k chunks/s); the two-kernel form stays the default.
-    static const bool pr_env = [] { const char* e = exp_env("INFV_POOL_ROWS"); return e && atoi(e) != 0; }();
-    const bool use_pr = pr_env && !kbar_pre && pool_rows_supported(h->P, h->d);
-    static const int pr_u = [] { const char* e = exp_env("INFV_PR_U"); return e ? atoi(e) : 4; }();
+    // Pool + rows in one kernel: the pooling stream writes the sub-batch's new rows R straight from the tokens -- in this path
+    // the frame means are consumed by the rows kernel only; same bits either way.  Default: pool_rows2_kernel (one short-lived
+    // workgroup per (chunk, row), a wave per frame and slice): no kbar round trip through HBM, no rows kernel on the side
+    // stream, and the pooling stream runs up to kRSets sub-batches ahead instead of three.  Measured in situ (round 3,
+    // tools/sweep_r03s.sh, alternating on one box): 132.5 k against 130.5 k chunks/s, pooling stream 14.65 against 15.05 ms.
+    // The experiments build keeps INFV_POOL_ROWS=0 (pool_frames_kernel + build_rows_kernel, the round-2 form, still used when
+    // frame means are handed in or the width has no pool_rows2 shape) and =1 (pool_rows_kernel: long-lived grid-stride
+    // workgroups stream faster alone, 218-270 us per launch against 304, but cost the chain launches their CUs: 116-121 k).
+    static const int pr_env = [] { const char* e = exp_env("INFV_POOL_ROWS"); return e ? atoi(e) : 2; }();
+    const bool use_pr2 = pr_env == 2 && !kbar_pre && pool_rows2_supported(h->d);
+    const bool use_pr = (pr_env == 1 && !kbar_pre && pool_rows_supported(h->P, h->d)) || use_pr2;
+    static const int pr_u = [] { const char* e = exp_env("INFV_PR_U"); return e ? atoi(e) : 8; }();
     static const int pr_nt = [] { const char* e = exp_env("INFV_PR_NT"); return e ? atoi(e) : 512; }();
     static const int pr_pad = [] { const char* e = exp_env("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
     static const int pr_wgs = [] { const char* e = exp_env("INFV_PR_WGS"); return e ? atoi(e) : 0; }();
@@ -1165,8 +1197,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
             if (!(skip_mask() & 1)) {
                 Timed t_(h->prof, INFV_KERNEL_POOL, pools);
-                HIP_TRY(launch_pool_rows(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
-                                         pools, pr_u, pr_nt, pr_pad, pr_wgs));
+                if (use_pr2)
+                    HIP_TRY(launch_pool_rows2(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
+                                              pools, pr_u, pr_pad, pr_wgs));
+                else
+                    HIP_TRY(launch_pool_rows(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
+                                             pools, pr_u, pr_nt, pr_pad, pr_wgs));
             }
             if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
             return INFV_OK;

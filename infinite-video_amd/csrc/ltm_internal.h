@@ -61,6 +61,10 @@ hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames,
 bool pool_rows_supported(int P, int d);
 hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
                             hipStream_t stream, int u, int nt, int lds_pad, int max_wgs = 0);
+// the same with short-lived workgroups: one workgroup per (chunk, row), a wave per (frame of the row, 256-float slice)
+bool pool_rows2_supported(int d);
+hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                             hipStream_t stream, int u, int lds_pad, int max_wgs = 0);
 int project_splitk(int M, int K);
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream);

@@ -319,7 +319,96 @@ __global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 2c. pool + rows with SHORT-LIVED workgroups: one workgroup per (chunk, row); wave (fi, slice) pools frame fb + fi of the row for
+//     one 256-float slice exactly as pool_frames_kernel does (32 loads of 1 KiB, U per burst), parks the frame mean in LDS, and the
+//     fi = 0 waves run build_rows_kernel's fma chain over the row's frames in order -- same bits as the two kernels, no kbar round
+//     trip through HBM, no rows kernel, and a workgroup lives as long as one of pool_frames_kernel's (a frame's worth of loads per
+//     wave), which is what lets role S find empty CUs at its launches (pool_rows_kernel's workgroups live four times longer).
+// ------------------------------------------------------------------------------------------------------
+template <int U, class Tok>
+__global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict__ k_, long chunk_stride, int P, int d4, int slices,
+                                                          OperatorView op, long n_rows_total, float* __restrict__ R) {
+    typedef typename Tok::vec tvec;
+    extern __shared__ __attribute__((aligned(16))) float pr2_lds[];          // [4 frames][d4] float4
+    floatx4* park = reinterpret_cast<floatx4*>(pr2_lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = wave / slices, sl = wave - fi * slices;
+    const int c4 = sl * 64 + lane;
+    const bool col_ok = c4 < d4;
+    const float fp = (float)P;
+    for (long rr = blockIdx.x; rr < n_rows_total; rr += gridDim.x) {
+        const long c = rr / op.rows;
+        const int r = (int)(rr - c * op.rows);
+        const int fb = op.row_begin[r], fe = op.row_end[r];
+        const float val = op.box_val[op.row_box[r]];
+        floatx4 racc = {0.f, 0.f, 0.f, 0.f};
+        for (int f0 = fb; f0 < fe; f0 += 4) {
+            const int f = f0 + fi;
+            if (f < fe && col_ok) {
+                const tvec* src = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)f * P * d4 + c4;
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                int p = 0;
+                for (; p + U <= P; p += U) {
+                    tvec v[U];
+#pragma unroll
+                    for (int i = 0; i < U; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
+#pragma unroll
+                    for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
+                }
+                for (; p < P; ++p) acc += Tok::widen(__builtin_nontemporal_load(src + (long)p * d4));
+                acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;              // mean = sum / P, as torch does (LTM.py:304)
+                park[fi * d4 + c4] = acc;
+            }
+            __syncthreads();
+            if (fi == 0 && col_ok) {
+                const int nf = min(4, fe - f0);
+                for (int j = 0; j < nf; ++j) {
+                    const floatx4 v = park[j * d4 + c4];
+                    racc.x = fmaf(val, v.x, racc.x); racc.y = fmaf(val, v.y, racc.y);
+                    racc.z = fmaf(val, v.z, racc.z); racc.w = fmaf(val, v.w, racc.w);
+                }
+            }
+            __syncthreads();
+        }
+        if (fi == 0 && col_ok) __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + rr * (long)d4 + c4);
+    }
+}
+
+template <class Tok>
+static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                                      hipStream_t stream, int u, int lds_pad, int max_wgs) {
+    const int d4 = d / 4, slices = (d4 + 63) / 64;
+    if (4 * slices * 64 > 1024) return hipErrorInvalidValue;
+    const long n_rows_total = (long)n_chunks * op.rows;
+    size_t lds = (size_t)4 * d4 * sizeof(floatx4);
+    if ((size_t)lds_pad > lds) lds = lds_pad;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<2, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    unsigned grid = (unsigned)n_rows_total;
+    if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
+    const dim3 block(4 * slices * 64);
+    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
+    else if (u >= 4) hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
+    else hipLaunchKernelGGL((pool_rows2_kernel<2, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
+                             hipStream_t stream, int u, int lds_pad, int max_wgs) {
+    if (op.rows == 0 || n_chunks == 0) return hipSuccess;
+    return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs)
+                  : launch_pool_rows2_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs);
+}
+
 bool pool_rows_supported(int P, int d) { return P % 4 == 0 && d % 4 == 0; }
+bool pool_rows2_supported(int d) { return d % 4 == 0 && ((d / 4 + 63) / 64) * 4 * 64 <= 1024; }
 
 template <int U, int NT, class Tok>
 static hipError_t launch_pool_rows_v(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,

@@ -208,6 +208,20 @@ class LTMEngine:
             _lib.check(self.lib.infv_ltm_pool(self._h, _ptr(k), n_frames, _ptr(out), _stream(self.device)))
         return out
 
+    def pool_rows(self, k: torch.Tensor) -> torch.Tensor:
+        """k [C, T*P, d] (fp32 or bf16) -> the memory's new rows R [C, rows, d] fp32: frame means (reference :304) summed
+        per box row with the operator's weights (reference :216), one pass over the tokens.  Sparse plans only."""
+        self._tokens(k)
+        if k.dim() != 3 or k.shape[-1] != self.d or k.shape[-2] % self.P:
+            raise ValueError(f"k must be [C, T*{self.P}, {self.d}], got {tuple(k.shape)}")
+        n_chunks, T = int(k.shape[0]), int(k.shape[1]) // self.P
+        self.ensure_plan(T)
+        rows = _lib.check(self.lib.infv_ltm_new_rows(self._h, T))
+        out = torch.empty(n_chunks, rows, self.d, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.infv_ltm_pool_rows(self._h, _ptr(k), n_chunks, T, _ptr(out), _stream(self.device)))
+        return out
+
     def step(self, kbar: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
              u: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One chunk from pooled frames kbar [T, d]; q [L, Q, dm]; u [L, S] f64 -> ctx [L, Q, dm]."""

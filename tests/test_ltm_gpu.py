@@ -50,6 +50,33 @@ def test_pool_matches_oracle(dev, P, d, T):
     np.testing.assert_allclose(out, O.ClosedFormOracle.pool(k, P), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("N,P,d,T,C", [(256, 32, 768, 256, 5), (64, 32, 768, 8, 3), (64, 196, 1024, 16, 2), (256, 32, 768, 64, 4),
+                                       (64, 30, 1280, 8, 2)])
+def test_pool_rows_matches_oracle_operator_on_pooled_frames(dev, N, P, d, T, C):
+    """infv_ltm_pool_rows (what the whole-video path runs per sub-batch): row r of chunk c = the oracle's update operator
+    (LTM.py:216, new-signal half) applied to the oracle's frame means (LTM.py:304).  Widths without a one-pass shape
+    (d = 1280) go through the two kernels behind the same entry point."""
+    from infinite_video_amd.basis_maps import build_plan
+    from infinite_video_amd.engine import LTMEngine
+    eng = LTMEngine(N, 12, 64, d, P, tau=.75, sticky=True, device=dev)
+    k = np.random.default_rng(T + C).standard_normal((C, T * P, d), dtype=np.float32)
+    R = eng.pool_rows(torch.from_numpy(k).to(dev)).cpu().numpy()
+    plan = build_plan(T, N, .75, O.NB_SAMPLES)
+    mp = O.build_maps(T, N, .75, O.NB_SAMPLES)
+    assert R.shape == (C, len(plan.inf_row_box), d)
+    col, val = mp.inf_col[O.NB_SAMPLES:], mp.inf_val[O.NB_SAMPLES:]
+    for c in range(C):
+        kbar = O.ClosedFormOracle.pool(k[c], P)
+        want = np.zeros((N, d), np.float32)
+        keep = col >= 0
+        np.add.at(want, col[keep], val[keep, None] * kbar[keep])
+        np.testing.assert_allclose(R[c], want[plan.inf_row_box], rtol=0, atol=2e-6)
+    # and the frame means themselves, through the two-kernel entry point, give the same rows
+    kb = eng.pool(torch.from_numpy(k).to(dev)).cpu().numpy()
+    for r, (b, fb, fe) in enumerate(zip(plan.inf_row_box, plan.inf_row_begin, plan.inf_row_end)):
+        np.testing.assert_allclose(R[:, r], plan.inf_box_val[b] * kb[:, fb:fe].sum(1), rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_chain_free_running_matches_oracle_and_reference(dev, case):
     """Per-chunk forward() of all layers; the GPU derives its own sticky probabilities."""

@@ -275,7 +275,9 @@ np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bi
 # non-default variants kept in the sources (A/B material, experiments build only): each must reproduce the shipped default
 _VARIANTS = [
     {},                                                        # the experiments build with no knob set
-    {"INFV_POOL_ROWS": "1"},                                   # fused pool + rows kernel (R straight from the tokens)
+    {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
+    {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
+    {"INFV_POOL_ROWS": "1"},                                   # long-lived fused pool + rows kernel
     {"INFV_POOL_ROWS": "1", "INFV_PR_NT": "256", "INFV_PR_U": "8", "INFV_PR_WGS": "300"},   # ... grid-stride, 4-wave workgroups
     {"INFV_POOL_DB": "2"},                                     # rolling double-buffered pooling kernel
     {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
