@@ -580,7 +580,9 @@ int infv_ltm_pool_rows(infv_ltm_handle h, const void* k, int32_t n_chunks, int32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Timed t_(h->prof, INFV_KERNEL_POOL, stream);
     if (pool_rows2_supported(h->d)) {
-        HIP_TRY(launch_pool_rows2(k, h->k_bf16, n_chunks, T, h->P, h->d, plan->inf.view(), R, stream, 8, 84 * 1024, 0));
+        static const int wgs = [] { const char* e = exp_env("INFV_PR_WGS"); return e ? atoi(e) : 0; }();      // (tools/pool_cus.py)
+        static const int pad = [] { const char* e = exp_env("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
+        HIP_TRY(launch_pool_rows2(k, h->k_bf16, n_chunks, T, h->P, h->d, plan->inf.view(), R, stream, 8, pad, wgs));
         return INFV_OK;
     }
     // widths without a pool_rows2 shape: the two kernels, one chunk group at a time through the pooled-frame workspace

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     constexpr int PPR = TR / 4;                                        // float4 pieces per new row of the S'new tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!(a.exp_flags & 1)) __builtin_amdgcn_s_setprio(3);
+    wg_stamp_begin(a.wg_stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
     const int rows = a.op.rows, tabw = a.op.tabw;
@@ -732,6 +733,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             a.Sp_out[(tile + row) * N + n1] = scc[j * kBRows * kScPitch + lane + 64];
         }
     }
+    wg_stamp_end(a.wg_stamps);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -751,6 +753,12 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
     const int i = blockIdx.x, lh = blockIdx.y, l = lh / H;
     const int snp = kA2Q + 1;
+    wg_stamp_begin(a.wg_stamps);
+#ifdef INFV_EXPERIMENTS
+    if (a.prio == 3) __builtin_amdgcn_s_setprio(3);          // (experiment INFV_ALPHA_PRIO)
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     int32_t* tabb = reinterpret_cast<int32_t*>(lds);                       // [N * tabw]
     float* prev = lds + ((N * tabw + 3) & ~3);                             // [kA2Q][kScPitch]
     float* snew = prev + kA2Q * kScPitch;                                  // [rows][kA2Q + 1]
@@ -835,11 +843,16 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
             if (lane == 0) a.asum_ring[slot * a.asum_slot + row0 + qq] = esum * inv;
         }
     }
+    wg_stamp_end(a.wg_stamps);
 }
 
-hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream) {
-    if (a.n_steps <= 0) return hipSuccess;
-    if (a.N > 256 || (a.N * a.tabw) % 4) return hipErrorInvalidValue;
+hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
+    if (a_.n_steps <= 0) return hipSuccess;
+    if (a_.N > 256 || (a_.N * a_.tabw) % 4) return hipErrorInvalidValue;
+    AlphaRows2Args a = a_;
+    a.wg_stamps = exp_stamps_reserve(WG_ALPHA, (long)a.n_steps * a.L * a.H);
+    static const int prio = [] { const char* e = exp_env("INFV_ALPHA_PRIO"); return e ? atoi(e) : 0; }();
+    a.prio = prio;
     const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + a.rows * (kA2Q + 1)) * sizeof(float);
     hipLaunchKernelGGL(alpha_rows2_kernel, dim3(a.n_steps, a.L * a.H), dim3(kA2NT), lds, stream, a);
     return hipGetLastError();
@@ -985,10 +998,12 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
         a.QS = (a.Q + kBRows * rpw - 1) / (kBRows * rpw);             // tiles of 8 * rpw query rows
         const int blocks = a.H * a.QS * a.L;
         const size_t lds = chain_batch2_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
+        a.wg_stamps = exp_stamps_reserve(WG_CHAIN, blocks);
         if (rpw == 2) hipLaunchKernelGGL(chain_batch2_kernel<2>, dim3(blocks), dim3(kBNT), lds, stream, a);
         else hipLaunchKernelGGL(chain_batch2_kernel<1>, dim3(blocks), dim3(kBNT), lds, stream, a);
         return hipGetLastError();
     }
+    a.wg_stamps = nullptr;
     hipLaunchKernelGGL(chain_batch_kernel, dim3(a.H * a.QS * a.L), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
                        stream, a);
     return hipGetLastError();

@@ -2,6 +2,7 @@
 // whole-video chain kernel (ltm_chain.hip).  All assume 256-thread workgroups (4 waves of 64).
 #pragma once
 #include "ltm_internal.h"
+#include "wg_stamps.h"
 
 namespace infv {
 

@@ -167,6 +167,7 @@ struct ChainBatchArgs {
     const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // [n_steps][rows] rows of pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
     const float* cq; const float* w; float w_out;
     long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
+    long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
 };
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
 bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);
@@ -183,6 +184,8 @@ struct AlphaRows2Args {
     const float* box_val; const int32_t* box_row;
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     float* Sp_out;                  // full bias-free score rows of the LAST step [L][H][Q][N], or nullptr
+    long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
+    int prio;                       // experiments build: s_setprio level of the kernel's waves (0 = leave)
 };
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
 bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int draw_mode, int points_ok, int Q);   // all workgroups of the kernel the launch will use fit on the device at once
@@ -205,6 +208,8 @@ struct UcArgs {
     float* ctx;                     // [n_chunks][L][Q][dm] outputs of the launch's chunks
     long long* dbg;                 // timing experiments: phase stamps of one V' workgroup, or nullptr
     int v16;                        // uc_fast_kernel: V' slices of 16 columns (twice the workgroups, half the read-out each)
+    long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
+    int prio;                       // experiments build: s_setprio level of the kernel's waves (0 = leave)
 };
 // scores -> softmax weights + row sums of the ring slots the persistent role S filled (in place)
 hipError_t launch_alpha_rows(float* alpha_ring, long alpha_slot, float* asum_ring, long asum_slot, long slot0, int ring,

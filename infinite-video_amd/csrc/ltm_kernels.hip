@@ -28,9 +28,17 @@ namespace infv {
 // ======================================================================================
 // Tokens as the producer stores them: fp32 (the reference's layout) or bf16 (half the HBM bytes of the only heavy
 // stream of the path; every bf16 value is exact in fp32, the sum runs in fp32 in the same order).
+typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
 struct TokF32 {
     typedef floatx4 vec;                               // 4 columns per lane
     static __device__ inline floatx4 widen(floatx4 v) { return v; }
+    // streaming (nt) buffer load: scalar resource + scalar row offset + one lane offset, no 64-bit address per load in flight
+    static __device__ inline floatx4 load_nt(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+        const uintx4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 2 /* nt */);
+        floatx4 r;
+        r.x = __uint_as_float(v.x); r.y = __uint_as_float(v.y); r.z = __uint_as_float(v.z); r.w = __uint_as_float(v.w);
+        return r;
+    }
 };
 typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 struct TokBF16 {
@@ -40,6 +48,9 @@ struct TokBF16 {
         r.x = __uint_as_float(v.x << 16); r.y = __uint_as_float(v.x & 0xffff0000u);
         r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xffff0000u);
         return r;
+    }
+    static __device__ inline uintx2 load_nt(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 2 /* nt */);
     }
 };
 
@@ -328,11 +339,20 @@ __global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ 
 // ------------------------------------------------------------------------------------------------------
 template <int U, class Tok>
 __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict__ k_, long chunk_stride, int P, int d4, int slices,
-                                                          OperatorView op, long n_rows_total, float* __restrict__ R) {
+                                                          OperatorView op, long n_rows_total, float* __restrict__ R,
+                                                          long long* __restrict__ stamps, int prio) {
     typedef typename Tok::vec tvec;
     extern __shared__ __attribute__((aligned(16))) float pr2_lds[];          // [4 frames][d4] float4
     floatx4* park = reinterpret_cast<floatx4*>(pr2_lds);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wg_stamp_begin(stamps);
+    // (experiment INFV_POOL_PRIO=1: issue priority over co-resident waves.  Beside a projection GEMM workgroup the matrix waves'
+    //  back-to-back MFMAs win the VALU port and this kernel's few adds per load wait behind them -- a pooling workgroup then
+    //  lives 40 us instead of 14, tools/sweep_r03y.sh; with the priority its workgroups live 14 us everywhere, but the UC and
+    //  chain kernels pay for it and the call gets slower, 122 k against 135 k chunks/s, tools/sweep_r03z.sh.  Off.)
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fi = wave / slices, sl = wave - fi * slices;
     const int c4 = sl * 64 + lane;
     const bool col_ok = c4 < d4;
@@ -346,17 +366,19 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
         for (int f0 = fb; f0 < fe; f0 += 4) {
             const int f = f0 + fi;
             if (f < fe && col_ok) {
-                const tvec* src = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)f * P * d4 + c4;
+                const tvec* frame = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)f * P * d4;       // wave-uniform
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<tvec*>(frame), 0, P * d4 * (int)sizeof(tvec), 0x00020000);
+                const int voff = c4 * (int)sizeof(tvec), row_bytes = d4 * (int)sizeof(tvec);
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
                 int p = 0;
                 for (; p + U <= P; p += U) {
                     tvec v[U];
 #pragma unroll
-                    for (int i = 0; i < U; ++i) v[i] = __builtin_nontemporal_load(src + (long)(p + i) * d4);
+                    for (int i = 0; i < U; ++i) v[i] = Tok::load_nt(rs, voff, (p + i) * row_bytes);
 #pragma unroll
                     for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
                 }
-                for (; p < P; ++p) acc += Tok::widen(__builtin_nontemporal_load(src + (long)p * d4));
+                for (; p < P; ++p) acc += Tok::widen(Tok::load_nt(rs, voff, p * row_bytes));
                 acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;              // mean = sum / P, as torch does (LTM.py:304)
                 park[fi * d4 + c4] = acc;
             }
@@ -373,7 +395,44 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
         }
         if (fi == 0 && col_ok) __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + rr * (long)d4 + c4);
     }
+#ifdef INFV_EXPERIMENTS
+    if (stamps != nullptr) { __syncthreads(); wg_stamp_end(stamps); }
+#endif
 }
+
+#ifdef INFV_EXPERIMENTS
+static long long* g_stamps = nullptr;            // [kStampCap][4], launches appended
+static long g_stamp_fill = 0;
+constexpr long kStampCap = 1l << 19;
+static int g_log_kind[1 << 12];                   // launch log: kind and record range of every stamped launch
+static long g_log_first[1 << 12], g_log_n[1 << 12];
+static int g_log_fill = 0;
+long long* exp_stamps_reserve(int kind, long n_wgs) {
+    static const bool want = exp_env("INFV_WG_STAMPS") != nullptr;
+    if (!want) return nullptr;
+    if (!g_stamps) {
+        if (hipMalloc(&g_stamps, kStampCap * 4 * sizeof(long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_stamps, 0, kStampCap * 4 * sizeof(long long));
+    }
+    if (g_stamp_fill + n_wgs > kStampCap || g_log_fill >= (1 << 12)) return nullptr;
+    long long* p = g_stamps + 4 * g_stamp_fill;
+    g_log_kind[g_log_fill] = kind; g_log_first[g_log_fill] = g_stamp_fill; g_log_n[g_log_fill] = n_wgs; ++g_log_fill;
+    g_stamp_fill += n_wgs;
+    return p;
+}
+// copies the records out (kind filled in from the launch log) and rewinds
+extern "C" long infv_exp_wg_stamps(long long* host, long cap) {
+    if (!g_stamps) return 0;
+    (void)hipDeviceSynchronize();
+    const long n = g_stamp_fill < cap ? g_stamp_fill : cap;
+    (void)hipMemcpy(host, g_stamps, (size_t)n * 4 * sizeof(long long), hipMemcpyDeviceToHost);
+    for (int i = 0; i < g_log_fill; ++i)
+        for (long j = g_log_first[i]; j < g_log_first[i] + g_log_n[i] && j < n; ++j) host[4 * j + 3] = g_log_kind[i];
+    (void)hipMemset(g_stamps, 0, (size_t)n * 4 * sizeof(long long));
+    g_stamp_fill = 0; g_log_fill = 0;
+    return n;
+}
+#endif
 
 template <class Tok>
 static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
@@ -394,9 +453,11 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     unsigned grid = (unsigned)n_rows_total;
     if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
     const dim3 block(4 * slices * 64);
-    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
-    else if (u >= 4) hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
-    else hipLaunchKernelGGL((pool_rows2_kernel<2, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R);
+    static const int prio = [] { const char* e = exp_env("INFV_POOL_PRIO"); return e ? atoi(e) : 0; }();
+    long long* stamps = exp_stamps_reserve(WG_POOL, grid);
+    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
+    else if (u >= 4) hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
+    else hipLaunchKernelGGL((pool_rows2_kernel<2, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
     return hipGetLastError();
 }
 
@@ -664,13 +725,15 @@ __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n
 
 template <int BM, int BN, int NT>
 __global__ __launch_bounds__(512, INFV_LW_WAVES) void gemm_nt_lw_kernel(const float* __restrict__ A, int M, int K, WSegs segs,
-                                                         float* __restrict__ C, int ldc, long split_stride) {
+                                                         float* __restrict__ C, int ldc, long split_stride,
+                                                         long long* __restrict__ stamps, int y0) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AR = BM / 32, BR = BN / 32;
     constexpr int kBuf = (BM + BN) * kLdsStride;       // floats per LDS buffer
+    wg_stamp_begin(stamps);
     extern __shared__ __attribute__((aligned(16))) float lw_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM, n0 = (blockIdx.y + y0) * BN;    // (y0: first column tile of this launch, when the launch is one slice of the GEMM)
     constexpr int ntiles = NT;                         // k-tiles per split: a compile-time constant, so that the loader's
     const int kbeg = blockIdx.z * (NT * kBK);          // loop unrolls completely and every vmcnt wait is an exact count
     C += (long)blockIdx.z * split_stride;
@@ -775,6 +838,7 @@ __global__ __launch_bounds__(512, INFV_LW_WAVES) void gemm_nt_lw_kernel(const fl
                 const int o = n0 + wn * (BN / 2) + j * 32 + li;
                 if (m < M) __builtin_nontemporal_store(acc[i][j][r], &C[(long)m * ldc + o]);
             }
+    wg_stamp_end(stamps);                              // (wave 0's last store issued: the other matrix waves end within a tile of it)
 }
 
 static void segs_clear(WSegs& s) {
@@ -823,11 +887,20 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
         if (((M + 127) / 128) * (n_cols / 128) <= 160 && ((M + 63) / 64) * (n_cols / 128) <= 256) {
             dim3 grid((M + 63) / 64, n_cols / 128, splitk);
             hipLaunchKernelGGL((gemm_nt_lw_kernel<64, 128, 24>), grid, dim3(512), 2 * (64 + 128) * kLdsStride * sizeof(float), stream,
-                               A, M, K, segs, C, ldc, split_stride);
+                               A, M, K, segs, C, ldc, split_stride, exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z), 0);
         } else {
-            dim3 grid((M + 127) / 128, n_cols / 128, splitk);
-            hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), 2 * (128 + 128) * kLdsStride * sizeof(float), stream,
-                               A, M, K, segs, C, ldc, split_stride);
+            // Column slices launched one after the other on the stream (experiment INFV_GEMM_SLICES): a launch whose workgroups do not
+            // all find a seat leaves a backlog at the dispatcher, and while it stands the pooling stream's workgroups are not
+            // dispatched either (tools/residency.py timelines); slices of <= ~200 workgroups never queue.
+            static const int slices = [] { const char* e = exp_env("INFV_GEMM_SLICES"); return e ? atoi(e) : 1; }();
+            const int gy = n_cols / 128;
+            for (int sl = 0; sl < slices; ++sl) {
+                const int y0 = gy * sl / slices, y1 = gy * (sl + 1) / slices;
+                if (y1 <= y0) continue;
+                dim3 grid((M + 127) / 128, y1 - y0, splitk);
+                hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), 2 * (128 + 128) * kLdsStride * sizeof(float), stream,
+                                   A, M, K, segs, C, ldc, split_stride, exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z), y0);
+            }
         }
         return hipGetLastError();
     }

@@ -317,6 +317,12 @@ __device__ inline int uf_slot(int r, int j4) { return r * 8 + (j4 ^ (((r >> 5) &
 template <bool V16>
 __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    wg_stamp_begin(a.wg_stamps);
+#ifdef INFV_EXPERIMENTS
+    if (a.prio == 3) __builtin_amdgcn_s_setprio(3);          // (experiment INFV_UC_PRIO: issue priority against co-resident pooling waves)
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, rows = a.op.rows;
     const int apitch = N + 4;
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
         const int n = bi + rpp * p;
         if (p < NP && n < N) *reinterpret_cast<floatx4*>(dst + (long)n * pitch + 4 * c4) = cur[slot(n, c4)];
     }
+    wg_stamp_end(a.wg_stamps);
 }
 
 bool uc_fast_supported(int N, int Q, int tabw) { return tabw == 4 && Q <= kUcQ && N % 64 == 0 && N <= 256; }
@@ -588,6 +595,9 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
         UcArgs b = a;
         b.v16 = 1;
         const int nblk = a.L * (a.d / kUcCols + a.dm / 16);
+        b.wg_stamps = exp_stamps_reserve(WG_UC, nblk);
+        static const int prio = [] { const char* e = exp_env("INFV_UC_PRIO"); return e ? atoi(e) : 0; }();
+        b.prio = prio;
         const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
         const size_t lds_floats = vfl > bfl ? vfl : bfl;
         hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);

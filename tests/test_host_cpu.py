@@ -108,6 +108,44 @@ def test_shipped_library_reads_only_the_documented_environment_options():
     assert documented < exp and {"INFV_SKIP", "INFV_CHAIN_FAULT", "INFV_POOL_ROWS"} <= exp
 
 
+def test_experiments_build_keeps_the_register_footprint_of_the_shipped_kernels(tmp_path):
+    """Who shares a CU with whom is decided by registers per wave: an experiment branch compiled into a
+    pipeline kernel must not change its allocation, or every A/B run with the experiments build measures a different pipeline
+    (round 3: timing branches took the projection GEMM from 130 to 202 VGPRs and with them its seat beside a pooling
+    workgroup).  Reads the VGPR counts of both libraries' gfx950 code objects."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("ROCm LLVM binutils not found")
+    def vgprs(lib):
+        d = tmp_path / lib
+        d.mkdir()
+        shutil.copy(os.path.join(os.path.dirname(_lib.LIB_PATH), lib), d / lib)
+        subprocess.run([f"{llvm}/llvm-objdump", "--offloading", lib], cwd=d, capture_output=True, check=True)
+        out = {}
+        for f in sorted(os.listdir(d)):
+            if "amdgcn" not in f:
+                continue
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], cwd=d, capture_output=True, text=True, check=True).stdout
+            name = None
+            for line in notes.split("\n"):
+                m = re.search(r"\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.search(r"\.vgpr_count:\s+(\d+)", line)
+                if m and name:
+                    out[name] = int(m.group(1))
+        return out
+    shipped, exp = vgprs("libinfv_ltm.so"), vgprs("libinfv_ltm_exp.so")
+    pipeline = [k for k in shipped if re.search(r"pool_rows2_kernel|pool_frames_kernel|gemm_nt_lw_kernel|uc_fast_kernel|"
+                                                r"chain_batch2_kernel|alpha_rows2_kernel|build_rows_kernel", k)]
+    assert len(pipeline) >= 8
+    granule = lambda v: (v + 7) // 8                                 # registers are allocated in blocks of 8
+    diff = {k: (shipped[k], exp.get(k)) for k in pipeline if k not in exp or granule(exp[k]) != granule(shipped[k])}
+    assert not diff, diff
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "infinite-video_amd")
     for dirpath, _, files in os.walk(pkg):

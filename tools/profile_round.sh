@@ -26,7 +26,7 @@ for name in ("fetch","write"):
     if not fs: print("no pmc file for",name); continue
     agg=collections.defaultdict(lambda:[0,0.0])
     for r in csv.DictReader(open(fs[0])):
-        k=r["Kernel_Name"][:60]
+        k=r["Kernel_Name"][:60]+" grid="+r["Grid_Size"]      # per launch size: a short tail launch is not a full one
         agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
     res[name]={k:(n,v/n) for k,(n,v) in agg.items()}
 json.dump(res,open(out+"/pmc_summary.json","w"),indent=1)
