@@ -893,12 +893,16 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
             // all find a seat leaves a backlog at the dispatcher, and while it stands the pooling stream's workgroups are not
             // dispatched either (tools/residency.py timelines); slices of <= ~200 workgroups never queue.
             static const int slices = [] { const char* e = exp_env("INFV_GEMM_SLICES"); return e ? atoi(e) : 1; }();
+            // (experiment INFV_GEMM_LW_LDS: total dynamic LDS of the launch; 90 KB keeps pooling workgroups off the GEMM's CUs)
+            static const size_t lw_lds = [] { const char* e = exp_env("INFV_GEMM_LW_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+            size_t lds_bytes = 2 * (128 + 128) * kLdsStride * sizeof(float);
+            if (lw_lds > lds_bytes && lw_lds <= 96 * 1024) lds_bytes = lw_lds;
             const int gy = n_cols / 128;
             for (int sl = 0; sl < slices; ++sl) {
                 const int y0 = gy * sl / slices, y1 = gy * (sl + 1) / slices;
                 if (y1 <= y0) continue;
                 dim3 grid((M + 127) / 128, y1 - y0, splitk);
-                hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), 2 * (128 + 128) * kLdsStride * sizeof(float), stream,
+                hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), lds_bytes, stream,
                                    A, M, K, segs, C, ldc, split_stride, exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z), y0);
             }
         }
