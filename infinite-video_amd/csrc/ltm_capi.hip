@@ -114,6 +114,10 @@ struct Timed {
 // New-row buffers R of the sub-batch pipeline: the pooling stream fills set b % kRSets for sub-batch b and may run that many
 // sub-batches ahead of the UC kernel, the last reader of a set (three sets coupled the pooling to the UC stream's progress).
 constexpr int kRSets = 8;
+#ifndef INFV_PSETS
+#define INFV_PSETS 5
+#endif
+constexpr int kPSets = INFV_PSETS;            // rotating sets of the sub-batch workspaces (projections, new-row scores, pooled frames) and their events
 
 struct infv_ltm_s {
     infv_ltm_config cfg;
@@ -133,15 +137,15 @@ struct infv_ltm_s {
     unsigned override_mask = 0;        // layers whose next draw uses probs_override (teacher forcing)
     // workspaces of the chunk-parallel stage, two sets: consolidate() fills set b&1 for sub-batch b on a side
     // stream while the chain of sub-batch b-1 runs on the caller's stream
-    DeviceBuf kbar_ws, kbar_side[3], R_ws[kRSets + 1], P_ws[3], Snew_ws[3];   // R: sets 0..kRSets-1 rotate over the sub-batches, kRSets = first chunk of a document
+    DeviceBuf kbar_ws, kbar_side[kPSets], R_ws[kRSets + 1], P_ws[kPSets], Snew_ws[kPSets];   // R: sets 0..kRSets-1 rotate over the sub-batches, kRSets = first chunk of a document
     DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
-    hipEvent_t ev_pool[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_pool[kPSets] = {};
     hipEvent_t ev_r[kRSets] = {};      // the UC kernel that read R set i is done
-    hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_start = nullptr, ev_q = nullptr, ev_p[kPSets] = {};
     // fast path (consolidate): bias-free scores (ping-pong), softmax weights + row sums (ring of 3,
     // read two launches later), resolved gather tables (ring of 2, read one launch later)
     DeviceBuf Sp[2], cqbuf;
@@ -150,7 +154,8 @@ struct infv_ltm_s {
     DeviceBuf crit_ring, tabb_ring;              // chain_batch2_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
-    hipEvent_t ev_s[3] = {nullptr, nullptr, nullptr}, ev_uc[3] = {nullptr, nullptr, nullptr};
+    hipStream_t chain_s = nullptr;      // CU-mask experiment: role S's own (masked) stream, else nullptr
+    hipEvent_t ev_s[kPSets] = {}, ev_uc[kPSets] = {};
     DeviceBuf sync_words;              // [0..7] arrival counters per layer
     // error word of the persistent chain kernel: pinned host memory mapped into the device, so a time-out is
     // visible to the host without any synchronisation or copy
@@ -178,13 +183,13 @@ struct infv_ltm_s {
         if (side) (void)hipStreamSynchronize(side);
         if (ucs) (void)hipStreamSynchronize(ucs);
         if (pools) (void)hipStreamSynchronize(pools);
-        for (int i = 0; i < 3; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
+        for (int i = 0; i < kPSets; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < kRSets; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
-        for (int i = 0; i < 3; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
+        for (int i = 0; i < kPSets; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_q) (void)hipEventDestroy(ev_q);
-        for (int i = 0; i < 3; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
+        for (int i = 0; i < kPSets; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
         if (err_host) (void)hipHostFree(err_host);
     }
 };
@@ -442,7 +447,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (const char* f = exp_env("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
     if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
     if (const char* f = exp_env("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
-    h->ring = 3 * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
+    h->ring = kPSets * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));
@@ -966,7 +971,10 @@ int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const floa
 // the first one's and its pipeline ran 12 % slower (107 k against 120 k chunks/s for the second engine of bench.py).
 // Handles are not re-entrant and their calls are issued from one host thread at a time, so FIFO order within a shared
 // stream is the order the host issued the work in; cross-stream dependencies are events, as before.
-struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr; };
+struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr, chain = nullptr; };   // chain: CU-mask experiment only
+// experiment INFV_CU_MASK=K: the first K CUs (in the runtime's CU-mask bit order) belong to role S alone -- its launches go to a
+// stream masked to them, the three worker streams are masked to the rest.  0 = no masks (default).
+int cu_mask_k() { static const int k = [] { const char* e = exp_env("INFV_CU_MASK"); return e ? atoi(e) : 0; }(); return k; }
 int shared_streams(int dev, SharedStreams** out) {
     static std::mutex mu;
     static SharedStreams pool[64];
@@ -979,6 +987,20 @@ int shared_streams(int dev, SharedStreams** out) {
         // INFV_PRIO_UCS / _POOL / _SIDE (experiments): -1 most urgent, 0 normal, 1 least urgent
         auto prio = [&](const char* name, int dflt) { const char* e = exp_env(name); int v = e ? atoi(e) : dflt; return v < hi ? hi : (v > lo ? lo : v); };
         const int prio_ucs = prio("INFV_PRIO_UCS", 0), prio_pool = prio("INFV_PRIO_POOL", lo), prio_side = prio("INFV_PRIO_SIDE", lo);
+        const int K = cu_mask_k();
+        if (K > 0) {
+            int cus = 0;
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            const int words = (cus + 31) / 32;
+            std::vector<uint32_t> ms(words, 0u), mo(words, 0u);
+            for (int i = 0; i < cus; ++i) ((i < K) ? ms : mo)[i / 32] |= 1u << (i % 32);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&p.chain, words, ms.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&p.ucs, words, mo.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&p.pools, words, mo.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&p.side, words, mo.data()));
+            *out = &p;
+            return INFV_OK;
+        }
         HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio_ucs));
         HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio_pool));
         HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio_side));   // last: marks the set complete
@@ -1009,8 +1031,8 @@ int ensure_side_stream(infv_ltm_handle h) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));                              // (the caller's current device: where the handle was created)
     if (int rc = shared_streams(dev, &sh)) return rc;
-    h->ucs = sh->ucs; h->pools = sh->pools;
-    for (int i = 0; i < 3; ++i) {
+    h->ucs = sh->ucs; h->pools = sh->pools; h->chain_s = sh->chain;
+    for (int i = 0; i < kPSets; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_s[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_uc[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_p[i], hipEventDisableTiming));
@@ -1089,7 +1111,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     HIP_TRY(launch_qtilde(q, Q, h->H, h->d, h->L, pp, h->qt_buf.as<float>(), h->cqbuf.as<float>(), stream));
     HIP_TRY(hipEventRecord(h->ev_q, stream));                 // the side stream's projections need no more than this
     int c = 0;
-    bool uc_pending[3] = {false, false, false};               // ev_uc[set] has been recorded in this call
+    bool uc_pending[kPSets] = {};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
         const float* kb0 = kbar_pre;
         if (!kb0) {
@@ -1157,7 +1179,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     static const bool split_pool_env = [] { const char* e = exp_env("INFV_SPLIT_POOL"); return !e || atoi(e) != 0; }();
     const bool split_pool = split_pool_env && !kbar_pre;      // (frame means handed in: there is no pooling stage)
     hipStream_t pools = split_pool ? h->pools : side;
-    bool p_pending[3] = {false, false, false};                // ev_p[set] has been recorded in this call
+    bool p_pending[kPSets] = {};                // ev_p[set] has been recorded in this call
     bool r_pending[kRSets] = {};                              // ev_r[rset] has been recorded in this call
     // Pool + rows in one kernel: the pooling stream writes the sub-batch's new rows R straight from the tokens -- in this path
     // the frame means are consumed by the rows kernel only; same bits either way.  Default: pool_rows2_kernel (one short-lived
@@ -1178,7 +1200,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const size_t need = (size_t)h->maxC * T * h->d * sizeof(float);
         if (need > h->kbar_side[0].bytes) {
             HIP_TRY(hipDeviceSynchronize());
-            for (int i = 0; i < 3; ++i) HIP_TRY(h->kbar_side[i].reserve(need));
+            for (int i = 0; i < kPSets; ++i) HIP_TRY(h->kbar_side[i].reserve(need));
         }
     }
     if (n_batches > 0) {                                      // the rotating R sets are written off the side stream: size them here
@@ -1193,7 +1215,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
         if (kbar_pre) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % kRSets;
+        const int set = b % kPSets, rset = b % kRSets;
         if (use_pr) {
             // R set rset was last read by the UC kernel (and the projections) of batch b - kRSets
             if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
@@ -1220,7 +1242,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     };
     auto stage_project = [&](int b) -> int {                   // rows -> [V'new | S'new] GEMM of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % kRSets;
+        const int set = b % kPSets, rset = b % kRSets;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (r_pending[rset] && !use_pr) HIP_TRY(hipStreamWaitEvent(side, h->ev_r[rset], 0));   // (the rows kernel writes R here)
         if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
@@ -1248,13 +1270,21 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     static const bool host_trace = exp_env("INFV_HOST_TRACE") != nullptr;   // host time of every loop iteration (is the host ahead of the device?)
     std::vector<double> host_us;
     const auto host_t0 = std::chrono::steady_clock::now();
+    // (CU-mask experiment: role S's launches go to the stream that owns the reserved CUs; it starts behind everything the caller's
+    //  stream has done so far and the caller's stream picks up behind it at the join)
+    hipStream_t ls = stream;
+    if (h->chain_s != nullptr && persistent && n_batches > 0) {
+        ls = h->chain_s;
+        HIP_TRY(hipStreamWaitEvent(ls, h->ev_in, 0));
+        pipe.stream = ls;
+    }
     for (int b = 0; b < n_batches; ++b) {
         if (host_trace) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
         int c0, nb; batch_range(b, &c0, &nb);
-        const int set = b % 3, rset = b % kRSets;
-        HIP_TRY(hipStreamWaitEvent(stream, h->ev_p[set], 0));
+        const int set = b % kPSets, rset = b % kRSets;
+        HIP_TRY(hipStreamWaitEvent(ls, h->ev_p[set], 0));
         // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
-        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[set], 0));
+        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
         const long slot0 = pipe.counter;
         static const bool serial = exp_env("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
         if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
@@ -1265,7 +1295,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); }
             if (int rc = pipe.launch_s_batch(nb, h->P_ws[set].as<float>() + (size_t)h->L * h->dm, sks[b], sss[b],
                                              u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
-            if (serial) HIP_TRY(hipStreamSynchronize(stream));
+            if (serial) HIP_TRY(hipStreamSynchronize(ls));
         } else {
             for (int i = 0; i < nb; ++i) {
                 const size_t ld = (size_t)h->L * h->dm + (size_t)h->L * h->H * Q;
@@ -1314,7 +1344,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
-        HIP_TRY(hipEventRecord(h->ev_s[set], stream));
+        HIP_TRY(hipEventRecord(h->ev_s[set], ls));
         HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
         if (persistent)
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
@@ -1332,7 +1362,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     }
     // join: the memory and every ctx are complete once the last UC kernel is; then hand the sticky histogram
     // back as one float partial row and bring the K' half of the projected memory up to date
-    for (int i = 0; i < 3; ++i)
+    if (ls != stream) {
+        HIP_TRY(hipEventRecord(h->ev_in, ls));
+        HIP_TRY(hipStreamWaitEvent(stream, h->ev_in, 0));
+        pipe.stream = stream;
+    }
+    for (int i = 0; i < kPSets; ++i)
         if (uc_pending[i]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[i], 0));
     if (pipe.counter > 0) {
         HIP_TRY(launch_acc_to_part(h->mass_acc[(pipe.counter + 2) % 3].as<unsigned long long>(), h->L, 1,
