@@ -1,0 +1,9 @@
+#!/bin/bash
+# UC kernel with even boxes first in LDS (parity row order) against the logical row order, same box alternating
+{
+python -m pytest tests/test_ltm_gpu.py tests/test_timed_path_gpu.py -x -q 2>&1 | tail -2
+for rep in 1 2 3; do
+INFV_LTM_LIBRARY=$PWD/tools/ab/lib_uc_old.so tools/env_sweep.sh "UC_ROWS=logical"
+INFV_LTM_LIBRARY=exp tools/env_sweep.sh "UC_ROWS=parity"
+done
+} 2>&1 | tee gpurun_out/sweep_r04v.txt
