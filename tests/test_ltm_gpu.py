@@ -77,6 +77,23 @@ def test_pool_rows_matches_oracle_operator_on_pooled_frames(dev, N, P, d, T, C):
         np.testing.assert_allclose(R[:, r], plan.inf_box_val[b] * kb[:, fb:fe].sum(1), rtol=0, atol=2e-6)
 
 
+def test_pool_rows_bf16_tokens_and_dense_plan_refusal(dev):
+    """bf16 frame tokens through the one-pass kernel equal the fp32 run on the same (bf16-representable) values bit for bit;
+    a num_basis whose plan is dense has no box rows: the entry point refuses it instead of returning something."""
+    from infinite_video_amd import _lib
+    from infinite_video_amd.engine import LTMEngine
+    eng = LTMEngine(256, 12, 64, 768, 32, tau=.75, sticky=True, device=dev)
+    k32 = torch.randn(3, 64 * 32, 768, device=dev).bfloat16().float()
+    R32 = eng.pool_rows(k32)
+    R16 = eng.pool_rows(k32.bfloat16())
+    assert torch.equal(R32, R16)
+    assert torch.equal(eng.pool_rows(k32), R32)                      # and back to fp32 tokens on the same handle
+    dense = LTMEngine(96, 12, 64, 768, 32, tau=.75, sticky=True, device=dev)
+    with pytest.raises(_lib.LTMError) as ei:
+        dense.pool_rows(torch.randn(1, 16 * 32, 768, device=dev))
+    assert ei.value.code == -2                                       # INFV_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_chain_free_running_matches_oracle_and_reference(dev, case):
     """Per-chunk forward() of all layers; the GPU derives its own sticky probabilities."""
