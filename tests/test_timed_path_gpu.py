@@ -284,6 +284,7 @@ _VARIANTS = [
     {"INFV_VPROJ_ON_UC": "1"},                                 # V' half of the projection as its own GEMM on the UC stream
     {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
     {"INFV_GEMM_LW": "0"},                                     # projection GEMM without loader waves
+    {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
     {"INFV_GEMM_SLICES": "2"},                                 # projection GEMM launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
 ]
