@@ -355,6 +355,31 @@ def main():
                   "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "max_abs_diff_vs_f32": float((ctx2 - ctx).abs().max())}
         del eng2, ctx2
 
+    # ---- secondary line (N = 1): the whole projection GEMM on the bf16 MFMA pipe, fp32-accurate (INFV_PROJ_X6=1 at engine
+    #      creation: exact three-piece bf16 splits of both operands, six partial products, fp32 accumulation; against fp64 its
+    #      error is below the fp32-MFMA GEMM's, tests/test_ltm_gpu.py) ----
+    proj_x6 = None
+    if world == 1 and not args.no_secondary and os.environ.get("INFV_PROJ_X6", "0") in ("", "0"):
+        os.environ["INFV_PROJ_X6"] = "1"
+        try:
+            eng4 = LTMEngine(N, H, DH, D, P, tau=TAU, sticky=True, n_layers=L, max_q=Q, device=dev,
+                             max_batch_chunks=args.batch_chunks)
+        finally:
+            del os.environ["INFV_PROJ_X6"]
+        for _ in range(2):
+            consolidate_video(eng4, k, q, projs, u)
+        torch.cuda.synchronize()
+        n4 = max(1, min(args.steps, 40))
+        t1 = time.perf_counter()
+        for _ in range(n4):
+            ctx4, _ = consolidate_video(eng4, k, q, projs, u)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t1
+        proj_x6 = {"dtype": "f32 operands as exact 3-piece bf16 splits, 6 MFMA products, f32 accumulation (projection GEMM only)",
+                   "value": args.chunks * n4 / dt4, "unit": "frame-chunks/s", "steps": n4, "ms_per_step": 1e3 * dt4 / n4,
+                   "max_abs_diff_vs_f32_mfma": float((ctx4 - ctx).abs().max())}
+        del eng4, ctx4
+
     # ---- secondary line (N = 1): the optional bf16 producer layout of the frame tokens (infv_ltm_set_token_dtype; half the
     #      bytes of the only HBM-heavy stream; everything after the pooling stays fp32) ----
     bf16_tokens = None
@@ -509,7 +534,9 @@ def main():
             "value": value, "unit": "frame-chunks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (V' projection bf16x3)" if v_split else "f32", "data": "synthetic",
+            "dtype": ("f32 (V' projection bf16x3)" if v_split else
+                      "f32 (projection GEMM: 6 bf16 MFMA products of exact 3-piece splits, f32 accumulation)"
+                      if os.environ.get("INFV_PROJ_X6", "0") not in ("", "0") else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.chunks}-chunk synthetic video, max_int=256 frames x 32 tokens x 768, "
                                    "num_basis=256, tau=0.75, sticky, 2 video-Q-former LTM layers, "
                                    "Q=32 queries, LLM/Q-former stubbed (BASELINE configs[1]/[2])",
@@ -529,6 +556,8 @@ def main():
             out["shard256_includes_rccl_all_gather"] = shard256_rccl
         if vsplit is not None:
             out["secondary_vproj_bf16x3"] = vsplit
+        if proj_x6 is not None:
+            out["secondary_proj_bf16x6"] = proj_x6
         if bf16_tokens is not None:
             out["secondary_bf16_tokens"] = bf16_tokens
         if encode_video is not None:

@@ -141,6 +141,11 @@ struct infv_ltm_s {
     DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
+    // INFV_PROJ_X6=1 at create: the projection GEMM of the whole-video path on the bf16 MFMA pipe, fp32-accurate (three exact
+    // bf16 pieces per operand, six products, fp32 accumulation: split_gemm.hip) instead of gemm_nt_lw_kernel's fp32 MFMAs.
+    // Planes of [Wv ; q~] are made once per call, of a sub-batch's new rows per launch.
+    DeviceBuf w3[3], r3[3];
+    bool proj_x6 = false, w3_valid = false;
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
     hipEvent_t ev_pool[kPSets] = {};
@@ -446,6 +451,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (e == hipSuccess) e = h->bins_forced.reserve((size_t)h->L * h->S * sizeof(int32_t));
     if (const char* f = exp_env("INFV_CHAIN_FAULT")) if (atoi(f) != 0) { h->expect_extra = 1; h->spin_limit = 1 << 12; }
     if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
+    if (const char* f = getenv("INFV_PROJ_X6")) h->proj_x6 = atoi(f) != 0;
     if (const char* f = exp_env("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
     h->ring = kPSets * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
@@ -943,6 +949,20 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
                                       h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
         *splitk = 1;
+    } else if (h->proj_x6 && h->w3_valid && inf && M >= 1024 && h->d % 32 == 0 && !defer_values) {
+        // [V'new | S'new] = R . [Wv ; q~]^T from three bf16 planes per operand (the weights' planes were made once for the call)
+        Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
+        const size_t szR = (size_t)M * h->d * sizeof(__bf16);
+        if (szR > h->r3[0].bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) HIP_TRY(h->r3[i].reserve((size_t)h->maxC * op.rows * h->d * sizeof(__bf16) > szR ? (size_t)h->maxC * op.rows * h->d * sizeof(__bf16) : szR));
+        }
+        HIP_TRY(launch_split3_rows(h->R_ws[rset].as<float>(), h->d, M, h->d, h->r3[0].p, h->r3[1].p, h->r3[2].p, 0, M, stream));
+        SplitGemm6 g{};
+        for (int i = 0; i < 3; ++i) { g.A[i] = h->r3[i].as<__bf16>(); g.B[i] = h->w3[i].as<__bf16>(); }
+        g.lda = h->d; g.ldb = h->d; g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.M = (int)M; g.N = (int)ld; g.K = h->d;
+        HIP_TRY(launch_gemm_x6(g, stream));
+        *splitk = 1;
     } else {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
@@ -1109,6 +1129,21 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     hipStream_t side = h->side, ucs = h->ucs;
     // pre-multiplied queries qt = (q/sqrt(dh)) . Wk_h and the bias term cq = q_h . bk_h / sqrt(dh), once per call
     HIP_TRY(launch_qtilde(q, Q, h->H, h->d, h->L, pp, h->qt_buf.as<float>(), h->cqbuf.as<float>(), stream));
+    h->w3_valid = false;
+    if (h->proj_x6 && h->d % 32 == 0 && ((long)h->L * h->dm + (long)h->L * h->H * Q) % 8 == 0) {
+        // bf16 planes of the projection GEMM's weight rows [Wv_0 ; ... ; Wv_{L-1} ; q~] (the caller's weights may change between calls)
+        const long n_rows = (long)h->L * h->dm + (long)h->L * h->H * Q;
+        const size_t szW = (size_t)n_rows * h->d * sizeof(__bf16);
+        if (szW > h->w3[0].bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) HIP_TRY(h->w3[i].reserve(szW));
+        }
+        for (int l = 0; l < h->L; ++l)
+            HIP_TRY(launch_split3_rows(pp.wv[l], h->d, h->dm, h->d, h->w3[0].p, h->w3[1].p, h->w3[2].p, (long)l * h->dm, n_rows, stream));
+        HIP_TRY(launch_split3_rows(h->qt_buf.as<float>(), h->d, (long)h->L * h->H * Q, h->d, h->w3[0].p, h->w3[1].p, h->w3[2].p,
+                                   (long)h->L * h->dm, n_rows, stream));
+        h->w3_valid = true;
+    }
     HIP_TRY(hipEventRecord(h->ev_q, stream));                 // the side stream's projections need no more than this
     int c = 0;
     bool uc_pending[kPSets] = {};               // ev_uc[set] has been recorded in this call

@@ -362,6 +362,194 @@ hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, vo
     return hipGetLastError();
 }
 
+// ======================================================================================================
+// fp32-accurate contraction on the bf16 MFMA pipe ("bf16x6").  An fp32 value is carried EXACTLY as three bf16 pieces
+//     x = p0 + p1 + p2,   p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)        (8 + 8 + 8 = 24 significand bits;
+// every difference is exact in fp32, only p2 may lose the last bit or two of x: <= 2^-25 relative), a product of two such
+// values as the six partial products with i + j <= 2, each exact in fp32 (8 x 8 bit significands), accumulated in the MFMA's fp32
+// accumulators smallest first: a2 b0 + a0 b2 + a1 b1, then a1 b0 + a0 b1, then a0 b0.  The three dropped products are <= 2^-24
+// relative together.  The result differs from an fp32 FMA chain the way two fp32 summation orders differ from each other
+// (tests/test_ltm_gpu.py measures both against fp64).  Six 32x32x16 bf16 MFMAs (6 x 32 clocks) replace eight 32x32x2 fp32
+// MFMAs (8 x 64 clocks) per 32 x 32 x 16 block: 2.7x less matrix-pipe time -- which in the whole-video pipeline is CU time the
+// projection GEMM's workgroups hold and during which a co-resident pooling workgroup streams three times slower.
+//   C[m][o] = sum_k A[m][k] * B[o][k],  A, B given as three bf16 planes each; 128 x 128 x 32 tiles, 4 waves as 2 x 2, register
+//   prefetch of the next k-tile, 60 KB of LDS (a pooling workgroup's 84 KB fit beside it).
+// ======================================================================================================
+namespace {
+constexpr int kXBK = 32;                          // k per tile (two 32x32x16 steps)
+constexpr int kXPitch = 2 * kXBK + 16;            // 80 bytes per LDS row
+constexpr int kXArr = 128 * kXPitch;              // one operand-plane tile (128 rows)
+constexpr int kXLds = 6 * kXArr;                  // A0 A1 A2 B0 B1 B2: 61 440 B
+__device__ inline void split3(float x, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)x;
+    const float r1 = x - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void gemm_x6_kernel(SplitGemm6 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    wg_stamp_begin(g.wg_stamps);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware tile order (see split_gemm_kernel): the tiles that share B rows run on one XCD at the same time
+        const unsigned nwg = gridDim.x * gridDim.y;
+        const unsigned orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)(v / gridDim.x);
+    }
+    const int m0 = bx * 128, n0 = by * 128;
+    const int ntiles = g.K / kXBK;
+    // staging: thread -> (row = tid >> 1, one half of the row's 32-k segment = 16 bf16 = two 16-byte vectors)
+    const int row = tid >> 1, half = tid & 1;
+    const bool a_ok = m0 + row < g.M, b_ok = n0 + row < g.N;
+    // k-tile-major planes: 16-k tile t of row r at ((t * rows + r) * 16); this kernel's 32-k tile = two of them (the thread's half)
+    const long a_off = ((long)half * g.M + (a_ok ? m0 + row : 0)) * 16;
+    const long b_off = ((long)half * g.N + (b_ok ? n0 + row : 0)) * 16;
+    const long a_t = (long)g.M * 4, b_t = (long)g.N * 4;        // uint4 per 32-k tile: 2 k-tiles x rows x 2
+    // Named registers, not arrays (see split_gemm_wide_kernel: hipcc leaves a staging array in scratch memory)
+    const uint4* sa0 = reinterpret_cast<const uint4*>(g.A[0] + a_off); const uint4* sa1 = reinterpret_cast<const uint4*>(g.A[1] + a_off);
+    const uint4* sa2 = reinterpret_cast<const uint4*>(g.A[2] + a_off); const uint4* sb0 = reinterpret_cast<const uint4*>(g.B[0] + b_off);
+    const uint4* sb1 = reinterpret_cast<const uint4*>(g.B[1] + b_off); const uint4* sb2 = reinterpret_cast<const uint4*>(g.B[2] + b_off);
+    uint4 ra0x, ra0y, ra1x, ra1y, ra2x, ra2y, rb0x, rb0y, rb1x, rb1y, rb2x, rb2y;
+#define INFV_X6_LOAD(t) { const long oa_ = (t) * a_t, ob_ = (t) * b_t;                                                  \
+        ra0x = sa0[oa_]; ra0y = sa0[oa_ + 1]; ra1x = sa1[oa_]; ra1y = sa1[oa_ + 1]; ra2x = sa2[oa_]; ra2y = sa2[oa_ + 1];    \
+        rb0x = sb0[ob_]; rb0y = sb0[ob_ + 1]; rb1x = sb1[ob_]; rb1y = sb1[ob_ + 1]; rb2x = sb2[ob_]; rb2y = sb2[ob_ + 1]; }
+    unsigned char* st_ = smem + row * kXPitch + half * 32;
+#define INFV_X6_ST(a, x, y) *reinterpret_cast<uint4*>(st_ + (a) * kXArr) = x; *reinterpret_cast<uint4*>(st_ + (a) * kXArr + 16) = y;
+#define INFV_X6_STORE() { INFV_X6_ST(0, ra0x, ra0y) INFV_X6_ST(1, ra1x, ra1y) INFV_X6_ST(2, ra2x, ra2y)               \
+                          INFV_X6_ST(3, rb0x, rb0y) INFV_X6_ST(4, rb1x, rb1y) INFV_X6_ST(5, rb2x, rb2y) }
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int li = lane & 31, kh = lane >> 5;
+    INFV_X6_LOAD(0)
+    for (int t = 0; t < ntiles; ++t) {
+        INFV_X6_STORE()
+        __syncthreads();
+        INFV_X6_LOAD(t + 1 < ntiles ? t + 1 : t)       // (the last iteration re-reads its own tile: no branch around the loads)
+#pragma unroll
+        for (int ks = 0; ks < kXBK / 16; ++ks) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(smem + pl * kXArr + (wm * 64 + i * 32 + li) * kXPitch + ks * 32 + kh * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(smem + (3 + pl) * kXArr + (wn * 64 + j * 32 + li) * kXPitch + ks * 32 + kh * 16);
+            // six sweeps over the four accumulators, smallest partial product first: consecutive MFMAs never share an accumulator
+#define INFV_X6_SWEEP(pa, pb)                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+            INFV_X6_SWEEP(2, 0) INFV_X6_SWEEP(0, 2) INFV_X6_SWEEP(1, 1) INFV_X6_SWEEP(1, 0) INFV_X6_SWEEP(0, 1) INFV_X6_SWEEP(0, 0)
+#undef INFV_X6_SWEEP
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int o = n0 + wn * 64 + j * 32 + li;
+                if (m < g.M && o < g.N) __builtin_nontemporal_store(acc[i][j][r], &g.C[(long)m * g.ldc + o]);
+            }
+#undef INFV_X6_LOAD
+#undef INFV_X6_ST
+#undef INFV_X6_STORE
+    wg_stamp_end(g.wg_stamps);
+}
+
+hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.K % kXBK) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    dim3 grid((g.M + 127) / 128, (g.N + 127) / 128);
+    SplitGemm6 gg = g;
+    gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y);
+    // (experiment INFV_X6_LDS: total dynamic LDS; above 80 KB only one of these workgroups fits a CU)
+    static const size_t lds_x = [] { const char* e = exp_env("INFV_X6_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), lds_x > (size_t)kXLds && lds_x <= 96 * 1024 ? lds_x : (size_t)kXLds, stream, gg);
+    return hipGetLastError();
+}
+
+// x [rows][cols] fp32 (rows row0 .. row0 + rows - 1 of an operand of rows_total rows) -> the three bf16 planes with x = p0 + p1 + p2,
+// K-TILE-MAJOR: element (r, c) of a plane sits at ((c / 16) * rows_total + r) * 16 + c % 16.  A k-tile of 128 consecutive rows is
+// then 4 KB of consecutive memory: a wave of the GEMM's staging loads reads 8 whole 128-byte lines instead of 32 bytes of each of 32
+// (row-major planes: the kernel spent its time in the CU's memory pipe, 61 us per workgroup for 15 us of MFMAs).
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ x, long ld_in, long rows, int cols4,
+                                                          __bf16* __restrict__ p0, __bf16* __restrict__ p1, __bf16* __restrict__ p2,
+                                                          long row0, long rows_total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols4) return;
+    const long r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    const floatx4 v = *reinterpret_cast<const floatx4*>(x + r * ld_in + c);
+    __bf16 a[4], b[4], d[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(v[e], a[e], b[e], d[e]);
+    const long o = ((long)(c >> 4) * rows_total + row0 + r) * 16 + (c & 15);
+    *reinterpret_cast<uint2*>(p0 + o) = make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
+    *reinterpret_cast<uint2*>(p1 + o) = make_uint2(pack2(b[0], b[1]), pack2(b[2], b[3]));
+    *reinterpret_cast<uint2*>(p2 + o) = make_uint2(pack2(d[0], d[1]), pack2(d[2], d[3]));
+}
+
+hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, void* p0, void* p1, void* p2, long row0, long rows_total,
+                              hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (cols % 16 || ld_in % 4) return hipErrorInvalidValue;
+    const long n = rows * (cols / 4);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld_in, rows, cols / 4,
+                       static_cast<__bf16*>(p0), static_cast<__bf16*>(p1), static_cast<__bf16*>(p2), row0, rows_total);
+    return hipGetLastError();
+}
+
+#ifdef INFV_EXPERIMENTS
+}  // namespace infv
+// test hook (experiments build only, tests/test_ltm_gpu.py): C [M][N] = A [M][K] . B [N][K]^T through the bf16x6 path (which = 0) or
+// through the fp32-MFMA kernel the whole-video path used before (which = 1); device pointers, synchronous
+extern "C" int infv_exp_gemm(int which, const float* A, const float* B, float* C, int M, int N, int K) {
+    using namespace infv;
+    if (which == 1) {
+        if (launch_project_scores(M, K, N, B, A, C, N, nullptr, 0) != hipSuccess) return -1;
+        return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    }
+    __bf16* pl[6] = {};
+    for (int i = 0; i < 6; ++i)
+        if (hipMalloc(&pl[i], (size_t)(i < 3 ? M : N) * K * sizeof(__bf16)) != hipSuccess) return -1;
+    int rc = 0;
+    if (launch_split3_rows(A, K, M, K, pl[0], pl[1], pl[2], 0, M, nullptr) != hipSuccess) rc = -1;
+    if (launch_split3_rows(B, K, N, K, pl[3], pl[4], pl[5], 0, N, nullptr) != hipSuccess) rc = -1;
+    SplitGemm6 g{};
+    for (int i = 0; i < 3; ++i) { g.A[i] = pl[i]; g.B[i] = pl[3 + i]; }
+    g.lda = K; g.ldb = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    if (rc == 0 && launch_gemm_x6(g, nullptr) != hipSuccess) rc = -1;
+    if (hipDeviceSynchronize() != hipSuccess) rc = -1;
+    for (int i = 0; i < 6; ++i) (void)hipFree(pl[i]);
+    return rc;
+}
+namespace infv {
+#endif
+
 // ------------------------------------------------------------------------------------------------------
 // Frame tokens of a chunk, both ways round:  F [n][d] fp32 ->  F_hi/F_lo [n][d]   (B operand of the score contraction)
 //                                                             FT_hi/FT_lo [d][n]  (B operand of the token-mean contraction)

@@ -60,6 +60,19 @@ struct SplitGemm {
     int M, N, K, k_per_split, splitk, nbatch;
 };
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad = 0);
+// fp32-accurate contraction from three bf16 planes per operand (six partial products, fp32 accumulation): C = A . B^T
+struct SplitGemm6 {
+    const __bf16* A[3]; long lda;    // planes of the [M][K] operand, k-tile-major (launch_split3_rows; lda unused)
+    const __bf16* B[3]; long ldb;    // planes of the [N][K] operand, k-tile-major
+    float* C; long ldc;
+    int M, N, K;
+    long long* wg_stamps;            // residency experiment (wg_stamps.h), or nullptr
+};
+hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream);
+// x [rows][cols] fp32 = rows row0.. of an operand with rows_total rows -> p0 + p1 + p2 = x, bf16 planes in k-tile-major order
+// (element (r, c) at ((c / 16) * rows_total + r) * 16 + c % 16); cols % 16 == 0
+hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, void* p0, void* p1, void* p2, long row0, long rows_total,
+                              hipStream_t stream);
 int shared_worker_stream(hipStream_t* out);   // ltm_capi.hip: the process-wide worker streams
 int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split);   // fills the chip with the tile shape that will run
 // x [rows][cols] fp32 -> hi = bf16(x), lo = bf16(x - hi)

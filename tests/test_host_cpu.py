@@ -101,7 +101,7 @@ def test_shipped_library_reads_only_the_documented_environment_options():
     def knobs(path):
         out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout.split("\n")
         return {w for line in out for w in re.findall(r"INFV_[A-Z0-9_]+", line)}
-    documented = {"INFV_VPROJ_SPLIT", "INFV_VQF_FP32", "INFV_VQF_FUSE", "INFV_VQF_SPLIT_CACHE_GB"}
+    documented = {"INFV_VPROJ_SPLIT", "INFV_PROJ_X6", "INFV_VQF_FP32", "INFV_VQF_FUSE", "INFV_VQF_SPLIT_CACHE_GB"}
     shipped = knobs(_lib.LIB_PATH if "exp" not in os.path.basename(_lib.LIB_PATH) else os.path.join(os.path.dirname(_lib.LIB_PATH), "libinfv_ltm.so"))
     assert shipped == documented, sorted(shipped - documented)
     exp = knobs(os.path.join(os.path.dirname(_lib.LIB_PATH), "libinfv_ltm_exp.so"))

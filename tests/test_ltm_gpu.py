@@ -1,10 +1,15 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the reference goldens.
 Needs a real MI355X: run with ``-m gpu``."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ltm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from tests.golden.cases import CASES, DENSE_CASES, call_uniforms, case_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -75,6 +80,50 @@ def test_pool_rows_matches_oracle_operator_on_pooled_frames(dev, N, P, d, T, C):
     kb = eng.pool(torch.from_numpy(k).to(dev)).cpu().numpy()
     for r, (b, fb, fe) in enumerate(zip(plan.inf_row_box, plan.inf_row_begin, plan.inf_row_end)):
         np.testing.assert_allclose(R[:, r], plan.inf_box_val[b] * kb[:, fb:fe].sum(1), rtol=0, atol=2e-6)
+
+
+_X6_CHILD = r'''
+import ctypes as C, sys, json
+import numpy as np, torch
+from infinite_video_amd import _lib
+lib = _lib.load()
+fn = lib.infv_exp_gemm
+fn.restype = C.c_int
+fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+dev = torch.device("cuda:0")
+out = {}
+for name, M, N, K, scale in [("unit", 2688, 2304, 768, 1.0), ("ragged", 1100, 640, 768, 1.0), ("wide_range", 1344, 1152, 768, None)]:
+    g = torch.Generator(device=dev).manual_seed(M)
+    A = torch.randn(M, K, device=dev, generator=g)
+    B = torch.randn(N, K, device=dev, generator=g)
+    if scale is None:                                       # magnitudes over 12 decades within one row
+        A = A * torch.exp(6.0 * torch.randn(M, K, device=dev, generator=g))
+        B = B * torch.exp(6.0 * torch.randn(N, K, device=dev, generator=g))
+    ref = A.double() @ B.double().T
+    mag = (A.double().abs() @ B.double().abs().T)           # sum_k |a_k b_k|: what rounding errors scale with
+    errs = {}
+    for which, tag in [(0, "x6"), (1, "f32")]:
+        Cc = torch.zeros(M, N, device=dev)
+        assert fn(which, A.data_ptr(), B.data_ptr(), Cc.data_ptr(), M, N, K) == 0
+        errs[tag] = float(((Cc.double() - ref).abs() / mag).max())
+    out[name] = errs
+json.dump(out, open(sys.argv[1], "w"))
+'''
+
+
+def test_bf16x6_projection_gemm_is_as_accurate_as_the_fp32_mfma_gemm(dev, tmp_path):
+    """The whole-video path's projection GEMM runs as six bf16 MFMA products of exact three-piece splits with fp32 accumulation
+    (split_gemm.hip).  Against fp64, relative to sum |a_k b_k|: its worst element error must not exceed the fp32-MFMA kernel's
+    (the round-2 GEMM, same operands) by more than a rounding unit, on unit-scale, ragged and wide-dynamic-range operands."""
+    import json
+    import subprocess
+    path = str(tmp_path / "x6.json")
+    env = dict(os.environ, INFV_LTM_LIBRARY="exp")
+    subprocess.run([sys.executable, "-c", _X6_CHILD, path], check=True, env=env, cwd=ROOT)
+    res = json.load(open(path))
+    for name, e in res.items():
+        assert e["f32"] < 2e-6, (name, e)                             # sanity of the yardstick: K = 768 fp32 roundings
+        assert e["x6"] <= e["f32"] + 6e-8, (name, e)
 
 
 def test_pool_rows_bf16_tokens_and_dense_plan_refusal(dev):

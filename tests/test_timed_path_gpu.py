@@ -128,12 +128,16 @@ def _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast=Non
     return worst, flips
 
 
-@pytest.mark.parametrize("n_chunks", [64, 256, 2048])
-def test_bench_call_matches_per_chunk_chain(dev, n_chunks):
+@pytest.mark.parametrize("n_chunks,x6", [(64, False), (256, False), (2048, False), (256, True), (2048, True)])
+def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
     """64 chunks: two 28-chunk sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
-    shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call."""
+    shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call.  x6: the same with INFV_PROJ_X6=1, the projection GEMM
+    as six bf16 MFMA products of exact three-piece splits -- same goldens, same oracle, same budgets as the fp32-MFMA GEMM."""
     k, q, projs, u, ws, qs = _video(dev, n_chunks)
+    if x6:
+        monkeypatch.setenv("INFV_PROJ_X6", "1")
     fast = _engine(dev, max_batch_chunks=42)
+    monkeypatch.delenv("INFV_PROJ_X6", raising=False)
     bins_all, probs_all = fast.set_trace(n_chunks)
     ctx = fast.consolidate(k, q, projs, u, new_doc=True)
     fast.sync()
