@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of how sweep_r05a/d.txt were produced: at that time the bf16x6 GEMM was the default, INFV_PROJ_FP32=1 selected the fp32-MFMA GEMM and
+#  INFV_X6_PIPE chose between the two bf16x6 kernels; now INFV_PROJ_X6=1 opts in and only the single-tile kernel is kept)
 # pipelined bf16x6 projection GEMM (default) against the single-tile one (INFV_X6_PIPE=0) and the fp32-MFMA GEMM (INFV_PROJ_FP32=1)
 export INFV_LTM_LIBRARY=exp
 {
