@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: INFV_X6_PIPE selected a pipelined bf16x6 kernel that was not kept)
 # bf16x6 projection GEMM as a short exclusive burst: the pipelined kernel with six tiles in flight (244 registers, 72 KB: two
 # workgroups per CU, no room for a pooling workgroup beside them)
 export INFV_LTM_LIBRARY=exp INFV_PROJ_X6=1
