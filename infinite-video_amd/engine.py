@@ -239,9 +239,9 @@ class LTMEngine:
     # -- lean entry points of the drop-in module's per-call path: the caller has validated shapes / dtypes / devices once for
     #    this call signature; nothing is re-checked here, no context manager is entered (the caller's device is current)
     def pool_into(self, k: torch.Tensor, kbar: torch.Tensor, n_frames: int, token_code: int, stream: C.c_void_p):
-        if token_code != getattr(self, "_token_code", -1):
-            _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, token_code))
-            self._token_code = token_code
+        # the token dtype is sticky state of the C handle and other callers of the same handle change it (the video
+        # Q-former's C path forces fp32): always set it, one cheap host call, never trust a Python-side cache
+        _lib.check(self.lib.infv_ltm_set_token_dtype(self._h, token_code))
         rc = self.lib.infv_ltm_pool(self._h, C.c_void_p(k.data_ptr()), n_frames, C.c_void_p(kbar.data_ptr()), stream)
         if rc < 0:
             _lib.check(rc)

@@ -95,16 +95,21 @@ def _all_gather_payload(payload: torch.Tensor, world: int, group=None) -> torch.
     return torch.cat(parts).to(payload.device)
 
 
+def _global_rank(group, group_rank: int) -> int:
+    """torch.distributed's send / recv take GLOBAL ranks; the hand-off chain is numbered inside ``group``."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def _send(t: torch.Tensor, dst: int, group=None):
-    dist.send(t if _device_collectives(group) else t.cpu(), dst, group=group)
+    dist.send(t if _device_collectives(group) else t.cpu(), _global_rank(group, dst), group=group)
 
 
 def _recv(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
     if _device_collectives(group):
-        dist.recv(t, src, group=group)
+        dist.recv(t, _global_rank(group, src), group=group)
         return t
     host = torch.empty(t.shape, dtype=t.dtype)
-    dist.recv(host, src, group=group)
+    dist.recv(host, _global_rank(group, src), group=group)
     return host.to(t.device)
 
 

@@ -157,6 +157,36 @@ def test_two_rank_handoff_equals_the_single_stream_run_bit_for_bit():
     assert np.abs(indep.consolidate(k[a:b], q, None, u[a:b]).numpy() - ctx_ref[a:b]).max() > 1e-3
 
 
+def _subgroup_handoff_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group(ranks=[1, 2])               # every process creates it; global rank 0 is not a member
+        if rank == 0:
+            return
+        k, q, u = _inputs()
+        a, b = shard_range(C, 2, dist.get_rank(grp))
+        ctx, mem = consolidate_video(OracleEngine(), k[a:b], q, None, u[a:b], group=grp, handoff=True)
+        ret[rank] = (ctx.numpy(), mem.B.numpy(), mem.count.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_handoff_inside_a_subgroup_whose_ranks_are_not_the_global_ones():
+    """The chain state travels between GROUP ranks 0 -> 1, which are global ranks 1 -> 2 here: send / recv take
+    global ranks, so the hand-off must translate (it went to the wrong process, or hung, before)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_handoff_worker, args=(3, port, ret), nprocs=3, join=True)
+    k, q, u = _inputs()
+    ctx_ref = OracleEngine().consolidate(k, q, None, u).numpy()
+    np.testing.assert_array_equal(np.concatenate([ret[1][0], ret[2][0]]), ctx_ref)
+    assert list(ret[2][2]) == [3.0, 3.0]
+
+
 def _qf_gather_worker(rank, world, port, out_q):
     import torch
     import torch.distributed as dist

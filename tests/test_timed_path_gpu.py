@@ -158,9 +158,11 @@ def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
     budget = max(4, int(4e-5 * n_chunks * L * S))
     ref, flips = _check_against_chain(dev, fast, k, q, projs, u, ctx, bins_all, probs_all, budget)
     print(f"[timed path] {n_chunks} chunks: {flips} of {(n_chunks - 1) * L * S} draws differ between consolidate and the per-chunk chain")
-    # the CPU oracle itself, both layers, teacher-forced to the call's traced bins: the whole call up to 256 chunks (then
-    # also final B and last scores), the first 128 chunks (three 42-chunk sub-batches) of the 2048-chunk bench call
-    n_or = n_chunks if n_chunks <= 256 else 128
+    # the CPU oracle itself, both layers, teacher-forced to the call's traced bins, over the WHOLE call (then also final B
+    # and last scores) -- including the 2048-chunk bench call (ring wrap of the workspace / R sets, the short 49th
+    # sub-batch with its split-K projection: all past chunk 128; about a minute of CPU); the bf16x6 variant of the
+    # 2048-chunk call keeps the first 128 chunks (three 42-chunk sub-batches)
+    n_or = n_chunks if (n_chunks <= 256 or not x6) else 128
     worst, oflips = _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast if n_or == n_chunks else None)
     print(f"[timed path] {n_chunks} chunks vs the CPU oracle over {n_or}: max |ctx diff| {worst:.2e}, {oflips} draws differ")
 
