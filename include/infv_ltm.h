@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define INFV_LTM_ABI_VERSION 2
+#define INFV_LTM_ABI_VERSION 3
 #define INFV_LTM_MAX_LAYERS 8
 
 typedef enum {
@@ -138,6 +138,27 @@ typedef struct {
     const int32_t* uniform_box2;      /* [S][2]        boxes of the non-sticky resample positions (:153-157,212)     */
 } infv_ltm_dense_plan;
 int infv_ltm_set_dense_plan(infv_ltm_handle h, const infv_ltm_dense_plan* plan);
+
+/* General-psi plan of chunk length T, on top of its dense plan: a basis family whose psi(t) is a dense row -- the reference's
+ * GaussianBasisFunctions (basis_functions.py:135-164, built by add_gaussian_basis_functions,
+ * long_term_attention_gibbs.py:167-174).  Besides the dense ridge operators (infv_ltm_set_dense_plan: compute_G :68-84) the
+ * step then needs psi itself wherever the reference evaluates it (batch_evaluate / evaluate):
+ *   psi_edge    at the modified histogram edges (update_inf :197-200 -> score :224-230): the sticky density
+ *   psi_bin     at the unmodified left edge of every bin, ts = bins[b] (:207-208): the resampled rows B_past^T psi(ts)
+ *   psi_uniform at the non-sticky resample positions (get_basis :153-157, used at :212)
+ *   psi_grid    on linspace(0, 1, n_grid) with the trapezoid weights grid_w (expected_value :251-286): the read-out
+ * Steps of that length take the per-call path with dense contractions for all of these (ltm_psi.hip).  All arrays are
+ * host pointers, copied. */
+typedef struct {
+    int32_t T;
+    int32_t n_grid;                   /* points of the read-out grid (1000, long_term_attention_gibbs.py:251) */
+    const float* psi_edge;            /* [n_bins+1][N] */
+    const float* psi_bin;             /* [n_bins][N]   */
+    const float* psi_uniform;         /* [S][N]        */
+    const float* psi_grid;            /* [n_grid][N]   */
+    const float* grid_w;              /* [n_grid]      */
+} infv_ltm_psi_plan;
+int infv_ltm_set_psi_plan(infv_ltm_handle h, const infv_ltm_psi_plan* plan);
 
 /* new_doc=True (long_term_attention_gibbs.py:300-302): forget the memory. */
 int infv_ltm_reset(infv_ltm_handle h);

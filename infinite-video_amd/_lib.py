@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _WHICH = os.environ.get("INFV_LTM_LIBRARY", "")
 LIB_PATH = (os.path.join(_HERE, "libinfv_ltm_exp.so") if _WHICH == "exp" else
             (_WHICH if _WHICH else os.path.join(_HERE, "libinfv_ltm.so")))
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LAYERS = 8
 
 i32p = C.POINTER(C.c_int32)
@@ -47,6 +47,13 @@ class PlanStruct(C.Structure):
         ("n_bins", C.c_int32),
         ("edge_box", i32p), ("edge_dx", f32p), ("bin_box", i32p),
         ("uniform_idx", i32p),
+    ]
+
+
+class PsiPlanStruct(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("n_grid", C.c_int32),
+        ("psi_edge", f32p), ("psi_bin", f32p), ("psi_uniform", f32p), ("psi_grid", f32p), ("grid_w", f32p),
     ]
 
 
@@ -101,6 +108,7 @@ _SIGNATURES = {
     "infv_ltm_destroy": (C.c_int, [C.c_void_p]),
     "infv_ltm_set_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanStruct)]),
     "infv_ltm_set_dense_plan": (C.c_int, [C.c_void_p, C.POINTER(DensePlanStruct)]),
+    "infv_ltm_set_psi_plan": (C.c_int, [C.c_void_p, C.POINTER(PsiPlanStruct)]),
     "infv_ltm_has_plan": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_reset": (C.c_int, [C.c_void_p]),
     "infv_ltm_has_memory": (C.c_int, [C.c_void_p]),

@@ -177,6 +177,67 @@ class Plan:
     bin_box2: np.ndarray = None       # [NB_BINS, 2]
     edge_box2: np.ndarray = None      # [NB_BINS + 1, 2]
     uniform_box2: np.ndarray = None   # [S, 2]
+    # general-psi form (a basis family whose psi(t) is a dense row: the Gaussian family): infv_ltm_set_psi_plan
+    psi: bool = False
+    psi_edge: np.ndarray = None       # [NB_BINS + 1, N]  psi at the modified histogram edges
+    psi_bin: np.ndarray = None        # [NB_BINS, N]      psi at the unmodified left edge of every bin
+    psi_uniform: np.ndarray = None    # [S, N]            psi at the non-sticky resample positions
+    psi_grid: np.ndarray = None       # [GRID_POINTS, N]  psi on the read-out grid
+    grid_w: np.ndarray = None         # [GRID_POINTS]     trapezoid weights of that grid
+
+
+def gaussian_psi(t: torch.Tensor, N: int, sigmas) -> torch.Tensor:
+    """psi(t) [M, N] of the reference's Gaussian family: centres x widths as ``add_gaussian_basis_functions`` builds them
+    (long_term_attention_gibbs.py:167-174), values as ``GaussianBasisFunctions.evaluate`` / ``batch_evaluate`` compute them
+    (basis_functions.py:155-164: the same fp32 elementwise sequence (t - mu) / sigma -> phi -> / sigma in both)."""
+    import math
+    mu, sigma = torch.meshgrid(torch.linspace(0, 1, N // len(sigmas)), torch.Tensor(list(sigmas)), indexing="ij")
+    mu, sigma = mu.flatten().unsqueeze(0), sigma.flatten().unsqueeze(0)
+    if mu.size(1) != N:
+        raise UnsupportedBasis("num_basis must be a multiple of len(sigmas)")
+    z = (t.to(torch.float32).reshape(-1, 1) - mu) / sigma
+    return (1. / math.sqrt(2 * math.pi) * torch.exp(-.5 * z ** 2)) / sigma
+
+
+@lru_cache(maxsize=64)
+def build_gaussian_plan(T: int, N: int, tau: float, sigmas: Tuple[float, ...], S: int = NB_SAMPLES) -> Plan:
+    """Plan of the reference's GAUSSIAN basis family for chunks of T frames: dense ridge operators (compute_G,
+    long_term_attention_gibbs.py:68-84, with the reference's own ATen sequence) and psi itself at every point the step
+    evaluates it -- histogram edges (:197-200), the bins' left edges (:207-208), the uniform resampling positions
+    (:153-157) and the 1000-point read-out grid with its trapezoid weights (:251-286)."""
+    if T < 2:
+        raise UnsupportedBasis("chunks of a single frame are empty in the reference (G[0:-0])")
+    sigmas = tuple(float(x) for x in sigmas)
+    bins = torch.linspace(0, 1, NB_BINS + 1)
+    mod = bins.clone()
+    mod[0] = -.000001
+    mod[-1] = 1.000001
+    edge_dx = (mod[1:] - mod[:-1]).numpy().astype(np.float32)
+    t_uni = (torch.arange(1, S + 1).float() * tau / S) / tau
+    t = torch.linspace(0, 1, GRID_POINTS)
+    dx = (t[1:] - t[:-1]).double().numpy()
+    wt = np.zeros(GRID_POINTS)
+    wt[:-1] += dx / 2
+    wt[1:] += dx / 2
+    f32 = lambda x: np.ascontiguousarray(x.numpy(), dtype=np.float32)
+    none_i = np.zeros(0, dtype=np.int32)
+    zeros_n = np.zeros(N, dtype=np.float32)
+    no_box = lambda n: np.full((n, 2), -1, dtype=np.int32)
+    return Plan(
+        T=T, N=N, tau=tau, S=S,
+        # neither the sparse operator tables nor the box tables apply to a dense psi: empty but valid
+        first_row_box=none_i, first_row_begin=none_i, first_row_end=none_i, first_box_val=zeros_n,
+        inf_row_box=none_i, inf_row_begin=none_i, inf_row_end=none_i, inf_box_val=zeros_n,
+        inf_old_ptr=np.zeros(N + 1, dtype=np.int32), inf_old_slot=none_i,
+        readout_w=zeros_n, readout_w_out=1.0,
+        edge_box=np.full(NB_BINS + 1, -1, np.int32), edge_dx=edge_dx, bin_box=np.zeros(NB_BINS, np.int32),
+        uniform_idx=np.full(S, -1, np.int32),
+        dense=True, first_GT=gaussian_operator_T(T, _positions_first(T), N, sigmas),
+        inf_GT=gaussian_operator_T(S + T, _positions_inf(T, tau, S), N, sigmas),
+        bin_box2=no_box(NB_BINS), edge_box2=no_box(NB_BINS + 1), uniform_box2=no_box(S),
+        psi=True, psi_edge=f32(gaussian_psi(mod, N, sigmas)), psi_bin=f32(gaussian_psi(bins[:-1], N, sigmas)),
+        psi_uniform=f32(gaussian_psi(t_uni, N, sigmas)), psi_grid=f32(gaussian_psi(t, N, sigmas)),
+        grid_w=wt.astype(np.float32))
 
 
 def gaussian_operator_T(l: int, positions: torch.Tensor, N: int, sigmas) -> np.ndarray:

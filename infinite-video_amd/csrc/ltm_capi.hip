@@ -66,6 +66,10 @@ struct DensePlan {
     int first_K = 0, inf_K = 0;
     DeviceBuf first_GT, inf_GT;        // [N][K]
     DeviceBuf bin_box2, edge_box2, uniform_box2;
+    // general-psi plan (infv_ltm_set_psi_plan): psi where the reference evaluates it, and the step's scratch
+    bool psi_on = false;
+    int n_grid = 0;
+    DeviceBuf psi_edge, psi_bin, psi_uniform, psi_grid, grid_w;
 };
 
 struct Plan {
@@ -75,7 +79,7 @@ struct Plan {
     DeviceBuf w, edge_box, edge_dx, bin_box, uniform_idx;
     float w_out = 0.f;
     int n_bins = 0;
-    bool points_ok = false;            // the histogram edges are the bins' left edges (what chain_batch2_kernel assumes)
+    bool points_ok = false;            // the histogram edges are the bins' left edges (what chain_batch3_kernel assumes)
     StickyView sticky() const {
         StickyView s;
         s.points_ok = points_ok ? 1 : 0;
@@ -156,7 +160,7 @@ struct infv_ltm_s {
     DeviceBuf Sp[2], cqbuf;
     DeviceBuf qt_buf;                  // fast path: pre-multiplied queries qt[(l*H+h)*Q+q][d] of the current call
     DeviceBuf alpha_ring, asum_ring, tab_ring;   // per-chunk outputs of role S for the UC kernel: ring of 2*maxC+2 slots
-    DeviceBuf crit_ring, tabb_ring;              // chain_batch2_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
+    DeviceBuf crit_ring, tabb_ring;              // chain_batch3_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
     hipStream_t chain_s = nullptr;      // CU-mask experiment: role S's own (masked) stream, else nullptr
@@ -178,7 +182,11 @@ struct infv_ltm_s {
     int spin_limit = 1 << 22; int expect_extra = 0;     // INFV_CHAIN_FAULT=1 (tests): expect one arrival too many -> every wait times out
     int32_t* trace_bins = nullptr; float* trace_probs = nullptr; long trace_cap = 0;   // draw trace of consolidate (caller's device buffers)
     DeviceBuf bins_forced; unsigned forced_mask = 0;    // one-shot forced draw of the per-call path
-    DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][128] u64, ring of 3 (read / accumulate / being cleared)
+    DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][kAccShards][128] u64, ring of 3 (read / accumulate / being cleared)
+    DeviceBuf uf_all;                  // a consolidate call's Gibbs uniforms as fp32 round-ups [n_chunks][L][S] (chain_batch3_kernel's search)
+    DeviceBuf psi_Y, psi_E, psi_Eg, psi_alpha;   // general-psi step: resampled rows, edge scores, grid scores / probabilities, read-out weights
+    DeviceBuf mbox;                    // chain_batch3_kernel: mailboxes of role S's exchange + placement handshake (chain_mailbox_bytes)
+    int mbox_G = 0;                    // workgroups per layer the mailboxes are laid out for
     int sc = 0;
     int n_bins = 128;
     Profiler prof;
@@ -343,7 +351,21 @@ int dense_step(infv_ltm_handle h, const Plan& plan, const float* kbar, int T, co
         pos_box2 = dp.bin_box2.as<int32_t>();
     }
     const int nxt = h->cur ^ 1;
-    {
+    if (dp.psi_on) {
+        // psi(t) is a dense row: the resampled rows are rows of Y = Psi_pos . B_past (128 positions when sticky, S otherwise)
+        Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
+        const bool use_bins = bins != nullptr;
+        const int n_pos = use_bins ? h->n_bins : h->S;
+        if (inf) {
+            HIP_TRY(h->psi_Y.reserve((size_t)h->L * n_pos * h->d * sizeof(float)));
+            HIP_TRY(launch_psi_gemm(false, use_bins ? dp.psi_bin.as<float>() : dp.psi_uniform.as<float>(), h->N, 0,
+                                    h->B[h->cur].as<float>(), h->d, (long)h->N * h->d, h->psi_Y.as<float>(), h->d, (long)n_pos * h->d,
+                                    n_pos, h->d, h->N, h->L, stream));
+        }
+        HIP_TRY(launch_psi_update(inf ? dp.inf_GT.as<float>() : dp.first_GT.as<float>(), inf ? dp.inf_K : dp.first_K,
+                                  inf ? dp.inf_K : dp.first_K, inf ? h->S : 0, bins, bins_stride, h->psi_Y.as<float>(), n_pos, kbar,
+                                  h->B[nxt].as<float>(), h->N, h->d, h->L, stream));
+    } else {
         Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
         HIP_TRY(launch_dense_update(inf ? dp.inf_GT.as<float>() : dp.first_GT.as<float>(), inf ? dp.inf_K : dp.first_K,
                                     inf ? dp.inf_K : dp.first_K, inf ? h->S : 0, bins, bins_stride, pos_box2,
@@ -357,9 +379,29 @@ int dense_step(infv_ltm_handle h, const Plan& plan, const float* kbar, int T, co
         Timed t_(h->prof, INFV_KERNEL_ATTEND, stream);
         HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
                               plan.sticky(), ctx, h->bin_part[h->pc].as<float>(), h->scores.as<float>(), stream));
+        if (dp.psi_on) {
+            // the attend kernel above supplied the scores S = q K^T / sqrt(dh); its read-out and masses assume boxes.  Dense forms:
+            const long rows_hq = (long)h->L * h->H * Q;
+            const int ldE = h->n_bins + 4, ldG = (dp.n_grid + 3) & ~3;
+            HIP_TRY(h->psi_E.reserve((size_t)rows_hq * ldE * sizeof(float)));
+            HIP_TRY(h->psi_Eg.reserve((size_t)rows_hq * ldG * sizeof(float)));
+            HIP_TRY(h->psi_alpha.reserve((size_t)rows_hq * h->N * sizeof(float)));
+            // edge scores z(t_j) = sum_n S[n] psi_n(t_j) -> sticky masses (LTM.py:197-203,224-230)
+            HIP_TRY(launch_psi_gemm(true, h->scores.as<float>(), h->N, 0, dp.psi_edge.as<float>(), h->N, 0, h->psi_E.as<float>(), ldE, 0,
+                                    (int)rows_hq, h->n_bins + 1, h->N, 1, stream));
+            HIP_TRY(launch_psi_masses(h->psi_E.as<float>(), ldE, Q, h->H, h->L, plan.edge_dx.as<float>(), h->bin_part[h->pc].as<float>(), stream));
+            // read-out on the 1000-point grid (LTM.py:251-286): z -> w o prob -> alpha = (w o prob) . Psi_grid -> ctx = alpha . (V' + bv)
+            HIP_TRY(launch_psi_gemm(true, h->scores.as<float>(), h->N, 0, dp.psi_grid.as<float>(), h->N, 0, h->psi_Eg.as<float>(), ldG, 0,
+                                    (int)rows_hq, dp.n_grid, h->N, 1, stream));
+            HIP_TRY(launch_psi_grid(h->psi_Eg.as<float>(), ldG, dp.n_grid, rows_hq, dp.grid_w.as<float>(), stream));
+            HIP_TRY(launch_psi_gemm(false, h->psi_Eg.as<float>(), ldG, 0, dp.psi_grid.as<float>(), h->N, 0, h->psi_alpha.as<float>(), h->N, 0,
+                                    (int)rows_hq, h->N, dp.n_grid, 1, stream));
+            HIP_TRY(launch_psi_ctx(h->psi_alpha.as<float>(), h->KV[h->cur].as<float>(), pp, Q, h->N, h->H, h->dm / h->H, h->L, ctx, stream));
+        } else {
         // the attend kernel's partials assume one box per edge: recompute them from the scores with the two-box table
         HIP_TRY(launch_dense_masses(h->scores.as<float>(), Q, h->N, h->H, h->L, dp.edge_box2.as<int32_t>(),
                                     plan.edge_dx.as<float>(), h->bin_part[h->pc].as<float>(), stream));
+        }
     }
     h->parts = h->H;
     h->lastQ = Q;
@@ -441,7 +483,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
         if (e == hipSuccess) e = h->Sp[i].reserve(nsq * sizeof(float));
     }
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        e = h->mass_acc[i].reserve((size_t)h->L * 128 * sizeof(unsigned long long));
+        e = h->mass_acc[i].reserve((size_t)h->L * kAccShards * 128 * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemset(h->mass_acc[i].p, 0, h->mass_acc[i].bytes);
     }
     if (e == hipSuccess) e = h->sync_words.reserve(16 * sizeof(unsigned int));
@@ -543,6 +585,25 @@ int infv_ltm_set_dense_plan(infv_ltm_handle h, const infv_ltm_dense_plan* p) {
     HIP_TRY(upload(d.uniform_box2, p->uniform_box2, (size_t)2 * h->S));
     d.first_K = p->first_K; d.inf_K = p->inf_K;
     d.on = true;
+    return INFV_OK;
+}
+
+int infv_ltm_set_psi_plan(infv_ltm_handle h, const infv_ltm_psi_plan* p) {
+    if (int rc = check_handle(h)) return rc;
+    if (!p || !p->psi_edge || !p->psi_bin || !p->psi_uniform || !p->psi_grid || !p->grid_w || p->n_grid < 2)
+        return fail(INFV_ERR_INVALID, "psi plan: null argument");
+    Plan* plan = nullptr;
+    if (int rc = find_plan(h, p->T, &plan)) return rc;
+    DensePlan& d = plan->dense;
+    if (!d.on) return fail(INFV_ERR_STATE, "psi plan: set the dense plan of T=%d first (infv_ltm_set_dense_plan)", p->T);
+    HIP_TRY(hipDeviceSynchronize());                            // a step of this length may still be reading the old tables
+    HIP_TRY(upload(d.psi_edge, p->psi_edge, (size_t)(h->n_bins + 1) * h->N));
+    HIP_TRY(upload(d.psi_bin, p->psi_bin, (size_t)h->n_bins * h->N));
+    HIP_TRY(upload(d.psi_uniform, p->psi_uniform, (size_t)h->S * h->N));
+    HIP_TRY(upload(d.psi_grid, p->psi_grid, (size_t)p->n_grid * h->N));
+    HIP_TRY(upload(d.grid_w, p->grid_w, (size_t)p->n_grid));
+    d.n_grid = p->n_grid;
+    d.psi_on = true;
     return INFV_OK;
 }
 
@@ -730,7 +791,7 @@ struct FastPipe {
     size_t asum_slot() const { return (size_t)h->L * h->H * Q; }
     size_t tab_slot() const { return (size_t)h->L * h->N * 16; }
     size_t crit_slot() const { return (size_t)h->L * h->H * Q * 128; }
-    bool last_v2 = false;            // the last persistent launch ran chain_batch2_kernel (scores rebuilt by alpha_rows2)
+    bool last_v2 = false;            // the last persistent launch ran chain_batch3_kernel (scores rebuilt by alpha_rows2)
     const float* last_snew = nullptr; int last_sk = 1; long last_ss = 0; float* last_sp_out = nullptr; int batch_launches = 0;
 
     int launch_s(const StepS& st) {
@@ -794,7 +855,8 @@ struct FastPipe {
     }
 
     // role S of `n` consecutive infinite-memory chunks in one persistent launch
-    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u) {
+    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u, const float* uf) {
+        static int prev_n = 0;                     // (experiments: steps of the previous launch, for the stamps' average)
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
         const int QS = chain_s_tiles(Q);
@@ -808,6 +870,19 @@ struct FastPipe {
         }
         b.n_steps = n; b.step0 = counter; b.ring = h->ring;
         b.first_from_parts = (counter == 0) ? 1 : 0;
+        b.first_from_acc = (counter > 0 && batch_launches == 0) ? 1 : 0;   // the step before ran in a per-chunk launch (first chunk of a document)
+        b.mbox = h->mbox.as<unsigned long long>();
+        { static int* rep = [] { int* p = nullptr; if (exp_env("INFV_XCC_REPORT")) { (void)hipMalloc(&p, 1024 * sizeof(int)); (void)hipMemset(p, 0xff, 1024 * sizeof(int)); } return p; }();
+          b.xcc_report = rep;
+          static int rep_calls = 0;
+          if (rep && (++rep_calls % 16) == 0) {
+              int hb[1024];
+              (void)hipStreamSynchronize(stream);
+              (void)hipMemcpy(hb, rep, sizeof(hb), hipMemcpyDeviceToHost);
+              fprintf(stderr, "[batch-S placement] (plain<<8 | xcc) per workgroup:");
+              for (int i = 0; i < 1024 && hb[i] != -1; ++i) fprintf(stderr, " %x", hb[i]);
+              fprintf(stderr, "\n");
+          } }
         b.part_prev = h->bin_part[h->pc].as<float>(); b.parts = h->parts;
         for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
         b.arrive = h->sync_words.as<unsigned int>(); b.error = h->err_dev;
@@ -819,7 +894,7 @@ struct FastPipe {
             b.bins_tr = h->trace_bins ? h->trace_bins + (size_t)counter * h->L * h->S : nullptr;
         }
         b.probs_override = h->probs_override.as<float>(); b.override_mask = h->override_mask;
-        b.u = u; b.uniform_idx = plan.uniform_idx.as<int32_t>();
+        b.u = u; b.uf = uf; b.uniform_idx = plan.uniform_idx.as<int32_t>();
         b.probs_out = h->probs.as<float>(); b.bins_out = h->bins.as<int32_t>(); b.idx_out = h->idx.as<int32_t>();
         b.tab_ring = h->tab_ring.as<int32_t>(); b.tab_slot = (long)tab_slot();
         b.tabb_ring = h->tabb_ring.as<int32_t>();
@@ -831,11 +906,11 @@ struct FastPipe {
         b.Snew = Snew; b.snew_ld = h->L * h->dm + h->L * h->H * Q; b.snew_splitk = sk; b.snew_split_stride = ss;
         b.cq = h->cqbuf.as<float>(); b.w = plan.w.as<float>(); b.w_out = plan.w_out;
         {
-            static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 16 * sizeof(long long)); (void)hipMemset(p, 0, 16 * sizeof(long long)); } return p; }();
+            static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_CHAIN_STAMPS")) { (void)hipMalloc(&p, 32 * sizeof(long long)); (void)hipMemset(p, 0, 32 * sizeof(long long)); } return p; }();
             b.dbg = dbg;
             static int calls = 0;
             if (dbg && (++calls % 8) == 0) {
-                long long hb[16];
+                long long hb[32];
                 (void)hipStreamSynchronize(stream);
                 (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[batch-S stamps x10ns] wait+read %lld draw %lld tab %lld recurrence %lld row-phase+add %lld - %lld alpha-out %lld | step %lld\n",
@@ -843,6 +918,8 @@ struct FastPipe {
                 // shader cycles of the same step (s_memtime): cycles / (10 ns ticks) = effective clock in units of 100 MHz
                 fprintf(stderr, "[batch-S clock] step %lld shader cycles over %lld x10ns -> %.2f GHz\n", hb[15] - hb[8], hb[7] - hb[0],
                         (hb[7] - hb[0]) > 0 ? 0.1 * (double)(hb[15] - hb[8]) / (double)(hb[7] - hb[0]) : 0.0);
+                if (prev_n > 2) fprintf(stderr, "[batch-S avg] %.3f us per step over steps 1..%d of the previous launch\n",
+                                        0.01 * (double)(hb[17] - hb[16]) / (prev_n - 2), prev_n - 1);
             }
         }
         {
@@ -850,6 +927,7 @@ struct FastPipe {
             if (!(skip_mask() & 8)) HIP_TRY(launch_chain_batch(b, stream));
         }
         last_v2 = chain_batch2_applies(b);
+        prev_n = n;
         last_snew = Snew; last_sk = sk; last_ss = ss; last_sp_out = b.Sp_out;
         ++batch_launches;
         if (b.draw_mode == 1) h->override_mask = 0;
@@ -864,7 +942,7 @@ struct FastPipe {
     int launch_alpha(int n, long slot0, hipStream_t s, bool last_batch) {
         if (skip_mask() & 4) return INFV_OK;
         if (last_v2) {
-            // chain_batch2_kernel published point scores + drawn bins: rebuild the full score rows, then the weights
+            // chain_batch3_kernel published point scores + drawn bins: rebuild the full score rows, then the weights
             AlphaRows2Args r;
             memset(&r, 0, sizeof(r));
             r.N = h->N; r.H = h->H; r.Q = Q; r.L = h->L; r.rows = plan.inf.rows; r.tabw = plan.inf.tabw; r.n_steps = n;
@@ -1145,6 +1223,23 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         h->w3_valid = true;
     }
     HIP_TRY(hipEventRecord(h->ev_q, stream));                 // the side stream's projections need no more than this
+    // the persistent role S searches in fp32 against the round-ups of the f64 uniforms (equivalent to the f64 compare):
+    // converted once per call, off the chain
+    const float* uf = nullptr;
+    if (u && h->cfg.sticky && chain_batch3_shape_ok(1, plan->sticky().points_ok, plan->inf.rows, h->S, Q)) {
+        const size_t need_u = (size_t)n_chunks * chunk_u * sizeof(float);
+        if (need_u > h->uf_all.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->uf_all.reserve(need_u)); }
+        HIP_TRY(launch_round_up_uniforms(u, h->uf_all.as<float>(), (long)n_chunks * (long)chunk_u, stream));
+        uf = h->uf_all.as<float>();
+        if (chain_batch3_mailboxes()) {
+            // (experiments) mailboxes of role S's exchange: zeroed per call (step tags restart with the call's chunk counter)
+            const int G = chain_batch_blocks(h->H, Q, h->L, 1, plan->sticky().points_ok, plan->inf.rows, h->S) / h->L;
+            const size_t need_m = chain_mailbox_bytes(h->L, G);
+            if (need_m > h->mbox.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->mbox.reserve(need_m)); }
+            h->mbox_G = G;
+            HIP_TRY(hipMemsetAsync(h->mbox.p, 0, need_m, stream));
+        }
+    }
     int c = 0;
     bool uc_pending[kPSets] = {};               // ev_uc[set] has been recorded in this call
     if (!h->has_memory) {                                     // first chunk of a document: first-chunk operator, set 1
@@ -1222,13 +1317,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // stream, and the pooling stream runs up to kRSets sub-batches ahead instead of three.  Measured in situ (round 3,
     // tools/sweep_r03s.sh, alternating on one box): 132.5 k against 130.5 k chunks/s, pooling stream 14.65 against 15.05 ms.
     // The experiments build keeps INFV_POOL_ROWS=0 (pool_frames_kernel + build_rows_kernel, the round-2 form, still used when
-    // frame means are handed in or the width has no pool_rows2 shape) and =1 (pool_rows_kernel: long-lived grid-stride
-    // workgroups stream faster alone, 218-270 us per launch against 304, but cost the chain launches their CUs: 116-121 k).
+    // frame means are handed in or the width has no pool_rows2 shape).  (Round 3's long-lived grid-stride form, pool_rows_kernel,
+    // streamed faster alone -- 218-270 us per launch against 304 -- but cost the chain launches their CUs, 116-121 k: deleted.)
     static const int pr_env = [] { const char* e = exp_env("INFV_POOL_ROWS"); return e ? atoi(e) : 2; }();
     const bool use_pr2 = pr_env == 2 && !kbar_pre && pool_rows2_supported(h->d);
-    const bool use_pr = (pr_env == 1 && !kbar_pre && pool_rows_supported(h->P, h->d)) || use_pr2;
+    const bool use_pr = use_pr2;
     static const int pr_u = [] { const char* e = exp_env("INFV_PR_U"); return e ? atoi(e) : 8; }();
-    static const int pr_nt = [] { const char* e = exp_env("INFV_PR_NT"); return e ? atoi(e) : 512; }();
     static const int pr_pad = [] { const char* e = exp_env("INFV_PR_PAD"); return e ? atoi(e) : 84 * 1024; }();
     static const int pr_wgs = [] { const char* e = exp_env("INFV_PR_WGS"); return e ? atoi(e) : 0; }();
     if (!kbar_pre && !use_pr) {
@@ -1256,12 +1350,8 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
             if (!(skip_mask() & 1)) {
                 Timed t_(h->prof, INFV_KERNEL_POOL, pools);
-                if (use_pr2)
-                    HIP_TRY(launch_pool_rows2(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
-                                              pools, pr_u, pr_pad, pr_wgs));
-                else
-                    HIP_TRY(launch_pool_rows(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
-                                             pools, pr_u, pr_nt, pr_pad, pr_wgs));
+                HIP_TRY(launch_pool_rows2(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
+                                          pools, pr_u, pr_pad, pr_wgs));
             }
             if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
             return INFV_OK;
@@ -1329,7 +1419,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                 if (int rc = stage_parallel(b + 1)) return rc;
             if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); }
             if (int rc = pipe.launch_s_batch(nb, h->P_ws[set].as<float>() + (size_t)h->L * h->dm, sks[b], sss[b],
-                                             u ? u + (size_t)c0 * chunk_u : nullptr)) return rc;
+                                             u ? u + (size_t)c0 * chunk_u : nullptr, uf ? uf + (size_t)c0 * chunk_u : nullptr)) return rc;
             if (serial) HIP_TRY(hipStreamSynchronize(ls));
         } else {
             for (int i = 0; i < nb; ++i) {
@@ -1405,8 +1495,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     for (int i = 0; i < kPSets; ++i)
         if (uc_pending[i]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[i], 0));
     if (pipe.counter > 0) {
-        HIP_TRY(launch_acc_to_part(h->mass_acc[(pipe.counter + 2) % 3].as<unsigned long long>(), h->L, 1,
-                                   h->bin_part[h->pc].as<float>(), stream));
+        if (pipe.last_v2 && pipe.batch_launches > 0 && chain_batch3_mailboxes())   // (experiments) the last step's totals are in the mailboxes
+            HIP_TRY(launch_mailbox_to_part(h->mbox.as<unsigned long long>(), h->L, h->mbox_G, (int)((pipe.counter - 1) & 1), 1,
+                                           h->bin_part[h->pc].as<float>(), stream));
+        else
+            HIP_TRY(launch_acc_to_part(h->mass_acc[(pipe.counter + 2) % 3].as<unsigned long long>(), h->L, 1,
+                                       h->bin_part[h->pc].as<float>(), stream));
         h->parts = 1;
     }
     h->k_stale = true;                                        // K' is re-projected from B on demand (per-call path, continuation)

@@ -195,9 +195,10 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         DrawRegs<1> dr;
         if (rs.draw_mode == 1)
             dr = draw_load<kNT, 1>(rs.part_prev + (long)l * rs.parts * kBins, rs.parts,
-                                   rs.acc_prev ? rs.acc_prev + l * kBins : nullptr, rs.probs_override + l * kBins,
+                                   rs.acc_prev ? rs.acc_prev + (long)l * kAccShards * kBins : nullptr, rs.probs_override + l * kBins,
                                    (rs.override_mask >> l) & 1u, rs.u + (long)l * a.S, a.S);
-        if (writer && tid < kBins) rs.acc_clear[l * kBins + acc_word(tid)] = 0ull;   // ring slot of the NEXT launch: idle now
+        if (writer)                                                                  // ring slot of the NEXT launch: idle now
+            for (int e = tid; e < kAccShards * kBins; e += kNT) rs.acc_clear[(long)l * kAccShards * kBins + e] = 0ull;
         int uni = -1;
         if (rs.draw_mode == 2 && tid < a.S) uni = rs.uniform_idx[tid];
         // ---- park the prologue in LDS ----
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kNT) void chain_kernel(ChainArgs a) {
         __syncthreads();
         STAMP(3);
         row_phase_wave(Ssm, sstride, N, valid, lds + m.w, rs.w_out, reinterpret_cast<const int32_t*>(lds + m.edge_box),
-                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, rs.acc_next + l * kBins, kRowsS);
+                       lds + m.edge_dx, lds + m.Dsm, lds + m.Msm, asum, nullptr, rs.acc_next + (long)l * kAccShards * kBins, kRowsS);
         STAMP(4);
         // alpha_k and its row sums for role C two launches later
         if (wave < valid) {
@@ -335,7 +336,10 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
 namespace infv {
 __global__ void acc_to_part_kernel(const unsigned long long* __restrict__ acc, int parts_pitch, float* __restrict__ part) {
     const int l = blockIdx.x, j = threadIdx.x;
-    if (j < kBins) part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)mass_of(acc[l * kBins + acc_word(j)]) : 0.f;
+    if (j >= kBins) return;
+    unsigned long long tot = 0ull;                                   // integer sum over the replicas: the exact total
+    for (int r = 0; r < kAccShards; ++r) tot += acc[((long)l * kAccShards + r) * kBins + acc_word(j)] & kMassMask;
+    part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)mass_of(tot) : 0.f;
 }
 hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream) {
     hipLaunchKernelGGL(acc_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, acc, parts_pitch, part);

@@ -52,27 +52,6 @@ __host__ __device__ inline BatchSmem batch_smem(int N, int S, int rows, int tabw
 
 __device__ inline unsigned long long coherent_read(unsigned long long* p) { return atomicAdd(p, 0ull); }
 
-// Poll of a layer's accumulator words by one wave: lane i reads words (2 i, 2 i + 1) = bins (i, i + 64) (acc_word) with ONE
-// 16-byte buffer load that bypasses the vector L1 and is served past the XCD's L2 (sc1).  The words are only ever written
-// by device-scope atomics, which execute at the memory side and leave no line behind in any L2, so the load sees every add
-// that has completed; an aligned 8-byte half never tears.  (Round 2 polled with returning atomicAdd(p, 0): correct too,
-// but every poll then serialises at the memory side with the deposits and the other workgroups' polls of the same word --
-// ~12 ns each, 24-48 workgroups, several polls per step.)  A stale or torn read could only delay the arrival count: the
-// waits are bounded and report through the error word.
-typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
-__device__ inline void poll_pair(const unsigned long long* layer_words, int lane, unsigned long long& w0, unsigned long long& w1) {
-#ifdef INFV_POLL_ATOMIC                                      /* A/B builds only: round 2's returning-atomic poll */
-    unsigned long long* p = const_cast<unsigned long long*>(layer_words);
-    w0 = atomicAdd(p + 2 * lane, 0ull);
-    w1 = atomicAdd(p + 2 * lane + 1, 0ull);
-    return;
-#endif
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(layer_words), 0, kBins * 8, 0x00020000);
-    const uintx4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 16 /* sc1 */);
-    w0 = ((unsigned long long)v.y << 32) | v.x;
-    w1 = ((unsigned long long)v.w << 32) | v.z;
-}
-
 __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __builtin_amdgcn_s_setprio(3);
@@ -156,9 +135,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
     const int ring_n = (int)a.ring;
     for (int i = 0; i < a.n_steps; ++i) {
         BSTAMP(0);
-        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;      // (g + 2) % 3
-        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
-        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;      // (g + 1) % 3
+        // this kernel adds into replica 0 of a layer's accumulators (ltm_internal.h: kAccShards)
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + (long)l * kAccShards * kBins;      // (g + 2) % 3
+        unsigned long long* acc_cur = a.acc[g3] + (long)l * kAccShards * kBins;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + (long)l * kAccShards * kBins;      // (g + 1) % 3
         const long slot = slot_run;
         if (++g3 == 3) g3 = 0;
         if (++slot_run == ring_n) slot_run = 0;
@@ -183,9 +163,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
                 }
             }
             mass_prev = mass_of(v);
+            // totals completed by an earlier launch may sit in the other replicas (chain_batch3_kernel)
+            if (i == 0)
+                for (int r = 1; r < kAccShards; ++r) mass_prev += mass_of(coherent_read(acc_prev + r * kBins + acc_word(tid)));
         }
         BSTAMP(1);
-        if (writer && tid < kBins) atomicExch(acc_clr + acc_word(tid), 0ull);      // slot of the NEXT step: idle until then
+        if (writer)                                                                  // slot of the NEXT step: idle until then
+            for (int e = tid; e < kAccShards * kBins; e += kBNT) atomicExch(acc_clr + e, 0ull);
         // ---- draw ----
         if (a.draw_mode == 1) {
             const bool ovr = (i == 0) && ((a.override_mask >> l) & 1u);
@@ -289,53 +273,41 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
 }
 
 // ======================================================================================================
-// chain_batch2_kernel: the same role S with only the truly sequential work on the chain.
+// chain_batch3_kernel: the same role S with only the truly sequential work on the chain.
 //
 // A step's draw needs the bin masses of the previous step, which need the scores at the 127 interior edges
 // of the sticky histogram, which are the scores of the boxes holding the bins' left edges -- the same boxes the
 // resampling reads (LTM.py:207-208: ts = bins[b]).  So the recurrence only ever feeds back through the 128
 // "points" j = 0..127 (left edge of bin j, box pb[j] = bin_box[j]); every other box is a pure output, rebuilt
 // later, chunk-parallel, by alpha_rows2_kernel from what this kernel publishes per step: the point scores and the
-// table of drawn bins.  Eight waves, wave r owns query row r.  Per step:
+// table of drawn bins.  Eight waves, wave r owns query rows r, r + 8, ...  Per step:
 //   wave 0      poll the previous totals (the poll is issued right behind this workgroup's own deposit, one step
-//               earlier), normalise, sequential fp32 cdf (systolic DPP scan)                      -> barrier 1
+//               earlier), normalise, sequential fp32 cdf                                          -> barrier 1
 //   all waves   one lower-bound search per thread (fp32 compares against the round-up of the f64 uniform:
-//               equivalent to the f64 compare), result written straight into the gather table;
-//               wave 7 also parks the NEXT step's inputs (new-row scores, uniforms), loaded two steps ago -> barrier 2
+//               equivalent to the f64 compare), result written straight into the gather table    -> barrier 2
 //   wave = row  recurrence of the row's 128 point scores (2 per lane, state private to the wave), edge densities,
 //               trapezoid masses: all in registers, neighbours through DPP shifts                    -> barrier 3
-//   tid < 127   8-row sum, fixed-point deposit (+ arrival count); wave 0 re-arms its poll and goes round
-//   waves 1-6   publish the step (point scores of all 8 rows; the layer's writer: drawn-bin table, source-box table)
-//   wave 7      requests the inputs of step i+3.
+//   tid < 127   row sum, fixed-point deposit (+ arrival count); wave 0 re-arms its poll and goes round
+//   waves 1-6   publish the step (point scores of all rows; the layer's writer: drawn-bin table, source-box table)
+//   wave 7      parks the inputs of step i+1 (new-row scores, uniforms), requests those of step i+3.
 // vmcnt counts loads, stores and atomics in issue order, so a wave that waits for a load also waits for the
 // acknowledgement of every store it issued before -- hence the split: the poller issues no store between arming and
 // reading its poll, the storing waves load nothing, the loading wave stores nothing.  While a streaming kernel shares
 // the CU every vector-memory INSTRUCTION also queues ~0.2 us at issue: each role issues a handful per step.
 // Requires the plan's edges to be the bins' left edges (StickyView.points_ok), the sticky draw (mode 1), rows <= 128.
+// (Round 2-3: chain_batch2_kernel -- unsharded exchange, systolic DPP scan, f64 uniforms converted by the loader,
+// ping-pong score rows: 5.4-5.7 us per step.)
 // ======================================================================================================
 constexpr int kB2Ld = 4;                  // float4 pieces of the new-row score tile the loader holds per lane (2 * rows <= 64 * kB2Ld)
-struct Batch2Smem { int cdf, coarse, pos, tabb, box_val, box_row, pb, sc0, sc1, Snew, uf, Msm, total; };
 constexpr int kScPitch = kBins + 4;
+typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
 
-// rpw: query rows per wave (the workgroup's tile is 8 * rpw rows of one head)
-__host__ __device__ inline Batch2Smem batch2_smem(int N, int S, int rows, int tabw, int rpw = 1) {
-    Batch2Smem m;
-    int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    m.cdf = take(kBins);
-    m.coarse = take(16);
-    m.pos = take(S);
-    m.tabb = take(N * tabw);
-    m.box_val = take(N);
-    m.box_row = take(N);
-    m.pb = take(kBins);
-    m.sc0 = take(rpw * kBRows * kScPitch);
-    m.sc1 = take(rpw * kBRows * kScPitch);
-    m.Snew = take(2 * rpw * kBRows * (rows + 1));
-    m.uf = take(2 * S);
-    m.Msm = take(rpw * kBRows * kMPitch);
-    m.total = o;
-    return m;
+// LDS written by some lanes of this wave is read by others: release / barrier / acquire at wavefront scope (no instruction
+// beyond the waits the hardware needs anyway; it pins the compiler's ordering across divergent code)
+__device__ inline void wave_lds_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // lane i <- lane i+1; lane 63 <- fill
@@ -343,28 +315,142 @@ __device__ inline float wave_shl1(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-// RPW query rows per wave: wave w owns rows w, w + 8, ... of the workgroup's 8*RPW-row tile.  More rows per wave = fewer
-// workgroups on the chip (H * ceil(Q / (8 RPW)) per layer; each owns a whole CU by its registers) and fewer arrivals per
-// exchange; the rows of a wave are independent dependency chains that share the table reads and overlap each other's
-// LDS / DPP latencies.  Same arithmetic per row for every RPW: the results do not depend on it.
-template <int RPW>
-__global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
+// Round 4 -- what shortened the step (measured with tools/ubench/exchange.hip and the in-kernel stamps):
+//  (1) The exchange stays inside ONE XCD's L2.  Every cross-XCD form of the 127-value all-reduce over a layer's 24 workgroups
+//      costs 1.8-1.9 us per step on an idle chip -- fixed-point atomics (one word or 2-8 replicas per bin), or mailboxes
+//      written and read with sc1 -- because each hop is a trip to the memory side.  A layer's workgroups are now launched
+//      with block ids that are equal mod 8 (round-robin placement puts them on one XCD; blocks of the other residues exit
+//      at once) and exchange through MAILBOXES: every workgroup stores its 127 row sums as 8-byte {mass, step tag} granules
+//      into its own 1-KB slot with PLAIN stores (write-through L1, the line stays in that XCD's L2), every workgroup reads
+//      all slots with sc1 loads (past its L1, served by that same L2), re-reads a slot until its tags match, and adds the
+//      slots in a fixed order: 0.85 us per step in the micro-benchmark.  Placement is never assumed: at launch the
+//      workgroups of a layer publish their HW_REG_XCC_ID through sc1 granules (valid at any placement) and only if all are
+//      equal use plain stores; otherwise the same mailboxes are written with sc1 stores (cross-XCD coherent, 1.8 us).  The
+//      totals are the same fp32 sums in the same order either way, on every workgroup: placement changes speed only.
+//  (2) The uniforms arrive as fp32 round-ups (round_up_uniforms_kernel, once per call, off the chain): the loader holds
+//      24 instead of 32 registers per set and parks with two b128 stores instead of 8 conversions; it parks BEHIND
+//      barrier 3 (in the shadow of the exchange), so the search window holds nothing but the search (0.84 -> 0.52 us).
+//  (3) Row phase: the gather table holds BYTE OFFSETS into a score row, empty slots point at a zero word inside the
+//      row (fma(val, 0, acc) == acc exactly), boxes without a new row read a zero column of the S'new tile: no clamp,
+//      no compare, no select per gathered value.  The point scores are updated in place (a row is private to its
+//      wave and LDS executes a wave's operations in order), no ping-pong buffer.
+//  Not kept: the cdf as one lane's register chain through LDS (a dependent v_add_f32 costs 9.3 clocks, not 4: 127 of them
+//  plus the LDS round trips took 1970 clocks against 1670 for the systolic DPP scan, whose floor is those 9.3 + a hazard nop).
+// ======================================================================================================
+struct Batch3Smem { int cdf, coarse, part, pos, tabb, box_val, box_row, pb, sc, Snew, uf, Msm, total; };
+constexpr int kZeroPoint = kBins;          // word 128 of every score row holds 0.0f (rows have kScPitch = 132 words)
+constexpr int kPollWaves = 6;              // waves 0..5 read the mailboxes (wave 7's long-latency input requests must not sit in
+                                           // front of a poll in its vmcnt queue; wave 6 carries the writer's extra stores)
+constexpr int kPollRound = 4;              // slots per wave and round: 24 workgroups per layer = one round
+
+__host__ __device__ inline Batch3Smem batch3_smem(int N, int S, int rows, int tabw, int rpw) {
+    Batch3Smem m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.cdf = take(kBins);
+    m.coarse = take(16);
+    m.part = take(kPollWaves * kBins);
+    m.pos = take(S);
+    m.tabb = take(N * tabw);
+    m.box_val = take(N);
+    m.box_row = take(N);
+    m.pb = take(kBins);
+    m.sc = take(rpw * kBRows * kScPitch);
+    m.Snew = take(2 * rpw * kBRows * (rows + 1));
+    m.uf = take(2 * S);
+    m.Msm = take(rpw * kBRows * kMPitch);
+    m.total = o;
+    return m;
+}
+
+// uf[i] = the smallest float >= u[i]:  (double)c < u  <=>  c < uf  for every float c (the search compares in fp32)
+__global__ void round_up_uniforms_kernel(const double* __restrict__ u, float* __restrict__ uf, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = u[i];
+    float f = (float)x;
+    if ((double)f < x) f = __int_as_float(__float_as_int(f) + 1);
+    uf[i] = f;
+}
+
+hipError_t launch_round_up_uniforms(const double* u, float* uf, long n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(round_up_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, uf, n);
+    return hipGetLastError();
+}
+
+// ---- mailboxes of the exchange (ChainBatchArgs.mbox): [2 parities][L][G slots][128 granules of {float mass, uint tag}], then the
+// placement handshake [L][G] 16-byte granules {xcc, tag, xcc, tag}.  Granule acc_word(j) of a slot holds bin j, so lane i's
+// 16-byte load at byte 16 i returns bins (i, i + 64).  The total of a bin is DEFINED as
+//     sum over w = 0..kPollWaves-1 (in order) of [ sum over slots g = w, w + kPollWaves, ... (in order) of mass[g] ]     (fp32)
+// -- the order the kernel's waves add in; mailbox_total() restates it for the hand-over kernels.
+__host__ __device__ inline long mbox_slot_granules(int L, int G, int parity, int l, int g) { return (((long)parity * L + l) * G + g) * kBins; }
+__host__ __device__ inline long mbox_handshake_granules(int L, int G) { return 2L * L * G * kBins; }     // 16-byte units follow at this 8-byte offset
+size_t chain_mailbox_bytes(int L, int G) { return (size_t)mbox_handshake_granules(L, G) * 8 + (size_t)L * G * 16; }
+
+__device__ inline float mailbox_total(const unsigned long long* mbox, int L, int G, int parity, int l, int j) {
+    float t = 0.f;
+    for (int w = 0; w < kPollWaves; ++w) {
+        float s = 0.f;
+        for (int g = w; g < G; g += kPollWaves) s += __uint_as_float((unsigned int)(mbox[mbox_slot_granules(L, G, parity, l, g) + acc_word(j)] & 0xffffffffull));
+        t += s;
+    }
+    return t;
+}
+
+// part[l][0][j] = total of bin j of the step whose mailboxes have parity `parity` (fast path -> per-call path hand-over)
+__global__ void mailbox_to_part_kernel(const unsigned long long* __restrict__ mbox, int L, int G, int parity, int parts_pitch, float* __restrict__ part) {
+    const int l = blockIdx.x, j = threadIdx.x;
+    if (j >= kBins) return;
+    part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? mailbox_total(mbox, L, G, parity, l, j) : 0.f;
+}
+hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, int G, int parity, int parts_pitch, float* part, hipStream_t stream) {
+    hipLaunchKernelGGL(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
+    return hipGetLastError();
+}
+
+__device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
+
+// MBOX = false: the exchange of rounds 1-3 (fixed-point u64 atomics at the memory side, arrival count in the word, one
+//                poller), valid at any placement, linear grid: what the per-sub-batch launches of consolidate() use;
+// MBOX = true:  mailboxes inside one XCD's L2 (XCD-aware grid + placement handshake): 0.6 us per step less and no slower
+//                beside the other kernels -- but a layer then needs 24 FREE CUs on one XCD at every launch, which in the shared
+//                pipeline takes longer than the launch saves (21.5 against 14.7 ms per video): experiments build only
+//                (INFV_CHAIN_XCD=1), for a future call-long launch on dedicated CUs.
+template <int RPW, bool MBOX>
+__global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     constexpr int TR = kBRows * RPW;                                   // rows of the tile
     constexpr int PPR = TR / 4;                                        // float4 pieces per new row of the S'new tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
+    const int blocks_per_layer = H * QS;
+    // ---- block -> (layer, workgroup of the layer).  XCD-aware launches (a.xcd_grid): grid = 8 * blocks_per_layer, block b sits
+    // in placement class b % 8 (blocks of one class share an XCD under round-robin placement); layer l is served by class
+    // (8 l) / L, the other classes have nothing to do.
+    int l, blk;
+    if (MBOX && a.xcd_grid) {
+        const int cls = blockIdx.x & 7;
+        l = -1;
+        for (int ll = 0; ll < a.L; ++ll) if ((8 * ll) / a.L == cls) l = ll;
+        if (l < 0) return;
+        blk = blockIdx.x >> 3;
+    } else {
+        l = blockIdx.x / blocks_per_layer;
+        blk = blockIdx.x - l * blocks_per_layer;
+    }
     if (!(a.exp_flags & 1)) __builtin_amdgcn_s_setprio(3);
     wg_stamp_begin(a.wg_stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = a.N, H = a.H, Q = a.Q, QS = a.QS;
     const int rows = a.op.rows, tabw = a.op.tabw;
-    const Batch2Smem m = batch2_smem(N, a.S, rows, tabw, RPW);
-    const int b = blockIdx.x;
-    const int h = b % H, qs = (b / H) % QS, l = b / (H * QS);
-    const int blocks_per_layer = H * QS;
+    const Batch3Smem m = batch3_smem(N, a.S, rows, tabw, RPW);
+    const int h = blk % H, qs = blk / H;
+    const int b = l * blocks_per_layer + blk;                          // (stamps: workgroup 0 = layer 0, head 0, tile 0)
+    const int G = blocks_per_layer;
     const int sn = rows + 1, sn_tile = TR * sn;
     float* cdf = lds + m.cdf;
     float* coarse = lds + m.coarse;
-    int32_t* tabb = reinterpret_cast<int32_t*>(lds + m.tabb);          // bin of the k-th resampled slot of box n, -1 = none
+    float* part = lds + m.part;
+    int32_t* tabb = reinterpret_cast<int32_t*>(lds + m.tabb);          // byte offset (into a score row) of the k-th resampled slot of box n
     int32_t* pb = reinterpret_cast<int32_t*>(lds + m.pb);
     const float* box_val = lds + m.box_val;
     const int32_t* box_row = reinterpret_cast<const int32_t*>(lds + m.box_row);
@@ -373,7 +459,18 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     const int valid = min(TR, Q - qs * TR);
     const bool writer = (h == 0 && qs == 0);
     const bool loader = wave == kBRows - 1;
+    const bool poller = wave < kPollWaves;
     const long tile_snew = (long)rows * a.snew_ld;
+
+    // ---- placement handshake, first half: publish this workgroup's XCD (sc1: visible at any placement) ----
+    const unsigned int launch_tag = (unsigned int)(a.step0 + 1);
+    uintx4_t* hs = MBOX ? reinterpret_cast<uintx4_t*>(a.mbox + mbox_handshake_granules(a.L, G)) + (long)l * G : nullptr;
+    if (MBOX && wave == 0 && lane == 0) {
+        const unsigned int x = (unsigned int)xcc_id();
+        const uintx4_t v = {x, launch_tag, x, launch_tag};
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs, 0, G * 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, blk * 16, 0, 16 /* sc1 */);
+    }
 
     // ---- one-time set-up ----
     {
@@ -384,10 +481,12 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         }
         if (tid < kBins) pb[tid] = a.st.bin_box[tid];
         if (tid < a.S) pos[tid] = -1;
+        for (int e = tid; e < 2 * sn_tile; e += kBNT) (lds + m.Snew)[e] = 0.f;     // incl. the zero column (index rows) of every row
+        for (int e = tid; e < TR * kScPitch; e += kBNT) (lds + m.sc)[e] = 0.f;     // incl. the zero point of every row
         __syncthreads();
         for (int e = tid; e < N * tabw; e += kBNT) {
             const int sl = a.op.slot_tab[e];
-            tabb[e] = -1;
+            tabb[e] = 4 * kZeroPoint;
             if (sl >= 0) pos[sl] = e;
         }
         __syncthreads();
@@ -396,12 +495,11 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
     bool row_ok[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) row_ok[j] = wave + kBRows * j < valid;
-    float* scc = lds + m.sc0 + wave * kScPitch;                        // this wave's first row of point scores (bias-free), current
-    float* scn = lds + m.sc1 + wave * kScPitch;                        // ... and next  (row j of the wave: + j * kBRows * kScPitch)
+    float* scw = lds + m.sc + wave * kScPitch;                         // this wave's first row of point scores (row j: + j * kBRows * kScPitch)
     // the two points of this lane: boxes, operator entries, edge validity and spacings (static)
     const int n0 = pb[lane], n1 = pb[lane + 64];
     const float val0 = box_val[n0], val1 = box_val[n1];
-    const int br0 = box_row[n0], br1 = box_row[n1];
+    const int br0 = box_row[n0] >= 0 ? box_row[n0] : rows, br1 = box_row[n1] >= 0 ? box_row[n1] : rows;   // `rows` = the zero column
     const bool e0ok = a.st.edge_box[lane] >= 0, e1ok = a.st.edge_box[lane + 64] >= 0;     // edge 0 lies left of every box
     const float dx0 = a.st.edge_dx[lane], dx1 = a.st.edge_dx[lane + 64];
     const float dxa = a.st.edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? a.st.edge_dx[lane + 65] : 0.f;
@@ -412,8 +510,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         cqr[j] = row_ok[j] ? a.cq[tile + row] : 0.f;
         const float i0 = row_ok[j] ? a.Sp_in[(tile + row) * N + n0] : 0.f;
         const float i1 = row_ok[j] ? a.Sp_in[(tile + row) * N + n1] : 0.f;
-        scc[j * kBRows * kScPitch + lane] = i0;
-        scc[j * kBRows * kScPitch + lane + 64] = i1;
+        scw[j * kBRows * kScPitch + lane] = i0;
+        scw[j * kBRows * kScPitch + lane + 64] = i1;
         if (a.publish_init && row_ok[j]) {
             // first launch of a call: the state before its first step, for the rows alpha_rows2_kernel rebuilds of that step
             const long prev = (a.step0 % a.ring == 0) ? a.ring - 1 : a.step0 % a.ring - 1;
@@ -423,10 +521,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         }
     }
 
-    // ---- loader (wave 7): the S'new tile and the uniforms of a step in registers, two sets (steps in flight: i+1, i+2).
-    // Wide loads only.   S'new tile: new row nr holds this tile's TR scores contiguously -> float4 e4 = lane + 64 k:
-    // row e4 / PPR, piece e4 % PPR;   uniforms: S float64 -> double2 per lane
-    struct LdSet { floatx4 sn[kB2Ld]; double2 u[4]; };
+    // ---- loader (wave 7): the S'new tile and the rounded-up uniforms of a step in registers, two sets (steps i+1, i+2 in
+    // flight).  Wide loads only.  S'new tile: new row nr holds this tile's TR scores contiguously -> float4 e4 = lane + 64 k:
+    // row e4 / PPR, piece e4 % PPR;   uniforms: S floats -> two float4 per lane
+    struct LdSet { floatx4 sn[kB2Ld]; floatx4 u[2]; };
     LdSet ldA, ldB;
     auto ld_request = [&](int i, LdSet& r) {
         const float* sb = a.Snew + (long)i * tile_snew + tile;
@@ -444,18 +542,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             }
             r.sn[k] = v;
         }
-        const double2* ub = reinterpret_cast<const double2*>(a.u + ((long)i * a.L + l) * a.S);
+        const floatx4* ub = reinterpret_cast<const floatx4*>(a.uf + ((long)i * a.L + l) * a.S);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int s2 = lane + 64 * k;
-            r.u[k] = (2 * s2 < a.S) ? ub[s2] : make_double2(2.0, 2.0);
+        for (int k = 0; k < 2; ++k) {
+            const int s4 = lane + 64 * k;
+            const floatx4 two = {2.f, 2.f, 2.f, 2.f};
+            r.u[k] = (4 * s4 < a.S) ? ub[s4] : two;
         }
-    };
-    auto round_up = [](double u) {
-        // (double)c < u  <=>  c < uf for every float c, with uf = the smallest float >= u
-        float f = (float)u;
-        if ((double)f < u) f = __int_as_float(__float_as_int(f) + 1);
-        return f;
     };
     auto ld_park = [&](int i, const LdSet& r) {                         // into the tiles of parity i & 1
         float* st = lds + m.Snew + (i & 1) * sn_tile;
@@ -470,9 +563,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int s2 = lane + 64 * k;
-            if (2 * s2 < a.S) { uf[2 * s2] = round_up(r.u[k].x); uf[2 * s2 + 1] = round_up(r.u[k].y); }
+        for (int k = 0; k < 2; ++k) {
+            const int s4 = lane + 64 * k;
+            if (4 * s4 < a.S) *reinterpret_cast<floatx4*>(&uf[4 * s4]) = r.u[k];
         }
     };
     if (loader) {
@@ -482,29 +575,171 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
         if (a.n_steps > 2) ld_request(2, ldA);
     }
 
-    int g3 = (int)(a.step0 % 3), slot_run = (int)(a.step0 % a.ring);
+    // ---- placement handshake, second half: one XCD for the whole layer?  (bounded wait; needs every workgroup resident, as
+    // the chain itself does) ----
+    bool plain = false;                                                       // plain mailbox stores: the layer's L2 is one
+    if constexpr (MBOX) {
+    if (wave == 0) {
+        bool same = false;
+        if (G <= 64 && a.xcd_grid && !(a.exp_flags & 32)) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hs, 0, G * 16, 0x00020000);
+            uintx4_t v = {0u, 0u, 0u, 0u};
+            int spins = 0;
+            for (;;) {
+                if (lane < G) v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 16 /* sc1 */);
+                if (!__any(lane < G && (v.y != launch_tag || v.w != launch_tag))) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            const unsigned int mine = __builtin_amdgcn_readfirstlane(v.x);
+            same = !__any(lane < G && (v.x != mine || v.z != mine));
+        }
+        if (lane == 0) reinterpret_cast<int32_t*>(coarse)[0] = same ? 1 : 0;
+    }
+    __syncthreads();
+    plain = reinterpret_cast<const int32_t*>(coarse)[0] != 0;
+    __syncthreads();                                                          // (coarse is rewritten by wave 0 in step 0)
+    if (a.xcc_report != nullptr && tid == 0) a.xcc_report[b] = (plain ? 0x100 : 0) | xcc_id();
+    }
+
+    const unsigned long long* mbox = a.mbox;
+    // poll registers of waves 0..5: this wave's slots of the first round (slot g = wave + kPollWaves k)
+    uintx4_t pv[kPollRound];
+#pragma unroll
+    for (int k = 0; k < kPollRound; ++k) pv[k] = uintx4_t{0u, 0u, 0u, 0u};
+    auto poll_issue = [&](int parity, int round) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(mbox + mbox_slot_granules(a.L, G, parity, l, 0)), 0,
+                                                                      G * kBins * 8, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < kPollRound; ++k) {
+            const int g = wave + kPollWaves * (kPollRound * round + k);
+            if (g < G) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, g * kBins * 8, 16 /* sc1 */);
+        }
+    };
+    // wait for this wave's slots to carry `tag`, add them in slot order, park the partial sums for wave 0
+    auto poll_collect = [&](int parity, unsigned int tag, bool wait) {
+        float s0 = 0.f, s1 = 0.f;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(mbox + mbox_slot_granules(a.L, G, parity, l, 0)), 0,
+                                                                      G * kBins * 8, 0x00020000);
+        for (int round = 0; wave + kPollWaves * kPollRound * round < G; ++round) {
+            if (round > 0) poll_issue(parity, round);
+#pragma unroll
+            for (int k = 0; k < kPollRound; ++k) {
+                const int g = wave + kPollWaves * (kPollRound * round + k);
+                if (g < G) {
+                    int spins = 0;
+                    while (wait && __any(pv[k].y != tag || pv[k].w != tag)) {
+                        if (a.exp_flags & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, g * kBins * 8, 16 /* sc1 */);
+                    }
+                    s0 += __uint_as_float(pv[k].x);
+                    s1 += __uint_as_float(pv[k].z);
+                }
+            }
+        }
+        part[wave * kBins + lane] = s0;
+        part[wave * kBins + lane + 64] = s1;
+    };
+
+    // ---- publish step `pi` (ring slot `pslot`) for alpha_rows2_kernel / the UC kernel: waves 1-6, stores only.  Runs in the shadow
+    // of wave 0's scan of the NEXT step (behind its barrier 0), or after the loop for the last step.  pa0 / pa1: the publishing
+    // wave's own point scores of that step.
+    auto publish_step = [&](int pi, long pslot, const float (&pa0)[RPW], const float (&pa1)[RPW]) {
+        const bool plast = (pi == a.n_steps - 1);
+        if (writer) {
+            int32_t* tab_out = a.tab_ring + pslot * a.tab_slot + (long)l * N * tabw;          // source BOX of every slot (UC kernel)
+            int32_t* tabb_out = a.tabb_ring + pslot * a.tab_slot + (long)l * N * tabw;        // drawn BIN of every slot
+            for (int e = tid - 64; e < N * tabw; e += kBNT - 128) {
+                const int bb = tabb[e] >> 2;
+                const bool none = bb == kZeroPoint;
+                tabb_out[e] = none ? -1 : bb;
+                tab_out[e] = none ? -1 : pb[bb];
+            }
+            if (wave == 6 && a.S > 448) {                                                    // wave 7's share of the draw diagnostics
+                const int s7 = 448 + lane;
+                const int lo = __float_as_int((lds + m.pos)[s7]);
+                if (s7 < a.S) {
+                    if (plast) { a.bins_out[(long)l * a.S + s7] = lo; a.idx_out[(long)l * a.S + s7] = pb[lo]; }
+                    if (a.bins_tr != nullptr && pi < a.trace_steps) a.bins_tr[((long)pi * a.L + l) * a.S + s7] = lo;
+                }
+            }
+        }
+        // point scores after the step: own rows from registers; wave 1 also wave 0's rows, wave 6 also wave 7's (from LDS)
+        float* cr = a.crit_ring + pslot * a.crit_slot + tile * kBins;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int row = wave + kBRows * j;
+            if (row_ok[j] && !(a.exp_flags & 4)) { cr[row * kBins + lane] = pa0[j]; cr[row * kBins + lane + 64] = pa1[j]; }
+            const int extra = (wave == 1) ? kBRows * j : ((wave == 6) ? kBRows * j + kBRows - 1 : -1);
+            if (extra >= 0 && extra < valid) {
+                const float* sx = lds + m.sc + extra * kScPitch;
+                cr[extra * kBins + lane] = sx[lane];
+                cr[extra * kBins + lane + 64] = sx[lane + 64];
+            }
+        }
+    };
+    float acc0[RPW], acc1[RPW];                                            // this wave's point scores of the step (kept for publish_step)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) acc0[j] = acc1[j] = 0.f;
+    long prev_slot = 0;
+
+    int slot_run = (int)(a.step0 % a.ring);
     const int ring_n = (int)a.ring;
-    const unsigned long long need_full = (unsigned long long)(blocks_per_layer + a.expect_extra);
-    // wave 0: totals of the previous step, polled one step ahead (lane j: bins j and j+64)
-    unsigned long long pv0 = 0ull, pv1 = 0ull;
     const bool ovr0 = ((a.override_mask >> l) & 1u) != 0;
-    const bool special0 = ovr0 || a.first_from_parts;                 // step 0 takes its probabilities from elsewhere
-    if (wave == 0 && !special0) {
-        poll_pair(a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins, lane, pv0, pv1);
+    // step 0 takes its totals from elsewhere than the exchange (mailboxes: also when the step before ran in a per-chunk launch)
+    const bool special0 = ovr0 || a.first_from_parts || (MBOX && a.first_from_acc);
+    // atomics exchange: ring of three accumulator slots (read g-1 / add g / clear g+1), wave 0 polls one 16-byte word pair per lane
+    int g3 = (int)(a.step0 % 3);
+    const long layer_words = (long)kAccShards * kBins;
+    const unsigned long long need_full = (unsigned long long)(blocks_per_layer + a.expect_extra);
+    uintx4_t pw = {0u, 0u, 0u, 0u};
+    auto poll_pair = [&](const unsigned long long* layer_words_p) {
+        // lane i reads words (2 i, 2 i + 1) = bins (i, i + 64) with ONE 16-byte load that bypasses the vector L1 (sc1); the words
+        // are only ever written by device-scope atomics, which execute at the memory side and leave no line behind in any L2
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(layer_words_p), 0, kBins * 8, 0x00020000);
+        pw = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 16 /* sc1 */);
+    };
+    if constexpr (MBOX) {
+        if (poller && !special0) poll_issue((int)((a.step0 + 1) & 1), 0);   // the mailboxes of global step step0 - 1
+    } else {
+        if (wave == 0 && !special0) poll_pair(a.acc[g3 == 0 ? 2 : g3 - 1] + l * layer_words);
     }
     __syncthreads();
 
-#define B2STAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
+#define B3STAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
     for (int i = 0; i < a.n_steps; ++i) {
-        B2STAMP(0);
-        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * kBins;
-        unsigned long long* acc_cur = a.acc[g3] + l * kBins;
-        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * kBins;
+        B3STAMP(0);
+        // (stamps 16 / 17: top of step 1 and of the last step -- the launch's average step without the per-phase stamps' own cost)
+        if (a.dbg != nullptr && b == 0 && tid == 0 && (i == 1 || i == a.n_steps - 1)) a.dbg[i == 1 ? 16 : 17] = wall_clock64();
+        const long gstep = a.step0 + i;                                         // global index of this step in the call
         const long slot = slot_run;
-        if (++g3 == 3) g3 = 0;
         if (++slot_run == ring_n) slot_run = 0;
         const bool last = (i == a.n_steps - 1);
         const float* Snew = lds + m.Snew + (i & 1) * sn_tile;
+        unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * layer_words;
+        unsigned long long* acc_cur = a.acc[g3] + l * layer_words;
+        unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * layer_words;
+        if (++g3 == 3) g3 = 0;
+        const bool from_box = MBOX && !(i == 0 && special0);
+        // ---- waves 0..5: the previous step's mailboxes (polled one step ahead) -> partial sums; fault injection: a slot nobody fills
+        if (from_box) {
+            if (poller) poll_collect((int)((gstep + 1) & 1), (unsigned int)gstep, i > 0 && !(a.exp_flags & 16));
+            if (a.expect_extra > 0 && i > 0 && wave == 0) {
+                for (int spins = 0; spins <= a.spin_limit; ++spins) __builtin_amdgcn_s_sleep(1);
+                __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __syncthreads();                                                     // barrier 0
+        }
+        if (i > 0) {
+            // in the shadow of wave 0's scan: the previous step goes out, the loader asks for the inputs of step i+2
+            if (loader) {
+                if (i + 2 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 2) & 1) ld_request(i + 2, ldB); else ld_request(i + 2, ldA); }
+            } else if (wave != 0) {
+                publish_step(i - 1, prev_slot, acc0, acc1);
+            }
+        }
+        prev_slot = slot;
         // ---- wave 0: probabilities -> cdf ----
         if (wave == 0) {
             constexpr int nb = kBins - 1;
@@ -514,33 +749,47 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                 p0 = a.probs_override[l * kBins + lane];
                 p1 = (j1 < nb) ? a.probs_override[l * kBins + j1] : 0.f;
             } else {
-                double a0 = 0.0, a1 = 0.0;
+                float raw0, raw1;
                 if (i == 0 && a.first_from_parts) {
+                    double a0 = 0.0, a1 = 0.0;
                     for (int p = 0; p < a.parts; ++p) {
                         a0 += (double)a.part_prev[((long)l * a.parts + p) * kBins + lane];
                         if (j1 < nb) a1 += (double)a.part_prev[((long)l * a.parts + p) * kBins + j1];
                     }
-                } else {
+                    raw0 = (float)a0; raw1 = (float)a1;
+                } else if (MBOX && i == 0 && a.first_from_acc) {
+                    // the previous step ran in a per-chunk launch: its fixed-point totals (complete: kernel boundary)
+                    raw0 = (float)mass_of(acc_prev[acc_word(lane)]);
+                    raw1 = (j1 < nb) ? (float)mass_of(acc_prev[acc_word(j1)]) : 0.f;
+                } else if (!MBOX) {
                     // the poll was issued one step ago; step 0 reads totals completed by an earlier launch (no count)
                     const unsigned long long need = (i > 0 && !(a.exp_flags & 16)) ? need_full : 0ull;
                     int spins = 0;
-                    while ((pv0 >> kArriveShift) < need || (j1 < nb && (pv1 >> kArriveShift) < need)) {
+                    unsigned long long w0, w1;
+                    for (;;) {
+                        w0 = ((unsigned long long)pw.y << 32) | pw.x;
+                        w1 = ((unsigned long long)pw.w << 32) | pw.z;
+                        if (!((w0 >> kArriveShift) < need || (j1 < nb && (w1 >> kArriveShift) < need))) break;
                         if (a.exp_flags & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
                         if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                        poll_pair(acc_prev, lane, pv0, pv1);
+                        poll_pair(acc_prev);
                     }
-                    a0 = mass_of(pv0);
-                    a1 = (j1 < nb) ? mass_of(pv1) : 0.0;
+                    raw0 = (float)mass_of(w0);
+                    raw1 = (j1 < nb) ? (float)mass_of(w1) : 0.f;
+                } else {
+                    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kPollWaves; ++w) { t0 += part[w * kBins + lane]; t1 += part[w * kBins + j1]; }
+                    raw0 = t0; raw1 = t1;
                 }
-                const float raw0 = (float)a0;
-                const float raw1 = (j1 < nb) ? (float)a1 : 0.f;
+                if (j1 >= nb) raw1 = 0.f;
                 const float tot1 = (float)wave_sum_f64((double)raw0 + (double)raw1);
                 const float q0 = raw0 / tot1, q1 = raw1 / tot1;                       // LTM.py:203
                 const float tot2 = (float)wave_sum_f64((double)q0 + (double)q1);
                 p0 = q0 / tot2; p1 = q1 / tot2;                                       // Categorical's own normalisation
             }
             if (j1 >= nb) p1 = 0.f;
-            B2STAMP(1);
+            B3STAMP(1);
             if (writer) {
                 if (last) { a.probs_out[l * kBins + lane] = p0; if (j1 < nb) a.probs_out[l * kBins + j1] = p1; }
                 if (a.probs_tr != nullptr && i < a.trace_steps) {
@@ -565,13 +814,14 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             if ((lane & 7) == 7) { coarse[lane >> 3] = f0; coarse[8 + (lane >> 3)] = f1; }
         }
         __syncthreads();                                                         // barrier 1
-        B2STAMP(2);
-        // Clear the accumulator slot of step i+1 (it held the totals of step i-2).  Wave 0 has just seen every arrival of
-        // step i-1, and a workgroup arrives only after its own poll of step i-2's totals, so nobody reads the slot any
-        // more; nobody adds to it before having seen all arrivals of step i, this workgroup's included -- and that arrival
-        // (behind barrier 3) is held back until the clear has been acknowledged: the clearing waves drain vmcnt before
-        // they join barrier 3.  (Round 2 issued the clear behind barrier 3, beside the arrival, with nothing ordering the two.)
-        if (writer && tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + acc_word(tid - 128), 0ull);
+        B3STAMP(2);
+        if constexpr (!MBOX) {
+            // Clear the accumulator slot of step i+1 (it held the totals of step i-2).  Wave 0 has just seen every arrival of
+            // step i-1, and a workgroup arrives only after its own poll of step i-2's totals, so nobody reads the slot any more;
+            // nobody adds to it before having seen all arrivals of step i, this workgroup's included -- and that arrival (behind
+            // barrier 3) is held back until the clear has been acknowledged: the clearing waves drain vmcnt before barrier 3.
+            if (writer && tid >= 128 && tid < 128 + kBins) atomicExch(acc_clr + (tid - 128), 0ull);
+        }
         if (tid < a.S) {
             // ---- lower bound of this thread's uniform in the cdf == number of entries below it ----
             const float my_uf = (lds + m.uf + (i & 1) * a.S)[tid];
@@ -590,39 +840,34 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
                       (f1.x < my_uf) + (f1.y < my_uf) + (f1.z < my_uf);
             }
             lo = min(lo, kBins - 2);
-            if (my_pos >= 0) tabb[my_pos] = lo;
+            if (my_pos >= 0) tabb[my_pos] = 4 * lo;
             if (writer && !loader) {
                 if (last) { a.bins_out[(long)l * a.S + tid] = lo; a.idx_out[(long)l * a.S + tid] = pb[lo]; }
                 if (a.bins_tr != nullptr && i < a.trace_steps) a.bins_tr[((long)i * a.L + l) * a.S + tid] = lo;
             }
             if (writer && loader) (lds + m.pos)[tid] = __int_as_float(lo);       // wave 7 stores nothing: wave 6 writes its 64 bins out
         }
-        // the next step's inputs were requested two steps ago: park them (tiles of the other parity: their last readers,
-        // recurrence and search of step i-1, are behind barrier 3 of that step)
-        if (loader && !last) { if ((i + 1) & 1) ld_park(i + 1, ldB); else ld_park(i + 1, ldA); }
         __syncthreads();                                                         // barrier 2
-        B2STAMP(3);
+        B3STAMP(3);
         // ---- wave = rows: recurrence of the 128 point scores of each of its rows, edge densities, bin masses (registers + DPP) ----
-        float acc0[RPW], acc1[RPW];
         {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) acc0[j] = acc1[j] = 0.f;
+            const char* scb = reinterpret_cast<const char*>(scw);
             for (int k0 = 0; k0 < tabw; k0 += 4) {
                 const int4 s0 = *reinterpret_cast<const int4*>(&tabb[n0 * tabw + k0]);
                 const int4 s1 = *reinterpret_cast<const int4*>(&tabb[n1 * tabw + k0]);
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) {
-                    const float* sc = scc + j * kBRows * kScPitch;
-                    const float v0 = sc[max(s0.x, 0)], v1 = sc[max(s0.y, 0)], v2 = sc[max(s0.z, 0)], v3 = sc[max(s0.w, 0)];
-                    const float w0 = sc[max(s1.x, 0)], w1 = sc[max(s1.y, 0)], w2 = sc[max(s1.z, 0)], w3 = sc[max(s1.w, 0)];
-                    if (s0.x >= 0) acc0[j] = fmaf(val0, v0, acc0[j]);
-                    if (s0.y >= 0) acc0[j] = fmaf(val0, v1, acc0[j]);
-                    if (s0.z >= 0) acc0[j] = fmaf(val0, v2, acc0[j]);
-                    if (s0.w >= 0) acc0[j] = fmaf(val0, v3, acc0[j]);
-                    if (s1.x >= 0) acc1[j] = fmaf(val1, w0, acc1[j]);
-                    if (s1.y >= 0) acc1[j] = fmaf(val1, w1, acc1[j]);
-                    if (s1.z >= 0) acc1[j] = fmaf(val1, w2, acc1[j]);
-                    if (s1.w >= 0) acc1[j] = fmaf(val1, w3, acc1[j]);
+                    const char* sc = scb + j * kBRows * kScPitch * 4;
+                    const float v0 = *reinterpret_cast<const float*>(sc + s0.x), v1 = *reinterpret_cast<const float*>(sc + s0.y);
+                    const float v2 = *reinterpret_cast<const float*>(sc + s0.z), v3 = *reinterpret_cast<const float*>(sc + s0.w);
+                    const float w0 = *reinterpret_cast<const float*>(sc + s1.x), w1 = *reinterpret_cast<const float*>(sc + s1.y);
+                    const float w2 = *reinterpret_cast<const float*>(sc + s1.z), w3 = *reinterpret_cast<const float*>(sc + s1.w);
+                    acc0[j] = fmaf(val0, v0, acc0[j]); acc0[j] = fmaf(val0, v1, acc0[j]);
+                    acc0[j] = fmaf(val0, v2, acc0[j]); acc0[j] = fmaf(val0, v3, acc0[j]);
+                    acc1[j] = fmaf(val1, w0, acc1[j]); acc1[j] = fmaf(val1, w1, acc1[j]);
+                    acc1[j] = fmaf(val1, w2, acc1[j]); acc1[j] = fmaf(val1, w3, acc1[j]);
                 }
             }
             // the rows of a wave are independent dependency chains: written phase by phase so that their LDS reads, DPP
@@ -631,10 +876,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int row = wave + kBRows * j;
-                if (br0 >= 0) acc0[j] += Snew[row * sn + br0];
-                if (br1 >= 0) acc1[j] += Snew[row * sn + br1];
-                scn[j * kBRows * kScPitch + lane] = acc0[j];
-                scn[j * kBRows * kScPitch + lane + 64] = acc1[j];
+                acc0[j] += Snew[row * sn + br0];
+                acc1[j] += Snew[row * sn + br1];
+                // in place: every gather of this wave is issued before these stores (the lanes read each other's old values),
+                // and LDS runs a wave's operations in order
+                if (j == 0) wave_lds_handover();
+                scw[j * kBRows * kScPitch + lane] = acc0[j];
+                scw[j * kBRows * kScPitch + lane + 64] = acc1[j];
                 // densities at the 129 edges: edge j (1..127) sits in the box of point j, edges 0 and 128 in none (score 0)
                 es0[j] = e0ok ? acc0[j] + cqr[j] : 0.f;
                 es1[j] = e1ok ? acc1[j] + cqr[j] : 0.f;
@@ -660,79 +908,74 @@ __global__ __launch_bounds__(kBNT) void chain_batch2_kernel(ChainBatchArgs a) {
             for (int j = 0; j < RPW; ++j) {
                 const int row = wave + kBRows * j;
                 const float inv_z = 1.0f / zz[j];
-                // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127)
-                Msm[row * kMPitch + lane] = row_ok[j] ? ((d0n[j] * inv_z + d0nn[j] * inv_z) * dxa) * 0.5f : 0.f;
-                if (lane + 64 < kBins - 1) Msm[row * kMPitch + lane + 64] = row_ok[j] ? ((d1n[j] * inv_z + d1nn[j] * inv_z) * dxb) * 0.5f : 0.f;
+                // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127); the
+                // two masses of a lane go out as one 8-byte LDS word (what the row sum below reads)
+                float2 mm;
+                mm.x = row_ok[j] ? ((d0n[j] * inv_z + d0nn[j] * inv_z) * dxa) * 0.5f : 0.f;
+                mm.y = (row_ok[j] && lane + 64 < kBins - 1) ? ((d1n[j] * inv_z + d1nn[j] * inv_z) * dxb) * 0.5f : 0.f;
+                *reinterpret_cast<float2*>(&Msm[row * kMPitch + 2 * lane]) = mm;
             }
         }
-        if (writer && (wave == 2 || wave == 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clear above is complete
+        if (!MBOX && writer && (wave == 2 || wave == 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clear above is complete
         __syncthreads();                                                         // barrier 3
-        B2STAMP(4);
-        if (tid < kBins - 1) {
-            float t = 0.f;
+        B3STAMP(4);
+        if constexpr (!MBOX) {
+            if (tid < kBins - 1) {
+                float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < TR; ++r) t += Msm[r * kMPitch + tid];
-            if (!(a.exp_flags & 16)) atomicAdd(&acc_cur[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
-        }
-        if (loader) {
-            // request the inputs of step i+3 (set of its parity: parked during this step) in the shadow of wave 0's poll
-            if (i + 3 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 3) & 1) ld_request(i + 3, ldB); else ld_request(i + 3, ldA); }
-        } else if (wave == 0) {
+                for (int r = 0; r < TR; ++r) t += Msm[r * kMPitch + acc_word(tid)];
+                if (!(a.exp_flags & 16))
+                    atomicAdd(&acc_cur[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
+            }
             // re-arm the poll right behind the deposit and go round: this wave issues nothing else until it has read it
-            if (!last && !(a.exp_flags & 16)) {
-                poll_pair(acc_cur, lane, pv0, pv1);
-            }
-            B2STAMP(5);
-        } else {
-            // ---- waves 1-6, stores only: publish the step for alpha_rows2_kernel / the UC kernel ----
-            if (writer) {
-                int32_t* tab_out = a.tab_ring + slot * a.tab_slot + (long)l * N * tabw;          // source BOX of every slot (UC kernel)
-                int32_t* tabb_out = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;        // drawn BIN of every slot
-                for (int e = tid - 64; e < N * tabw; e += kBNT - 128) {
-                    const int bb = tabb[e];
-                    tabb_out[e] = bb;
-                    tab_out[e] = (bb >= 0) ? pb[bb] : -1;
-                }
-                if (wave == 6 && a.S > 448) {                                                    // wave 7's share of the draw diagnostics
-                    const int s7 = 448 + lane;
-                    const int lo = __float_as_int((lds + m.pos)[s7]);
-                    if (s7 < a.S) {
-                        if (last) { a.bins_out[(long)l * a.S + s7] = lo; a.idx_out[(long)l * a.S + s7] = pb[lo]; }
-                        if (a.bins_tr != nullptr && i < a.trace_steps) a.bins_tr[((long)i * a.L + l) * a.S + s7] = lo;
-                    }
-                }
-            }
-            // point scores after this step: own rows from registers; wave 1 also wave 0's rows, wave 6 also wave 7's (from LDS)
-            float* cr = a.crit_ring + slot * a.crit_slot + tile * kBins;
+            if (wave == 0 && !last && !(a.exp_flags & 16)) poll_pair(acc_cur);
+        } else if (wave == 0) {
+            // ---- this workgroup's row sums of the step -> its mailbox: one 16-byte store per lane = two {mass, tag} granules
+            float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                const int row = wave + kBRows * j;
-                if (row_ok[j] && !(a.exp_flags & 4)) { cr[row * kBins + lane] = acc0[j]; cr[row * kBins + lane + 64] = acc1[j]; }
-                const int extra = (wave == 1) ? kBRows * j : ((wave == 6) ? kBRows * j + kBRows - 1 : -1);
-                if (extra >= 0 && extra < valid) {
-                    const float* sx = lds + ((i & 1) ? m.sc0 : m.sc1) + extra * kScPitch;        // that row's NEXT buffer
-                    cr[extra * kBins + lane] = sx[lane];
-                    cr[extra * kBins + lane + 64] = sx[lane + 64];
+            for (int r = 0; r < TR; ++r) {
+                const float2 mm = *reinterpret_cast<const float2*>(&Msm[r * kMPitch + 2 * lane]);
+                t0 += mm.x; t1 += mm.y;
+            }
+            if (!(a.exp_flags & 16)) {
+                const unsigned int tag = (unsigned int)(gstep + 1);
+                const uintx4_t v = {__float_as_uint(t0), tag, __float_as_uint(t1), tag};
+                unsigned long long* dst = a.mbox + mbox_slot_granules(a.L, G, (int)(gstep & 1), l, blk);
+                if (plain) {
+                    reinterpret_cast<uintx4_t*>(dst)[lane] = v;                 // stays in this XCD's L2, where the whole layer reads it
+                } else {
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, kBins * 8, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 16 /* sc1: write-through, valid at any placement */);
                 }
             }
         }
-        { float* t = scc; scc = scn; scn = t; }
-        B2STAMP(6);
-        B2STAMP(7);
-        // LDS reuse: cdf / coarse are rewritten by wave 0 after barrier 3, i.e. after every search of this step; the
-        // S'new / uniform tiles of parity i are rewritten by wave 7 behind barrier 1 of step i+1; tabb and the bins parked in
-        // `pos` behind barrier 1 as well (their readers, the publishing waves, reach that barrier after their stores were
-        // issued); Msm behind barrier 2; the rows read by waves 1 and 6 are rewritten behind barrier 2 of step i+1.
+        // re-arm the polls right behind the deposit.  Nothing else touches memory between here and barrier 0 of the next step:
+        // the publishing stores and the loader's requests wait for the window behind that barrier (wave 0's scan), so neither a
+        // poll nor a re-poll queues behind them in this CU's memory pipe
+        if (MBOX && poller && !last) poll_issue((int)(gstep & 1), 0);
+        if (loader && !last) { if ((i + 1) & 1) ld_park(i + 1, ldB); else ld_park(i + 1, ldA); }   // LDS only (requested two steps ago)
+        if (wave == 0) B3STAMP(5);
+        B3STAMP(6);
+        B3STAMP(7);
+        // LDS reuse: `part` is rewritten by the polling waves at the top of step i+1, its reader (wave 0) is past barrier 1 of
+        // step i by then... and every polling wave passes barriers 1-3 of step i in between; cdf / coarse are rewritten by wave 0
+        // after barrier 0 of step i+1, i.e. after every search of this step; the S'new / uniform tiles of parity i+1 are rewritten
+        // by wave 7 behind barrier 3 (their readers ran before barrier 3 of step i-1); tabb and the bins parked in `pos` behind
+        // barrier 1 (their readers, the publishing waves, reach barrier 0 after their loads); Msm behind barrier 2; the score rows
+        // read by waves 1 and 6 behind barrier 2 of step i+1.
     }
+    if (a.n_steps > 0 && wave != 0 && !loader) publish_step(a.n_steps - 1, prev_slot, acc0, acc1);
     // ---- hand the point scores to the next launch (its set-up reads them back through pb) ----
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int row = wave + kBRows * j;
         if (row_ok[j]) {
-            a.Sp_out[(tile + row) * N + n0] = scc[j * kBRows * kScPitch + lane];
-            a.Sp_out[(tile + row) * N + n1] = scc[j * kBRows * kScPitch + lane + 64];
+            a.Sp_out[(tile + row) * N + n0] = scw[j * kBRows * kScPitch + lane];
+            a.Sp_out[(tile + row) * N + n1] = scw[j * kBRows * kScPitch + lane + 64];
         }
     }
+    // (the last step's totals stay in the mailboxes: the next launch's step 0 reads them there; whoever continues without
+    // mailboxes -- the next call, a per-chunk launch -- gets them from launch_mailbox_to_part)
     wg_stamp_end(a.wg_stamps);
 }
 
@@ -917,15 +1160,29 @@ bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
            n_blocks <= 384 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
 }
 
+// Variants of the persistent role S.  The shipped library launches ONE: 16-row tiles, atomics exchange.  The experiments build
+// can select 8-row tiles (INFV_CHAIN_RPW=1) and the mailbox exchange inside one XCD's L2 (INFV_CHAIN_XCD=1) for A/B runs.
+constexpr int kDefRpw = 2;
+typedef void (*Chain3Fn)(ChainBatchArgs);
+bool chain_batch3_mailboxes() {
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_XCD"); return e && atoi(e) != 0; }();
+    return want;
+}
+static Chain3Fn chain3_fn(int rpw) {
+#ifdef INFV_EXPERIMENTS
+    if (chain_batch3_mailboxes()) return rpw == 1 ? chain_batch3_kernel<1, true> : chain_batch3_kernel<2, true>;
+    if (rpw == 1) return chain_batch3_kernel<1, false>;
+#endif
+    return chain_batch3_kernel<2, false>;
+}
+
 static hipError_t chain_batch_attr() {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel<1>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch2_kernel<2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int rpw = 1; rpw <= 2 && e == hipSuccess; ++rpw)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain3_fn(rpw)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -936,34 +1193,41 @@ static hipError_t chain_batch_attr() {
 // kernel's registers and LDS, even if nothing else left room (other kernels may still delay residency; the waits are
 // bounded and report through the error word).  One workgroup per CU less than the API's answer: the occupancy
 // query reads one high for some SGPR counts (MI355X_MICROARCH.md, residency).
-bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q) {
-    static const bool want_v2 = [] { const char* e = exp_env("INFV_CHAIN_V1"); return !e || atoi(e) == 0; }();
-    return want_v2 && draw_mode == 1 && points_ok && 2 * rows <= 64 * kB2Ld && S <= 512 && S % 2 == 0 && Q % 4 == 0;
+static int chain_batch3_rpw(int rows, int Q);
+bool chain_batch3_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q) {
+    static const bool want_v3 = [] { const char* e = exp_env("INFV_CHAIN_V1"); return !e || atoi(e) == 0; }();
+    return want_v3 && draw_mode == 1 && points_ok && 2 * rows <= 64 * kB2Ld && S <= 512 && S % 4 == 0 && Q % 4 == 0 &&
+           chain_batch3_rpw(rows, Q) > 0;
 }
 
-// Query rows per wave of chain_batch2_kernel for this shape: 2 (16-row tiles, half the workgroups -- each of which owns a
+// Query rows per wave of chain_batch3_kernel for this shape: 2 (16-row tiles, half the workgroups -- each of which owns a
 // whole CU by its registers -- and half the arrivals per exchange) when the loader's register tile holds 16 scores per new
-// row; INFV_CHAIN_RPW=1 restores 8-row tiles.
-int chain_batch2_rpw(int rows, int Q) {
-    static const int want = [] { const char* e = exp_env("INFV_CHAIN_RPW"); return e ? atoi(e) : 2; }();
+// row; INFV_CHAIN_RPW=1 (experiments build) selects 8-row tiles.
+static int chain_batch3_rpw(int rows, int Q) {
+    static const int want = [] { const char* e = exp_env("INFV_CHAIN_RPW"); return e ? atoi(e) : kDefRpw; }();
     if (want >= 2 && 4 * rows <= 64 * kB2Ld && Q > kBRows) return 2;
+#ifdef INFV_EXPERIMENTS
     return 1;
+#else
+    return 0;                                          // (8-row tiles are not compiled into the shipped library: v1 kernel instead)
+#endif
 }
 
 bool chain_batch2_applies(const ChainBatchArgs& a) {
-    return chain_batch2_shape_ok(a.draw_mode, a.st.points_ok, a.op.rows, a.S, a.Q) && a.crit_ring != nullptr;
+    return chain_batch3_shape_ok(a.draw_mode, a.st.points_ok, a.op.rows, a.S, a.Q) && a.crit_ring != nullptr && a.uf != nullptr &&
+           (a.mbox != nullptr || !chain_batch3_mailboxes());
 }
 
 // Workgroups of the persistent role-S launch for this shape (the kernel launch_chain_batch will choose).
 int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int rows, int S) {
-    const int rpw = chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q) ? chain_batch2_rpw(rows, Q) : 1;
+    const int rpw = chain_batch3_shape_ok(draw_mode, points_ok, rows, S, Q) ? chain_batch3_rpw(rows, Q) : 1;
     return H * ((Q + kBRows * rpw - 1) / (kBRows * rpw)) * L;
 }
 
-static size_t chain_batch2_launch_lds(int N, int S, int rows, int tabw, int rpw) {
+static size_t chain_batch3_launch_lds(int N, int S, int rows, int tabw, int rpw) {
     // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
     static const int pad = [] { const char* e = exp_env("INFV_S_LDS"); return e ? atoi(e) : 0; }();
-    size_t lds = (size_t)batch2_smem(N, S, rows, tabw, rpw).total * sizeof(float);
+    size_t lds = (size_t)batch3_smem(N, S, rows, tabw, rpw).total * sizeof(float);
     if ((size_t)pad > lds) lds = pad;
     return lds;
 }
@@ -975,11 +1239,10 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     hipError_t e;
-    if (chain_batch2_shape_ok(draw_mode, points_ok, rows, S, Q)) {
-        const int rpw = chain_batch2_rpw(rows, Q);
-        const size_t lds = chain_batch2_launch_lds(N, S, rows, tabw, rpw);
-        e = rpw == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel<2>, kBNT, lds)
-                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch2_kernel<1>, kBNT, lds);
+    if (chain_batch3_shape_ok(draw_mode, points_ok, rows, S, Q)) {
+        const int rpw = chain_batch3_rpw(rows, Q);
+        const size_t lds = chain_batch3_launch_lds(N, S, rows, tabw, rpw);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain3_fn(rpw), kBNT, lds);
     } else {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_batch_kernel, kBNT, chain_batch_lds_bytes(N, S, rows, tabw));
     }
@@ -994,13 +1257,17 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
     ChainBatchArgs a = a_in;
     if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, a.H * a.QS * a.L)) return hipErrorInvalidValue;
     if (chain_batch2_applies(a)) {
-        const int rpw = chain_batch2_rpw(a.op.rows, a.Q);
+        const int rpw = chain_batch3_rpw(a.op.rows, a.Q);
         a.QS = (a.Q + kBRows * rpw - 1) / (kBRows * rpw);             // tiles of 8 * rpw query rows
-        const int blocks = a.H * a.QS * a.L;
-        const size_t lds = chain_batch2_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
+        const int G = a.H * a.QS;                                      // workgroups of a layer
+        // XCD-aware launch: a layer's workgroups get block ids that are equal mod 8 (one XCD under round-robin placement, where
+        // the exchange then stays in that XCD's L2); needs a layer to fit one XCD's CUs and a placement class per layer.  The
+        // kernel verifies the placement itself (handshake) and is correct without it.
+        a.xcd_grid = (chain_batch3_mailboxes() && G <= 32 && a.L <= 8) ? 1 : 0;
+        const int blocks = a.xcd_grid ? 8 * G : G * a.L;
+        const size_t lds = chain_batch3_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
         a.wg_stamps = exp_stamps_reserve(WG_CHAIN, blocks);
-        if (rpw == 2) hipLaunchKernelGGL(chain_batch2_kernel<2>, dim3(blocks), dim3(kBNT), lds, stream, a);
-        else hipLaunchKernelGGL(chain_batch2_kernel<1>, dim3(blocks), dim3(kBNT), lds, stream, a);
+        hipLaunchKernelGGL(chain3_fn(rpw), dim3(blocks), dim3(kBNT), lds, stream, a);
         return hipGetLastError();
     }
     a.wg_stamps = nullptr;

@@ -123,7 +123,12 @@ __device__ inline DrawRegs<SPT> draw_load(const float* __restrict__ part, int pa
             if (tid + 64 < nb) r.ovr[1] = probs_override[tid + 64];
         }
     } else if (mass_acc != nullptr) {
-        if (tid < kBins - 1) r.acc = mass_of(mass_acc[acc_word(tid)]);           // group 0 holds the totals
+        if (tid < kBins - 1) {                                                   // group 0 holds the totals
+            unsigned long long tot = 0ull;                                       // integer sum over the replicas (kAccShards)
+#pragma unroll
+            for (int sh = 0; sh < kAccShards; ++sh) tot += mass_acc[sh * kBins + acc_word(tid)] & kMassMask;
+            r.acc = mass_of(tot);
+        }
     } else {
         constexpr int G = NT / kBins;                   // thread groups that split the partial rows
         const int j = tid & (kBins - 1), grp = tid / kBins;

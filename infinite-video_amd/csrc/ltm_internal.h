@@ -14,6 +14,12 @@ constexpr int kQTile = 16;         // query rows per attend workgroup (one MFMA 
 // interleaves the two halves of the histogram -- words (2 i, 2 i + 1) = bins (i, i + 64) -- so that ONE 16-byte load per
 // lane hands lane i exactly the two bins it owns in the draw (the poll of the persistent chain kernel).
 __host__ __device__ inline int acc_word(int j) { return j < 64 ? 2 * j : 2 * (j - 64) + 1; }
+// A ring slot holds, per layer, kAccShards replicas of those 128 words ([L][kAccShards][128]); the total of a bin is the
+// (integer) sum over the replicas, whoever clears a slot clears all of them.  Round 4 measured 2-8 replicas for the
+// persistent role S (adds to one word serialise at the memory side): 1.77-1.95 us per exchange against 1.90 with one --
+// every cross-XCD exchange costs that much -- so role S now exchanges through mailboxes inside one XCD's L2
+// (chain_batch3_kernel) and the accumulators, used by the per-chunk kernels only, are back to one replica.
+constexpr int kAccShards = 1;
 
 // Device-side view of one ridge operator (first-chunk or infinite-memory) of a plan.
 struct OperatorView {
@@ -56,12 +62,9 @@ hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames,
 
 // R[c][r][:] = val * sum of the frames of row r of chunk c;  Pnew[sk][c][r][l][kv][dm] = split-K
 // partials of R . W[l][kv]^T  (sk = project_splitk(n_chunks*rows, d) slabs of n_chunks*rows*L*2*dm floats).
-// pool + rows in one pass (fast path): R straight from the tokens, bit-identical to launch_pool + launch_rows.
-// u: 1-KiB loads per group (two groups in flight per wave), nt: threads per workgroup (256 / 512), lds_pad: occupancy cap.
-bool pool_rows_supported(int P, int d);
-hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                            hipStream_t stream, int u, int nt, int lds_pad, int max_wgs = 0);
-// the same with short-lived workgroups: one workgroup per (chunk, row), a wave per (frame of the row, 256-float slice)
+// pool + rows in one pass (fast path): R straight from the tokens, bit-identical to launch_pool + launch_rows:
+// one short-lived workgroup per (chunk, row), a wave per (frame of the row, 256-float slice); u: 1-KiB loads per burst,
+// lds_pad: occupancy cap
 bool pool_rows2_supported(int d);
 hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
                              hipStream_t stream, int u, int lds_pad, int max_wgs = 0);
@@ -117,7 +120,7 @@ struct ChainRoleS {
     OperatorView op;
     int draw_mode;                  // 0: none (first chunk of a document), 1: sticky Gibbs draw, 2: uniform resample
     const float* part_prev; int parts;            // float partials of the previous step (per-call path hand-over) ...
-    const unsigned long long* acc_prev;           // ... or its fixed-point totals [L][128] (fast path steady state)
+    const unsigned long long* acc_prev;           // ... or its fixed-point totals [L][kAccShards][128] (fast path steady state)
     unsigned long long* acc_next; unsigned long long* acc_clear;   // this step's totals; the ring slot to zero for the next
     const float* probs_override; unsigned override_mask; const double* u; const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;     // [L][128], [L][S], [L][S]  (diagnostics)
@@ -146,8 +149,12 @@ struct ChainBatchArgs {
     int n_steps;
     long step0; int ring;           // step i has global index step0+i: histogram slot (step0+i)%3, output slot (step0+i)%ring
     int first_from_parts;           // step 0 reads the float partials of the per-call path instead of the ring
+    int first_from_acc;             // chain_batch3_kernel: step 0 reads the fixed-point totals of a per-chunk launch (acc[(step0+2)%3]) instead of the mailboxes
+    unsigned long long* mbox;       // chain_batch3_kernel: mailboxes of the exchange + placement handshake (chain_mailbox_bytes), zeroed at the start of a call
+    int xcd_grid;                   // chain_batch3_kernel: launched as 8 * (H*QS) blocks, layer l served by placement class (8 l) / L (set by launch_chain_batch)
+    int* xcc_report;                // experiments / tests: per workgroup (plain-store mode << 8) | XCC id, or nullptr
     const float* part_prev; int parts;
-    unsigned long long* acc[3];     // fixed-point sticky histograms [L][128], ring of 3
+    unsigned long long* acc[3];     // fixed-point sticky histograms [L][kAccShards][128], ring of 3
     unsigned int* arrive;           // [L] arrival counters, zero at launch
     unsigned int* error;            // host-visible word, set to 1 if a wait timed out
     int spin_limit;                 // polls before a wait gives up
@@ -155,13 +162,14 @@ struct ChainBatchArgs {
     int expect_extra;               // fault injection (tests): arrivals expected beyond the launch's workgroups
     const float* probs_override; unsigned override_mask;     // teacher forcing of step 0
     const double* u;                // [n_steps][L][S]
+    const float* uf;                // chain_batch3_kernel: the same uniforms as fp32 round-ups (launch_round_up_uniforms), or nullptr
     const int32_t* uniform_idx;
     float* probs_out; int32_t* bins_out; int32_t* idx_out;    // diagnostics of the last step
     float* probs_tr; int32_t* bins_tr; int trace_steps;       // draw trace of steps [0, trace_steps): [.][L][128], [.][L][S] (either may be null)
     int32_t* tab_ring; long tab_slot;
-    int32_t* tabb_ring;             // chain_batch2_kernel: drawn bin of every (box, slot), same slot layout as tab_ring
-    float* crit_ring; long crit_slot;   // chain_batch2_kernel: point scores after every step, [ring][L][H][Q][128]
-    int publish_init;               // chain_batch2_kernel: also write the state BEFORE step 0 to the slot before slot0's
+    int32_t* tabb_ring;             // chain_batch3_kernel: drawn bin of every (box, slot), same slot layout as tab_ring
+    float* crit_ring; long crit_slot;   // chain_batch3_kernel: point scores after every step, [ring][L][H][Q][128]
+    int publish_init;               // chain_batch3_kernel: also write the state BEFORE step 0 to the slot before slot0's
     float* alpha_ring; long alpha_slot; float* asum_ring; long asum_slot;
     const float* Sp_in; float* Sp_out;                        // [L][H][Q][N] bias-free scores before / after the sub-batch
     const float* Snew; int snew_ld; int snew_splitk; long snew_split_stride;   // [n_steps][rows] rows of pitch snew_ld, column (l*H+h)*Q+q, split-K slabs
@@ -170,10 +178,15 @@ struct ChainBatchArgs {
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
 };
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
-bool chain_batch2_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);
-bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch2_kernel (scores rebuilt by alpha_rows2)
+bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch3_kernel (scores rebuilt by alpha_rows2)
+bool chain_batch3_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);   // the shape runs chain_batch3_kernel (needs ChainBatchArgs.uf)
+hipError_t launch_round_up_uniforms(const double* u, float* uf, long n, hipStream_t stream);   // uf[i] = smallest float >= u[i]
+bool chain_batch3_mailboxes();                               // experiments build, INFV_CHAIN_XCD=1: role S exchanges through mailboxes in one XCD's L2
+size_t chain_mailbox_bytes(int L, int G);                    // G = workgroups of a layer (chain_batch_blocks / L)
+// part[l][0][j] = total of bin j held by the mailboxes of parity `parity` (the last step of a chain_batch3 launch), same sum order as the kernel
+hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, int G, int parity, int parts_pitch, float* part, hipStream_t stream);
 int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int rows, int S);   // workgroups of the launch for this shape
-// the chunk-parallel half of chain_batch2_kernel: full score rows from the published point scores + drawn bins, then alpha
+// the chunk-parallel half of chain_batch3_kernel: full score rows from the published point scores + drawn bins, then alpha
 struct AlphaRows2Args {
     int N, H, Q, L, rows, tabw, n_steps;
     long slot0; int ring;
@@ -231,6 +244,16 @@ hipError_t launch_dense_update(const float* GT, int K, int ldg, int n_old, const
 // part[l][h][j] = sum_q trapezoid mass of interval j+1 of row (h, q)'s 129-edge density; an edge may lie in two boxes
 hipError_t launch_dense_masses(const float* scores, int Q, int N, int H, int n_layers, const int32_t* edge_box2,
                                const float* edge_dx, float* part, hipStream_t stream);
+
+// ---- general-psi form of the step (ltm_psi.hip): basis families whose psi(t) is a dense row (the reference's Gaussian family) ----
+hipError_t launch_psi_gemm(bool transB, const float* A, int lda, long sA, const float* B, int ldb, long sB, float* C, int ldc, long sC,
+                           int M, int Nc, int K, int batch, hipStream_t stream);      // C[z] = A[z] . B[z]^T (transB) or A[z] . B[z], fp32 MFMA tiles
+hipError_t launch_psi_update(const float* GT, int K, int ldg, int n_old, const int32_t* bins, int bins_stride, const float* Y, int n_pos,
+                             const float* kbar, float* B_next, int N, int d, int n_layers, hipStream_t stream);
+hipError_t launch_psi_masses(const float* E, int ldE, int Q, int H, int n_layers, const float* edge_dx, float* part, hipStream_t stream);
+hipError_t launch_psi_grid(float* Eg, int ldg, int n_grid, long n_rows, const float* w, hipStream_t stream);
+hipError_t launch_psi_ctx(const float* alpha, const float* KV, const ProjPtrs& proj, int Q, int N, int H, int dh, int n_layers, float* ctx,
+                          hipStream_t stream);
 
 // part[l][0][j] = acc[l][j] / 2^40 (fast path -> per-call path hand-over of the sticky histogram)
 hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream);

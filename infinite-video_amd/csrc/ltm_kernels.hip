@@ -83,54 +83,6 @@ __global__ __launch_bounds__(NT) void pool_frames_kernel(const void* __restrict_
     }
 }
 
-// The same kernel with a rolling register double buffer (round 3): the U loads of group g+1 are issued before group g is
-// summed, so a wave keeps U..2U KiB in flight all the time instead of issuing a burst, waiting for all of it and starting
-// over (in situ, where a load takes ~2 us, the burst form leaves the wave with nothing in flight about half the time).
-// Same unit (one wave per frame and 256-float slice: short-lived workgroups, which is what lets the persistent chain
-// kernel find empty CUs at every sub-batch launch), same summation order, same bits.  Needs P % U == 0.
-template <int U, int NT, class Tok = TokF32>
-__global__ __launch_bounds__(NT) void pool_frames_db_kernel(const void* __restrict__ k_, float* __restrict__ kbar,
-                                                             long n_units, int P, int d4, int slices) {
-    typedef typename Tok::vec tvec;
-    const int lane = threadIdx.x & 63;
-    for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
-        const long frame = unit / slices;
-        const int c4 = (int)(unit - frame * slices) * 64 + lane;
-        if (c4 >= d4) continue;
-        const tvec* src = reinterpret_cast<const tvec*>(k_) + frame * (long)P * d4 + c4;
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-        tvec va[U], vb[U];
-        const int n_groups = P / U;
-#pragma unroll
-        for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)i * d4);
-        int g = 0;
-        for (; g + 2 < n_groups; g += 2) {
-#pragma unroll
-            for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(src + (long)((g + 1) * U + i) * d4);
-#pragma unroll
-            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
-#pragma unroll
-            for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)((g + 2) * U + i) * d4);
-#pragma unroll
-            for (int i = 0; i < U; ++i) acc += Tok::widen(vb[i]);
-        }
-        if (g + 1 < n_groups) {
-#pragma unroll
-            for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(src + (long)((g + 1) * U + i) * d4);
-#pragma unroll
-            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
-#pragma unroll
-            for (int i = 0; i < U; ++i) acc += Tok::widen(vb[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < U; ++i) acc += Tok::widen(va[i]);
-        }
-        const float fp = (float)P;
-        acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;
-        __builtin_nontemporal_store(acc, reinterpret_cast<floatx4*>(kbar) + frame * d4 + c4);
-    }
-}
-
 // `lds_pad` bytes of (unused) dynamic LDS per workgroup cap how many of them a CU hosts, so that a
 // latency-critical kernel on another stream always finds wave slots and LDS (see consolidate()).
 template <class Tok>
@@ -149,87 +101,21 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
     if (n_units == 0) return hipSuccess;
     if (lds_pad > 0) {
         // overlapped mode: 512-thread workgroups whose padding LDS lets only ONE of them live on a CU
-        // (8 waves x 32 KiB in flight still cover the HBM latency), so the chain kernel always finds room
+        // (8 waves x 4 KiB in flight still cover the HBM latency), so the chain kernel always finds room.
+        // Loads in flight per wave: the pool's outstanding bytes set the queueing delay that every other kernel's memory
+        // operation sees while it runs; 4 KiB per wave (8 MiB chip-wide) keeps ~95 % of the in-situ pooling rate and gives
+        // role S back ~0.5 ms per video; 16 is fastest for the pool alone.  (Rounds 1-3 also measured 256- and 1024-thread
+        // workgroups, 2 / 8 / 16 KiB in flight, a bounded grid and a rolling double buffer: all within noise or slower in
+        // the pipeline -- DESIGN notebook; those instantiations are gone.)
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 512, Tok>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 512, Tok>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        static const int max_wgs = [] { const char* e = exp_env("INFV_POOL_WGS"); return e ? atoi(e) : 0; }();   // throttle (experiments)
-        // loads in flight per wave (KiB).  The pool's outstanding bytes set the queueing delay that every other kernel's
-        // memory operation sees while it runs (role S's atomics and stores: all of its phases stretch 1.5-2x during
-        // pooling).  4 KiB per wave (8 MiB chip-wide) keeps ~95 % of the in-situ pooling rate and gives role S back
-        // ~0.5 ms per video; 16 is fastest for the pool alone.
-        static const int unroll = [] { const char* e = exp_env("INFV_POOL_UNROLL"); return e ? atoi(e) : 4; }();
-        // INFV_POOL_NT=1024: sixteen waves per workgroup (still one workgroup per CU by the padding LDS): the pooling rate
-        // follows the number of resident pooling waves, and other kernels hold part of the CUs
-        static const int nt1024 = [] { const char* e = exp_env("INFV_POOL_NT"); return e && atoi(e) == 1024; }();
-        if (nt1024) {
-            static bool attr_big = false;
-            if (!attr_big) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 1024, Tok>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<2, 1024, Tok>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr_big = true;
-            }
-            const unsigned g16 = (unsigned)((n_units + 15) / 16);
-            if (unroll <= 2)
-                hipLaunchKernelGGL((pool_frames_kernel<2, 1024, Tok>), dim3(g16), dim3(1024), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            else
-                hipLaunchKernelGGL((pool_frames_kernel<4, 1024, Tok>), dim3(g16), dim3(1024), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            return hipGetLastError();
-        }
-        // INFV_POOL_NT=256: four-wave workgroups (one wave per SIMD, <= 72 registers): small enough to sit beside a role-S
-        // workgroup (432 of 512 registers per SIMD), which then no longer needs an EMPTY CU at its launches
-        static const int nt256 = [] { const char* e = exp_env("INFV_POOL_NT"); return e && atoi(e) == 256; }();
-        if (nt256) {
-            static bool attr_256 = false;
-            if (!attr_256) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<4, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<8, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_kernel<16, 256, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr_256 = true;
-            }
-            const unsigned g4 = (unsigned)((n_units + 3) / 4);
-            if (unroll <= 4) hipLaunchKernelGGL((pool_frames_kernel<4, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            else if (unroll <= 8) hipLaunchKernelGGL((pool_frames_kernel<8, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            else hipLaunchKernelGGL((pool_frames_kernel<16, 256, Tok>), dim3(g4), dim3(256), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            return hipGetLastError();
-        }
-        unsigned grid = (unsigned)((n_units + 7) / 8);
-        if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
-        // INFV_POOL_DB=<U>: the rolling double-buffered form with U loads per group (U | P)
-        static const int db = [] { const char* e = exp_env("INFV_POOL_DB"); return e ? atoi(e) : 0; }();
-        if (db > 0 && P % db == 0 && (db == 1 || db == 2 || db == 4)) {
-            static bool attr_db = false;
-            if (!attr_db) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<1, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<2, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_frames_db_kernel<4, 512, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr_db = true;
-            }
-            if (db == 1) hipLaunchKernelGGL((pool_frames_db_kernel<1, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            else if (db == 2) hipLaunchKernelGGL((pool_frames_db_kernel<2, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            else hipLaunchKernelGGL((pool_frames_db_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-            return hipGetLastError();
-        }
-        if (unroll <= 2)
-            hipLaunchKernelGGL((pool_frames_kernel<2, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-        else if (unroll <= 4)
-            hipLaunchKernelGGL((pool_frames_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-        else if (unroll <= 8)
-            hipLaunchKernelGGL((pool_frames_kernel<8, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
-        else
-            hipLaunchKernelGGL((pool_frames_kernel<16, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+        const unsigned grid = (unsigned)((n_units + 7) / 8);
+        hipLaunchKernelGGL((pool_frames_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
     } else {
         hipLaunchKernelGGL((pool_frames_kernel<16, 256, Tok>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
                            n_units, P, d4, slices);
@@ -255,78 +141,6 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
             acc.z = fmaf(val, v.z, acc.z); acc.w = fmaf(val, v.w, acc.w);
         }
         __builtin_nontemporal_store(acc, dst + c4);
-    }
-}
-
-// ======================================================================================
-// 2b. pool + rows in one pass (fast path):  R[c][r][:] = sum_{f in [begin_r,end_r)} val_r * (sum_p k[c][f][p][:] / P)
-//     In the whole-video path the frame means are consumed by build_rows_kernel only, and a new row is the weighted sum
-//     of a CONTIGUOUS block of tokens (its frames are consecutive: 4 frames x 32 tokens x 3 KiB = 384 KiB at the headline
-//     shape), so the pooling kernel can emit R directly: no kbar round trip, no second kernel, no event hop.
-//     One wave per (chunk, row, 256-float column slice); it streams the block's (end-begin)*P token rows as 1 KiB loads,
-//     U of them per group, two groups in flight (register double buffer: the loads of group g+1 are issued before group g
-//     is summed).  The arithmetic is pool_frames_kernel's followed by build_rows_kernel's in the same order -- token sum in
-//     p order, division by P, fma chain over the frames -- so R is bit-identical to the two-kernel path.
-//     Needs P % U == 0 (a group never straddles a frame).
-// ======================================================================================
-template <int U, int NT, class Tok>
-__global__ __launch_bounds__(NT) void pool_rows_kernel(const void* __restrict__ k_, long chunk_stride /*token vectors per chunk*/,
-                                                       int P, int d4, int slices, OperatorView op, long n_units,
-                                                       float* __restrict__ R) {
-    typedef typename Tok::vec tvec;
-    const int lane = threadIdx.x & 63;
-    // grid-stride over units: a full grid gives every wave one unit; a smaller grid (launch_pool_rows' max_wgs) bounds the
-    // kernel's footprint on the chip for the whole launch
-    for (long unit = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); unit < n_units; unit += (long)gridDim.x * (NT / 64)) {
-    const int s = (int)(unit % slices);
-    const long cr = unit / slices;
-    const int r = (int)(cr % op.rows);
-    const long c = cr / op.rows;
-    const int c4 = s * 64 + lane;
-    if (c4 >= d4) continue;
-    const int fb = op.row_begin[r], fe = op.row_end[r];
-    const float val = op.box_val[op.row_box[r]];
-    const tvec* src = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)fb * P * d4 + c4;
-    const int gpf = P / U;                               // groups per frame
-    const int n_groups = (fe - fb) * gpf;
-    const float fp = (float)P;
-    tvec va[U], vb[U];
-    floatx4 acc = {0.f, 0.f, 0.f, 0.f}, racc = {0.f, 0.f, 0.f, 0.f};
-    int in_frame = 0;
-    auto consume = [&](const tvec (&v)[U]) {
-#pragma unroll
-        for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
-        if (++in_frame == gpf) {
-            in_frame = 0;
-            acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;      // mean = sum / P, as torch does (LTM.py:304)
-            racc.x = fmaf(val, acc.x, racc.x); racc.y = fmaf(val, acc.y, racc.y);
-            racc.z = fmaf(val, acc.z, racc.z); racc.w = fmaf(val, acc.w, racc.w);
-            acc = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(src + (long)i * d4);
-    int g = 0;
-    for (; g + 2 < n_groups; g += 2) {
-        const tvec* s1 = src + (long)(g + 1) * U * d4;
-#pragma unroll
-        for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(s1 + (long)i * d4);
-        consume(va);
-        const tvec* s2 = src + (long)(g + 2) * U * d4;
-#pragma unroll
-        for (int i = 0; i < U; ++i) va[i] = __builtin_nontemporal_load(s2 + (long)i * d4);
-        consume(vb);
-    }
-    if (g + 1 < n_groups) {
-        const tvec* s1 = src + (long)(g + 1) * U * d4;
-#pragma unroll
-        for (int i = 0; i < U; ++i) vb[i] = __builtin_nontemporal_load(s1 + (long)i * d4);
-        consume(va);
-        consume(vb);
-    } else {
-        consume(va);
-    }
-    __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + (c * op.rows + r) * (long)d4 + c4);
     }
 }
 
@@ -434,6 +248,7 @@ extern "C" long infv_exp_wg_stamps(long long* host, long cap) {
 }
 #endif
 
+#ifdef INFV_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------------
 // 2d. pool_rows2_kernel with the token rows streamed global -> LDS directly (`buffer_load_dwordx4 ... lds`, no VGPR destination):
 //     NB 1-KiB pieces in flight per wave, each lane reads back its own 16 bytes and adds them in token order -- the same
@@ -513,6 +328,8 @@ __global__ __launch_bounds__(1024) void pool_rows2_dma_kernel(const float* __res
 #endif
 }
 
+#endif
+
 template <class Tok>
 static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
                                       hipStream_t stream, int u, int lds_pad, int max_wgs) {
@@ -524,7 +341,6 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<2, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -533,6 +349,7 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
     const dim3 block(4 * slices * 64);
     static const int prio = [] { const char* e = exp_env("INFV_POOL_PRIO"); return e ? atoi(e) : 0; }();
+#ifdef INFV_EXPERIMENTS
     static const int want_dma = [] { const char* e = exp_env("INFV_POOL_DMA"); return e ? atoi(e) : 0; }();
     if (want_dma && sizeof(typename Tok::vec) == 16 && P >= 6 && slices == 3) {
         // (12 waves x 6 KiB + 12 KiB of parked frame means = 84 KB: the padding size of the register-load kernel)
@@ -549,10 +366,10 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
                            n_rows_total, R, exp_stamps_reserve(WG_POOL, grid));
         return hipGetLastError();
     }
+#endif
     long long* stamps = exp_stamps_reserve(WG_POOL, grid);
     if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
-    else if (u >= 4) hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
-    else hipLaunchKernelGGL((pool_rows2_kernel<2, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
+    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
     return hipGetLastError();
 }
 
@@ -563,51 +380,7 @@ hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int
                   : launch_pool_rows2_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs);
 }
 
-bool pool_rows_supported(int P, int d) { return P % 4 == 0 && d % 4 == 0; }
 bool pool_rows2_supported(int d) { return d % 4 == 0 && ((d / 4 + 63) / 64) * 4 * 64 <= 1024; }
-
-template <int U, int NT, class Tok>
-static hipError_t launch_pool_rows_v(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                     hipStream_t stream, int lds_pad, int max_wgs) {
-    const int d4 = d / 4, slices = (d4 + 63) / 64;
-    const long n_units = (long)n_chunks * op.rows * slices;
-    if (lds_pad > 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<U, NT, Tok>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-    }
-    unsigned grid = (unsigned)((n_units + NT / 64 - 1) / (NT / 64));
-    if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
-    hipLaunchKernelGGL((pool_rows_kernel<U, NT, Tok>), dim3(grid), dim3(NT), lds_pad, stream,
-                       k, (long)T * P * d4, P, d4, slices, op, n_units, R);
-    return hipGetLastError();
-}
-
-template <class Tok>
-static hipError_t launch_pool_rows_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                     hipStream_t stream, int u, int nt, int lds_pad, int max_wgs) {
-    if (P % 8 != 0 && u > 4) u = 4;
-    if (nt == 512) {
-        if (u >= 8) return launch_pool_rows_v<8, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-        if (u >= 4) return launch_pool_rows_v<4, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-        return launch_pool_rows_v<2, 512, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-    }
-    if (u >= 8) return launch_pool_rows_v<8, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-    if (u >= 4) return launch_pool_rows_v<4, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-    return launch_pool_rows_v<2, 256, Tok>(k, n_chunks, T, P, d, op, R, stream, lds_pad, max_wgs);
-}
-
-hipError_t launch_pool_rows(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                            hipStream_t stream, int u, int nt, int lds_pad, int max_wgs) {
-    if (op.rows == 0 || n_chunks == 0) return hipSuccess;
-    if (!pool_rows_supported(P, d)) return hipErrorInvalidValue;
-    return k_bf16 ? launch_pool_rows_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad, max_wgs)
-                  : launch_pool_rows_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, nt, lds_pad, max_wgs);
-}
 
 // ======================================================================================
 // 3. projection GEMM (NT):  C[sk][m][o] = sum_{k in split sk} A[m][k] * Wrow(o)[k]

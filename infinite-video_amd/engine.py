@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .basis_maps import NB_BINS, NB_SAMPLES, Plan, build_plan
+from .basis_maps import NB_BINS, NB_SAMPLES, Plan, build_gaussian_plan, build_plan
 
 ProjTensors = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]   # (wk, bk, wv, bv)
 
@@ -51,7 +51,10 @@ class LTMEngine:
     def __init__(self, num_basis: int, n_heads: int, head_size: int, d_in: int, tokens_per_frame: int,
                  tau: float, sticky: bool, n_layers: int = 1, max_q: int = 32,
                  device: Optional[torch.device] = None, nb_samples: int = NB_SAMPLES,
-                 max_batch_chunks: int = 32):
+                 max_batch_chunks: int = 32, gaussian_sigmas: Optional[Sequence[float]] = None):
+        """``gaussian_sigmas``: use the reference's Gaussian basis family (``add_gaussian_basis_functions``,
+        long_term_attention_gibbs.py:167-174: centres ``linspace(0, 1, num_basis // len(sigmas))`` x these widths) instead
+        of the rectangular one the active reference module builds; every step then takes the dense per-call path."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("LTMEngine needs a HIP device (no CPU fallback exists)")
@@ -62,6 +65,7 @@ class LTMEngine:
         self.dm = n_heads * head_size
         self.tau, self.sticky, self.L, self.S = float(tau), bool(sticky), n_layers, nb_samples
         self.max_q = max_q
+        self.gaussian_sigmas = tuple(float(x) for x in gaussian_sigmas) if gaussian_sigmas else None
         cfg = _lib.Config(num_basis, n_heads, head_size, d_in, tokens_per_frame, n_layers, nb_samples,
                           int(self.sticky), max_q, max_batch_chunks)
         handle = C.c_void_p()
@@ -83,7 +87,8 @@ class LTMEngine:
     def ensure_plan(self, T: int) -> Plan:
         if T in self._plans:
             return self._plans[T]
-        p = build_plan(int(T), self.N, self.tau, self.S)
+        p = (build_gaussian_plan(int(T), self.N, self.tau, self.gaussian_sigmas, self.S) if self.gaussian_sigmas
+             else build_plan(int(T), self.N, self.tau, self.S))
         arrs = dict(
             first_row_box=_np_i32(p.first_row_box), first_row_begin=_np_i32(p.first_row_begin),
             first_row_end=_np_i32(p.first_row_end), first_box_val=_np_f32(p.first_box_val),
@@ -115,6 +120,12 @@ class LTMEngine:
                     bin_box2=dn["bin_box2"].ctypes.data_as(_lib.i32p), edge_box2=dn["edge_box2"].ctypes.data_as(_lib.i32p),
                     uniform_box2=dn["uniform_box2"].ctypes.data_as(_lib.i32p))
                 _lib.check(self.lib.infv_ltm_set_dense_plan(self._h, C.byref(ds)))
+            if p.psi:
+                # a basis family whose psi(t) is a dense row (the reference's Gaussian family): psi wherever the step evaluates it
+                pn = {k: _np_f32(getattr(p, k)) for k in ("psi_edge", "psi_bin", "psi_uniform", "psi_grid", "grid_w")}
+                ps = _lib.PsiPlanStruct(T=int(T), n_grid=int(p.psi_grid.shape[0]),
+                                        **{k: v.ctypes.data_as(_lib.f32p) for k, v in pn.items()})
+                _lib.check(self.lib.infv_ltm_set_psi_plan(self._h, C.byref(ps)))
         self._plans[T] = p
         return p
 

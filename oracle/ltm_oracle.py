@@ -110,10 +110,21 @@ def _trim(rows: int, l: int) -> slice:
     return slice(l // 2, rows - (l // 2))
 
 
-def dense_ridge_operator(l: int, positions: torch.Tensor, num_basis: int) -> torch.Tensor:
-    """G = F^T (F F^T + ridge I)^-1, trimmed (LTM.py:68-84), as dense fp32 ATen calls."""
+def gaussian_membership(t: torch.Tensor, num_basis: int, sigmas) -> torch.Tensor:
+    """[M] points -> [M, N] values of the reference's GAUSSIAN family: centres x widths of add_gaussian_basis_functions
+    (LTM.py:167-174), psi(t) = phi((t - mu) / sigma) / sigma as GaussianBasisFunctions.evaluate / batch_evaluate compute it
+    (BASIS.py:155-164; both are the same fp32 elementwise sequence)."""
+    mu, sigma = torch.meshgrid(torch.linspace(0, 1, num_basis // len(sigmas)), torch.Tensor(list(sigmas)), indexing="ij")
+    mu, sigma = mu.flatten().unsqueeze(0), sigma.flatten().unsqueeze(0)
+    z = (t.reshape(-1, 1).to(torch.float32) - mu) / sigma
+    return (1. / math.sqrt(2 * math.pi) * torch.exp(-.5 * z ** 2)) / sigma
+
+
+def dense_ridge_operator(l: int, positions: torch.Tensor, num_basis: int, psi=None) -> torch.Tensor:
+    """G = F^T (F F^T + ridge I)^-1, trimmed (LTM.py:68-84), as dense fp32 ATen calls; ``psi(t) -> [M, N]`` selects the
+    basis family (default: the rectangular one)."""
     F = torch.zeros(num_basis, positions.size(0))
-    F[:, :] = box_membership(positions, num_basis).t()
+    F[:, :] = (psi(positions) if psi is not None else box_membership(positions, num_basis)).t()
     eye = torch.eye(num_basis)
     G = F.t().matmul((F.matmul(F.t()) + RIDGE * eye).inverse())
     return G[_trim(G.size(0), l), :]
@@ -328,8 +339,12 @@ class DenseOracle:
     def __init__(self, num_basis: int, n_heads: int, head_size: int, tau: float, sticky: bool,
                  proj_key: torch.nn.Linear, proj_value: torch.nn.Linear,
                  pool_shape: Sequence[int] = (32,), nb_samples: int = NB_SAMPLES,
-                 density_side_effect: bool = False):
+                 density_side_effect: bool = False, gaussian_sigmas: Sequence[float] = None):
+        """``gaussian_sigmas``: the reference module with its builder hook pointed at its own Gaussian builder
+        (add_gaussian_basis_functions, LTM.py:167-174) -- every psi evaluation below then uses that family."""
         self.N, self.H, self.dh = num_basis, n_heads, head_size
+        self._psi = (lambda t: gaussian_membership(t, num_basis, gaussian_sigmas)) if gaussian_sigmas else \
+                    (lambda t: box_membership(t, num_basis))
         self.tau, self.sticky, self.S = tau, sticky, nb_samples
         self.proj_key, self.proj_value = proj_key, proj_value
         self.pool_shape = tuple(pool_shape)
@@ -341,18 +356,18 @@ class DenseOracle:
     # -- per-call basis construction (LTM.py:67-165; rebuilt on every forward, :298) --
     def _build(self, L: int):
         N = self.N
-        self.G_first = dense_ridge_operator(L, first_positions(L), N)
-        self.G_inf = dense_ridge_operator(self.S + L, inf_positions(L, self.tau, self.S), N)
+        self.G_first = dense_ridge_operator(L, first_positions(L), N, self._psi)
+        self.G_inf = dense_ridge_operator(self.S + L, inf_positions(L, self.tau, self.S), N, self._psi)
         old = torch.arange(1, self.S + 1).float() * self.tau / self.S
         rows = None
         for t in old:                                   # LTM.py:153-157 (S sequential cats)
-            r = box_membership((t / self.tau).reshape(1), N)
+            r = self._psi((t / self.tau).reshape(1))
             rows = r if rows is None else torch.cat([rows, r], 0)
         self.uniform_samples = rows
         self.bins = torch.linspace(0, 1, NB_BINS + 1)
 
     def _scores_at(self, t: torch.Tensor) -> torch.Tensor:
-        psis = box_membership(t, self.N)                             # [M,N]  LTM.py:225
+        psis = self._psi(t)                                          # [M,N]  LTM.py:225
         query = self.queries / (self.dh ** 0.5)
         keys = torch.matmul(self.keys.transpose(-1, -2), psis.T)     # [1,H,dh,M]
         return torch.matmul(query, keys)                             # [1,H,Q,M]
@@ -377,7 +392,7 @@ class DenseOracle:
                 t = torch.distributions.Categorical(torch.ones(1)).sample((self.S, 1))
                 ts = (t * (self.bins[b + 1] - self.bins[b]) / 1 + self.bins[b]).transpose(1, 0)
                 self.last_bins = b.reshape(-1)
-                samples = box_membership(ts[0], self.N).contiguous()
+                samples = self._psi(ts[0]).contiguous()
             else:
                 samples = self.uniform_samples
             old = self.B_past.transpose(-1, -2).matmul(samples.transpose(-1, -2))   # [1,d,S]
@@ -403,7 +418,7 @@ class DenseOracle:
         self.values = values.view(1, self.N, self.H, self.dh).transpose(1, 2)
         # expected value on the 1000-point grid (LTM.py:251-286)
         t = torch.linspace(0, 1, GRID_POINTS)
-        psi = box_membership(t, self.N)                               # [M,N]
+        psi = self._psi(t)                                            # [M,N]
         prob = self._density(t)                                       # [1,H,Q,M]
         # p(t) psi_n(t) as the reference materialises it (LTM.py:276-282): a batched
         # [.,1,1] x [.,1,N] outer product per grid point -> [1,H,Q,N,M] (393 MB at the

@@ -73,6 +73,16 @@ DENSE_CASES = [
 ]
 
 
+# The reference's GAUSSIAN basis family as a whole LTM chain (make_gaussian_goldens.py points the module's builder hook at its
+# own add_gaussian_basis_functions, long_term_attention_gibbs.py:167-174): every operator dense, psi(bins[b]) a dense row,
+# the edge scores and the 1000-point read-out dense contractions.
+GAUSS_SIGMAS = [0.03, 0.1]
+GAUSS_CASES = [
+    Case("gauss_chain", N=64, chunk_T=[16, 16, 12, 16], seed_base=9100, n_layers=2, dense=True),
+    Case("gauss_uniform", N=64, sticky=False, chunk_T=[8, 8, 8], seed_base=9300, n_layers=1, dense=True),
+]
+
+
 def call_seed(case: Case, chunk: int, layer: int) -> int:
     return case.seed_base + 16 * chunk + layer
 

@@ -184,6 +184,25 @@ def test_dense_plan_matches_reference_operators(case):
             assert sorted(np.flatnonzero(smp[s_]).tolist()) == sorted(x for x in (int(a), int(b)) if x >= 0)
 
 
+def test_gaussian_plan_operators_match_the_reference_chain():
+    """basis_maps.build_gaussian_plan: both dense ridge operators of every chunk length of the Gaussian-family chains equal what
+    the REAL reference built (golden gauss_chain.npz / gauss_uniform.npz), and psi is a dense, strictly positive row wherever
+    the step evaluates it."""
+    from tests.golden.cases import GAUSS_CASES, GAUSS_SIGMAS, load_golden
+    for case in GAUSS_CASES:
+        g = load_golden(case)
+        for T in sorted(set(case.chunk_T)):
+            p = basis_maps.build_gaussian_plan(T, case.N, case.tau, tuple(GAUSS_SIGMAS))
+            assert p.dense and p.psi
+            # (the N x N inverse comes from LAPACK on the host, as in the reference: same library here, so the bits agree)
+            np.testing.assert_allclose(p.first_GT.T, g[f"T{T}_first_G"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(p.inf_GT.T, g[f"T{T}_inf_G"], rtol=0, atol=1e-6)
+            assert p.psi_edge.shape == (129, case.N) and p.psi_bin.shape == (128, case.N)
+            assert p.psi_uniform.shape == (512, case.N) and p.psi_grid.shape == (1000, case.N)
+            assert float(p.psi_grid.max()) > 1.0 and float(p.psi_grid.min()) >= 0.0
+            assert abs(float(p.grid_w.sum()) - 1.0) < 1e-6
+
+
 def test_gaussian_operator_matches_the_reference_family():
     """Second basis family at operator level: ``compute_G`` of the reference with its own ``GaussianBasisFunctions`` (the golden
     comes from the real module with its builder hook pointed at ``add_gaussian_basis_functions``,

@@ -10,7 +10,7 @@ import torch
 from oracle import ltm_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-from tests.golden.cases import CASES, DENSE_CASES, call_uniforms, case_inputs, load_golden
+from tests.golden.cases import CASES, DENSE_CASES, GAUSS_CASES, GAUSS_SIGMAS, call_uniforms, case_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -207,6 +207,56 @@ def test_dense_operator_chain_matches_the_reference(dev, case):
             np.testing.assert_allclose(eng.last_scores(l, case.Q), g[tag + "_scores"], rtol=1e-4, atol=2e-5)
     if len(set(case.chunk_T)) == 1:
         eng2 = _engine(case, dev)
+        us = np.stack([[call_uniforms(case, c, l) for l in range(case.n_layers)] for c in range(len(case.chunk_T))])
+        whole = eng2.consolidate(torch.from_numpy(np.stack(ks)).to(dev), q, projs, torch.from_numpy(us).to(dev), new_doc=True)
+        assert torch.equal(whole, torch.stack(outs))
+
+
+@pytest.mark.parametrize("case", GAUSS_CASES, ids=lambda c: c.name)
+def test_gaussian_family_chain_matches_the_reference(dev, case):
+    """The reference's GAUSSIAN basis family as a whole LTM step: psi(t) is a dense row, so the resampled
+    rows (B_past^T psi(bins[b]), LTM.py:207-210), the edge scores of the sticky density (:197-203,224-230) and the 1000-point
+    read-out (:251-286) are dense fp32-MFMA contractions (csrc/ltm_psi.hip).  Goldens: the REAL reference module with its
+    builder hook pointed at its own ``add_gaussian_basis_functions`` (tests/golden/make_gaussian_goldens.py), sticky chain of
+    four chunks on two layers (one ragged) and a uniform-resampling chain.  The free-running HIP chain must reproduce every
+    drawn bin, the probabilities, B, contexts and scores.  (The ridge operators are taken from the golden: the inverse of the
+    ill-conditioned Gaussian Gram matrix depends on the host's LAPACK in the 5th digit; tests/test_host_cpu.py pins the host
+    builder to the same G in the build container.)"""
+    from infinite_video_amd.engine import LTMEngine
+    g = load_golden(case)
+    ks, qs, ws = case_inputs(case)
+    eng = LTMEngine(case.N, case.H, case.dh, case.d, case.P, tau=case.tau, sticky=case.sticky, n_layers=case.n_layers,
+                    max_q=case.Q, device=dev, gaussian_sigmas=GAUSS_SIGMAS)
+    for T in sorted(set(case.chunk_T)):
+        p = eng.ensure_plan(T)
+        assert p.dense and p.psi
+        eng.set_dense_operators(T, g[f"T{T}_first_G"].T.copy(), g[f"T{T}_inf_G"].T.copy())
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    q = torch.from_numpy(np.stack(qs)).to(dev)
+    outs = []
+    for c in range(len(case.chunk_T)):
+        new_doc = c in case.new_doc_at
+        u = np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)])
+        ctx = eng.forward(torch.from_numpy(ks[c]).to(dev), q, projs, torch.from_numpy(u).to(dev), new_doc=new_doc)
+        outs.append(ctx.clone())
+        ctx = ctx.cpu().numpy()
+        for l in range(case.n_layers):
+            tag = f"c{c}_l{l}"
+            if case.sticky and not new_doc:
+                bins, _, probs = eng.last_draw(l)
+                np.testing.assert_allclose(probs, g[tag + "_probs"], rtol=2e-5, atol=1e-9)
+                np.testing.assert_array_equal(bins, g[tag + "_bins"])      # == the reference's own draw
+            B, _ = eng.export_state(l)
+            np.testing.assert_allclose(B.cpu().numpy(), g[tag + "_B"], rtol=0, atol=B_TOL)
+            np.testing.assert_allclose(ctx[l], g[tag + "_ctx"], rtol=0, atol=CTX_TOL)
+            np.testing.assert_allclose(eng.last_scores(l, case.Q), g[tag + "_scores"], rtol=1e-4, atol=2e-5)
+    if len(set(case.chunk_T)) == 1:
+        # consolidate() loops over chunks for such plans: same bits as the per-chunk chain
+        eng2 = LTMEngine(case.N, case.H, case.dh, case.d, case.P, tau=case.tau, sticky=case.sticky, n_layers=case.n_layers,
+                         max_q=case.Q, device=dev, gaussian_sigmas=GAUSS_SIGMAS)
+        T = case.chunk_T[0]
+        eng2.ensure_plan(T)
+        eng2.set_dense_operators(T, g[f"T{T}_first_G"].T.copy(), g[f"T{T}_inf_G"].T.copy())
         us = np.stack([[call_uniforms(case, c, l) for l in range(case.n_layers)] for c in range(len(case.chunk_T))])
         whole = eng2.consolidate(torch.from_numpy(np.stack(ks)).to(dev), q, projs, torch.from_numpy(us).to(dev), new_doc=True)
         assert torch.equal(whole, torch.stack(outs))

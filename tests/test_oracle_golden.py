@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import ltm_oracle as O
-from tests.golden.cases import CASES, DENSE_CASES, call_seed, call_uniforms, case_inputs, load_golden
+from tests.golden.cases import (CASES, DENSE_CASES, GAUSS_CASES, GAUSS_SIGMAS, call_seed, call_uniforms, case_inputs,
+                                load_golden)
 
 FAST = [c for c in CASES if max(c.chunk_T) <= 16]
 BIG = [c for c in CASES if max(c.chunk_T) > 16]
@@ -55,11 +56,13 @@ def test_closed_form_chain_matches_reference(case):
             np.testing.assert_allclose(sc, g[tag + "_scores"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("case", FAST + BIG[:1] + DENSE_CASES, ids=lambda c: c.name)
+@pytest.mark.parametrize("case", FAST + BIG[:1] + DENSE_CASES + GAUSS_CASES, ids=lambda c: c.name)
 def test_dense_port_chain_matches_reference(case):
     """The reference-shaped port consumes torch's global generator like the reference.  DENSE_CASES: num_basis whose fp32
-    boxes overlap (two non-zeros in rows of G, histogram edges in two boxes) -- the dense port is their oracle."""
+    boxes overlap (two non-zeros in rows of G, histogram edges in two boxes) -- the dense port is their oracle.
+    GAUSS_CASES: the reference's Gaussian basis family as whole chains (tests/golden/make_gaussian_goldens.py)."""
     g = load_golden(case)
+    gauss = case in GAUSS_CASES
     ks, qs, ws = case_inputs(case)
     layers = []
     for l in range(case.n_layers):
@@ -69,7 +72,7 @@ def test_dense_port_chain_matches_reference(case):
             pk.weight.copy_(torch.from_numpy(wk)); pk.bias.copy_(torch.from_numpy(bk))
             pv.weight.copy_(torch.from_numpy(wv)); pv.bias.copy_(torch.from_numpy(bv))
         layers.append(O.DenseOracle(case.N, case.H, case.dh, case.tau, case.sticky, pk, pv,
-                                    pool_shape=case.pool_shape))
+                                    pool_shape=case.pool_shape, gaussian_sigmas=GAUSS_SIGMAS if gauss else None))
     n_chunks = len(case.chunk_T) if (case in FAST or case.dense) else 2
     with torch.no_grad():
         for c in range(n_chunks):
