@@ -783,6 +783,8 @@ struct StepS {                       // critical work of the chunk entering the 
     const Operator* op; bool inf; const float* Snew; const double* u; int sk; long ss;   // Snew: scores part of the chunk's first output row
 };
 
+constexpr int kPollDelay = 0;       // units of 64 clocks between role S's deposit and its first poll (INFV_S_POLL_DELAY in the experiments build)
+
 struct FastPipe {
     infv_ltm_handle h; const Plan& plan; int Q; const ProjPtrs& pp; hipStream_t stream;
     long counter = 0;                // chunks that entered the chain in this call
@@ -887,6 +889,7 @@ struct FastPipe {
         for (int i = 0; i < 3; ++i) b.acc[i] = h->mass_acc[i].as<unsigned long long>();
         b.arrive = h->sync_words.as<unsigned int>(); b.error = h->err_dev;
         b.spin_limit = h->spin_limit; b.expect_extra = h->expect_extra;
+        { static const int pd = [] { const char* e = exp_env("INFV_S_POLL_DELAY"); return e ? atoi(e) : kPollDelay; }(); b.poll_delay = pd; }
         { static const int fl = [] { const char* e = exp_env("INFV_S_FLAGS"); return e ? atoi(e) : 0; }(); b.exp_flags = fl; }
         if (h->trace_cap > counter) {
             b.trace_steps = (int)((h->trace_cap - counter < n) ? h->trace_cap - counter : n);

@@ -398,6 +398,7 @@ __device__ inline float mailbox_total(const unsigned long long* mbox, int L, int
     return t;
 }
 
+#ifdef INFV_EXPERIMENTS
 // part[l][0][j] = total of bin j of the step whose mailboxes have parity `parity` (fast path -> per-call path hand-over)
 __global__ void mailbox_to_part_kernel(const unsigned long long* __restrict__ mbox, int L, int G, int parity, int parts_pitch, float* __restrict__ part) {
     const int l = blockIdx.x, j = threadIdx.x;
@@ -408,6 +409,9 @@ hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, 
     hipLaunchKernelGGL(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
     return hipGetLastError();
 }
+#else
+hipError_t launch_mailbox_to_part(const unsigned long long*, int, int, int, int, float*, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 __device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 
@@ -927,8 +931,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
                 if (!(a.exp_flags & 16))
                     atomicAdd(&acc_cur[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
             }
-            // re-arm the poll right behind the deposit and go round: this wave issues nothing else until it has read it
-            if (wave == 0 && !last && !(a.exp_flags & 16)) poll_pair(acc_cur);
+            // re-arm the poll behind the deposit and go round: this wave issues nothing else until it has read it.  A poll that
+            // reaches the memory side before the slowest workgroup's adds returns an incomplete count and costs a second round
+            // trip, so the first poll is held back by poll_delay x 64 clocks (tuned in situ: chain_ab.sh)
+            if (wave == 0 && !last && !(a.exp_flags & 16)) {
+                for (int dly = 0; dly < a.poll_delay; ++dly) __builtin_amdgcn_s_sleep(1);
+                poll_pair(acc_cur);
+            }
         } else if (wave == 0) {
             // ---- this workgroup's row sums of the step -> its mailbox: one 16-byte store per lane = two {mass, tag} granules
             float t0 = 0.f, t1 = 0.f;

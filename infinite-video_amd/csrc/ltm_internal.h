@@ -158,6 +158,7 @@ struct ChainBatchArgs {
     unsigned int* arrive;           // [L] arrival counters, zero at launch
     unsigned int* error;            // host-visible word, set to 1 if a wait timed out
     int spin_limit;                 // polls before a wait gives up
+    int poll_delay;                 // chain_batch3_kernel: units of 64 clocks between a step's deposit and its first poll
     int exp_flags;                  // INFV_S_FLAGS (timing experiments): 1 no s_setprio, 2 long sleep between polls, 4 no point-score stores, 8 no loader requests, 16 no exchange (deposit / poll)
     int expect_extra;               // fault injection (tests): arrivals expected beyond the launch's workgroups
     const float* probs_override; unsigned override_mask;     // teacher forcing of step 0

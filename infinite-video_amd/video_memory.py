@@ -114,8 +114,8 @@ def _recv(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
 
 
 def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Sequence,
-                      u_local: Optional[torch.Tensor], group=None, handoff: bool = False
-                      ) -> Tuple[torch.Tensor, ConsolidatedMemory]:
+                      u_local: Optional[torch.Tensor], group=None, handoff: bool = False,
+                      timings: Optional[dict] = None) -> Tuple[torch.Tensor, ConsolidatedMemory]:
     """Consolidate this rank's block of chunks and all-gather the consolidated memory.
 
     k_local [C_local, T*P, d]; q [L, Q, dm]; u_local [C_local, L, S] (rows keyed by global chunk id).
@@ -133,7 +133,12 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
     for bit -- and the ranks run one after the other, so it does not scale.
 
     This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
-    raises if the persistent chain kernel reported a failure instead of passing an invalid memory on."""
+    raises if the persistent chain kernel reported a failure instead of passing an invalid memory on.
+
+    ``timings`` (a dict, benchmarks only): accumulates ``shard_s`` (this rank's consolidation + packing, up to the sync in
+    front of the collective) and ``allgather_s`` (the collective, synchronised) so that a multi-GPU line decomposes."""
+    import time
+    t_begin = time.perf_counter() if timings is not None else 0.0
     have_group = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if have_group else 1
     rank = dist.get_rank(group) if have_group else 0
@@ -150,6 +155,13 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
         _send(blob, rank + 1, group)
     payload = pack_local_memory(engine, ctx)         # stream-ordered behind the consolidation: no host round trip in between
     engine.sync()                                    # a latched chain failure raises here, before anything is handed on
+    t_shard = time.perf_counter() if timings is not None else 0.0
     gathered = _all_gather_payload(payload, world, group) if have_group else payload
+    if timings is not None:
+        if have_group and payload.is_cuda:
+            torch.cuda.synchronize(payload.device)
+        timings["shard_s"] = timings.get("shard_s", 0.0) + (t_shard - t_begin)
+        timings["allgather_s"] = timings.get("allgather_s", 0.0) + (time.perf_counter() - t_shard)
+        timings["calls"] = timings.get("calls", 0) + 1
     mem = unpack_memory(gathered, world, engine.L, engine.N, engine.d, q.shape[1], engine.dm)
     return ctx, mem

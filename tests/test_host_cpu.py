@@ -139,11 +139,51 @@ def test_experiments_build_keeps_the_register_footprint_of_the_shipped_kernels(t
         return out
     shipped, exp = vgprs("libinfv_ltm.so"), vgprs("libinfv_ltm_exp.so")
     pipeline = [k for k in shipped if re.search(r"pool_rows2_kernel|pool_frames_kernel|gemm_nt_lw_kernel|uc_fast_kernel|"
-                                                r"chain_batch2_kernel|alpha_rows2_kernel|build_rows_kernel", k)]
+                                                r"chain_batch3_kernel|alpha_rows2_kernel|build_rows_kernel", k)]
     assert len(pipeline) >= 8
     granule = lambda v: (v + 7) // 8                                 # registers are allocated in blocks of 8
     diff = {k: (shipped[k], exp.get(k)) for k in pipeline if k not in exp or granule(exp[k]) != granule(shipped[k])}
     assert not diff, diff
+
+
+def _kernel_names(lib, tmp_path):
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("ROCm LLVM binutils not found")
+    d = tmp_path / ("names_" + lib)
+    d.mkdir()
+    shutil.copy(os.path.join(os.path.dirname(_lib.LIB_PATH), lib), d / lib)
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", lib], cwd=d, capture_output=True, check=True)
+    names = set()
+    for f in sorted(os.listdir(d)):
+        if "amdgcn" in f:
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], cwd=d, capture_output=True, text=True, check=True).stdout
+            names |= set(re.findall(r"\.name:\s+(\S+)", notes))
+    return names
+
+
+def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
+    """A/B variants live in the experiments build only: the shipped code object has ONE persistent role-S kernel (16-row tiles,
+    atomics exchange), ONE instantiation per pooling form and token type it can select, no LDS-DMA / mailbox / 8-row-tile
+    variants, none of the kernels deleted in round 4 (grid-stride fused pooling, rolling double-buffered pooling, round 2-3's
+    chain_batch2)."""
+    shipped, exp = _kernel_names("libinfv_ltm.so", tmp_path), _kernel_names("libinfv_ltm_exp.so", tmp_path)
+    def having(names, frag):
+        return sorted(n for n in names if frag in n)
+    assert len(having(shipped, "chain_batch3_kernel")) == 1 and "Lb0" in having(shipped, "chain_batch3_kernel")[0]
+    assert len(having(exp, "chain_batch3_kernel")) == 4
+    for gone in ("chain_batch2_kernel", "pool_rows_kernel", "pool_frames_db_kernel"):
+        assert not having(shipped, gone) and not having(exp, gone), gone
+    for exp_only in ("pool_rows2_dma_kernel", "mailbox_to_part_kernel"):
+        assert not having(shipped, exp_only) and having(exp, exp_only), exp_only
+    assert len(having(shipped, "pool_frames_kernel")) == 4          # {padded 512-thread, plain 256-thread} x {fp32, bf16 tokens}
+    assert len(having(shipped, "pool_rows2_kernel")) == 4           # {8, 4 loads per burst} x {fp32, bf16 tokens}
+    # the general-psi step (Gaussian family) and the dense step are product paths
+    for needed in ("psi_gemm_kernel", "psi_update_kernel", "psi_masses_kernel", "psi_grid_kernel", "psi_ctx_kernel",
+                   "dense_update_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "gemm_nt_lw_kernel"):
+        assert having(shipped, needed), needed
 
 
 def test_product_package_never_imports_the_oracle():

@@ -217,3 +217,24 @@ def test_qformer_block_sums_reproduce_the_global_mean_over_chunks():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_rank_body_end_to_end_with_a_stub_engine():
+    """``python bench.py --gpus 2 --stub-engine``: the parent spawns two ranks through torch.distributed.run (127.0.0.1
+    rendezvous), each shards the video, runs warm-up + timed steps through consolidate_video (gloo all-gather), the clock is the
+    max over ranks and EXACTLY ONE JSON line appears on stdout, printed by rank 0, carrying the shard / all-gather decomposition
+    a SCALE line needs.  The engine is a stand-in (no GPU here); everything around it is the code the 8-GPU run executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-engine", "--chunks", "6",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["stub_engine"] is True
+    assert d["config"]["chunks"] == 6 and d["config"]["chunks_per_gpu"] == 3
+    assert d["gathered_counts"] == [3.0, 3.0]                      # every rank's block arrived in the all-gather
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["shard_ms"] > 0 and d["allgather_ms"] >= 0

@@ -283,9 +283,6 @@ _VARIANTS = [
     {},                                                        # the experiments build with no knob set
     {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
     {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
-    {"INFV_POOL_ROWS": "1"},                                   # long-lived fused pool + rows kernel
-    {"INFV_POOL_ROWS": "1", "INFV_PR_NT": "256", "INFV_PR_U": "8", "INFV_PR_WGS": "300"},   # ... grid-stride, 4-wave workgroups
-    {"INFV_POOL_DB": "2"},                                     # rolling double-buffered pooling kernel
     {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
     {"INFV_VPROJ_ON_UC": "1"},                                 # V' half of the projection as its own GEMM on the UC stream
     {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
@@ -308,6 +305,28 @@ def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
         got = run(dict(v, INFV_LTM_LIBRARY="exp"), f"v{i}.npz")
         for key in base:
             np.testing.assert_array_equal(base[key], got[key], err_msg=f"{v}: {key}")
+
+
+def test_xcd_local_mailbox_exchange_variant(dev, tmp_path):
+    """INFV_CHAIN_XCD=1 (experiments build): role S exchanges its bin masses through mailboxes inside one XCD's L2 (XCD-aware
+    grid + placement handshake, csrc/ltm_chain_batch.hip).  The totals are fp32 sums of per-workgroup row sums in a fixed order
+    instead of the exact fixed-point totals of the atomics exchange: same draws (but for a flip within rounding of a cdf
+    edge), contexts and memory equal to fp32 rounding; and the result must not depend on the placement (sc1 mailboxes when the
+    handshake finds the layer on several XCDs: forced with INFV_S_FLAGS=32) -- bit for bit."""
+    def run(env_add, name):
+        path = str(tmp_path / name)
+        _run_child(_VARIANT_CHILD, env_add, path)
+        return {k_: v for k_, v in np.load(path).items()}
+    base = run({}, "base.npz")
+    xcd = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "1"}, "xcd.npz")
+    far = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "1", "INFV_S_FLAGS": "32"}, "far.npz")
+    for key in base:
+        np.testing.assert_array_equal(xcd[key], far[key], err_msg=f"placement changed {key}")
+    assert int((base["bins"] != xcd["bins"]).sum()) <= 1
+    for key in ("a", "b"):
+        assert float(np.abs(base[key] - xcd[key]).max()) <= 1e-5, key
+    for key in ("B0", "B1"):
+        assert float(np.abs(base[key] - xcd[key]).max()) <= 2e-6, key
 
 
 @pytest.mark.parametrize("n_chunks,max_batch,split", [(33, 42, 0), (45, 7, 0), (70, 28, 37), (129, 42, 1), (97, 13, 50),
