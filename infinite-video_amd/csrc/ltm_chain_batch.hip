@@ -896,7 +896,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
             for (int j = 0; j < RPW; ++j) mx[j] = fmaxf(wave_max(mx[j]), 0.f);
             float d0[RPW], d1[RPW], d128[RPW];
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) { d0[j] = expf(es0[j] - mx[j]); d1[j] = expf(es1[j] - mx[j]); d128[j] = expf(0.f - mx[j]); }
+            // (hardware exp2 / reciprocal: the masses feed the draw through a sum over 384 rows and two normalisations; their
+            //  ~1e-6 relative error is a twentieth of the 2e-5 the probabilities are held to, and 45 of the row phase's ~200
+            //  instructions per row go -- the phase is issue-bound, two waves per SIMD)
+            for (int j = 0; j < RPW; ++j) { d0[j] = __expf(es0[j] - mx[j]); d1[j] = __expf(es1[j] - mx[j]); d128[j] = __expf(0.f - mx[j]); }
             float d0n[RPW], d1n[RPW], d0nn[RPW], d1nn[RPW], zz[RPW];
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int row = wave + kBRows * j;
-                const float inv_z = 1.0f / zz[j];
+                const float inv_z = __builtin_amdgcn_rcpf(zz[j]);
                 // mass of interval j+1 -> bin j (cum[j+1]-cum[j], LTM.py:201-202): lanes take j = lane and lane+64 (< 127); the
                 // two masses of a lane go out as one 8-byte LDS word (what the row sum below reads)
                 float2 mm;
@@ -925,9 +928,14 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         B3STAMP(4);
         if constexpr (!MBOX) {
             if (tid < kBins - 1) {
-                float t = 0.f;
+                float mr[TR];
 #pragma unroll
-                for (int r = 0; r < TR; ++r) t += Msm[r * kMPitch + acc_word(tid)];
+                for (int r = 0; r < TR; ++r) mr[r] = Msm[r * kMPitch + acc_word(tid)];
+#pragma unroll
+                for (int w = TR / 2; w >= 1; w >>= 1)                   // pairwise: log2(TR) dependent adds instead of TR
+#pragma unroll
+                    for (int r = 0; r < w; ++r) mr[r] += mr[r + w];
+                const float t = mr[0];
                 if (!(a.exp_flags & 16))
                     atomicAdd(&acc_cur[acc_word(tid)], (unsigned long long)((double)t * kMassScale + 0.5) + (1ull << kArriveShift));
             }
