@@ -184,6 +184,9 @@ class Plan:
     psi_uniform: np.ndarray = None    # [S, N]            psi at the non-sticky resample positions
     psi_grid: np.ndarray = None       # [GRID_POINTS, N]  psi on the read-out grid
     grid_w: np.ndarray = None         # [GRID_POINTS]     trapezoid weights of that grid
+    # num_basis that is not a multiple of 16 (the kernels' tile): the device sees N_pad = the next multiple, the extra basis
+    # functions have zero operator rows and zero read-out weight (padded_N(N)); 0 = no padding
+    N_pad: int = 0
 
 
 def gaussian_psi(t: torch.Tensor, N: int, sigmas) -> torch.Tensor:
@@ -269,15 +272,24 @@ def _first_box(pairs: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(pairs[:, 0], dtype=np.int32)
 
 
+def padded_N(N: int) -> int:
+    """What the device allocates for ``num_basis`` = N: the kernels tile the basis dimension by 16."""
+    return (N + 15) // 16 * 16
+
+
 def _build_dense_plan(T: int, N: int, tau: float, S: int) -> Plan:
-    """Plan for a num_basis whose boxes overlap where the step looks: dense operators from the reference's sequence and
-    two-box tables for the histogram edges and the resampling points.  The 1000-point grid of expected_value()
-    (long_term_attention_gibbs.py:251-286) must still see at most one box per point (true for every multiple of 16 up
-    to 512 except 432): the read-out keeps its closed form."""
+    """Plan for a num_basis whose boxes overlap where the step looks -- or that is no multiple of 16: dense operators from
+    the reference's sequence and two-box tables for the histogram edges and the resampling points.  The 1000-point grid of
+    expected_value() (long_term_attention_gibbs.py:251-286) must still see at most one box per point (true for every
+    multiple of 16 up to 512 except 432): the read-out keeps its closed form.
+    A num_basis that is no multiple of 16 is padded to the next one: the operators get zero rows for the extra basis
+    functions (their coefficients stay 0), the read-out weights zero entries (they never receive attention mass), and no
+    edge / bin / resampling table refers to them -- the N real basis functions compute exactly what the reference does."""
     t = torch.linspace(0, 1, GRID_POINTS)
     gbox2 = boxes2_of(t, N)
-    if int((gbox2[:, 1] >= 0).sum()):
-        raise UnsupportedBasis(f"a point of the read-out grid lies in two boxes for num_basis={N}")
+    # a point of the read-out grid in two boxes (num_basis 37, 432, ...): no count-weighted closed form -- the step then takes
+    # the general-psi form with the rectangular psi itself as dense 0/1 rows (infv_ltm_set_psi_plan), like the Gaussian family
+    grid_overlap = bool(int((gbox2[:, 1] >= 0).sum()))
     gbox = gbox2[:, 0]
     dx = (t[1:] - t[:-1]).double().numpy()
     wt = np.zeros(GRID_POINTS)
@@ -293,25 +305,34 @@ def _build_dense_plan(T: int, N: int, tau: float, S: int) -> Plan:
     t_uni = (torch.arange(1, S + 1).float() * tau / S) / tau
     bin_box2, edge_box2, uniform_box2 = boxes2_of(bins[:-1], N), boxes2_of(mod, N), boxes2_of(t_uni, N)
     none_i = np.zeros(0, dtype=np.int32)
-    zeros_n = np.zeros(N, dtype=np.float32)
+    Np = padded_N(N)
+    zeros_n = np.zeros(Np, dtype=np.float32)
+    pad_rows = lambda GT: np.ascontiguousarray(np.concatenate([GT, np.zeros((Np - N, GT.shape[1]), np.float32)], 0))
+    psi_kw = {}
+    if grid_overlap:
+        pad_cols = lambda m: np.ascontiguousarray(np.concatenate([m.numpy().astype(np.float32), np.zeros((m.shape[0], Np - N), np.float32)], 1))
+        psi_kw = dict(psi=True, psi_edge=pad_cols(membership(mod, N)), psi_bin=pad_cols(membership(bins[:-1], N)),
+                      psi_uniform=pad_cols(membership(t_uni, N)), psi_grid=pad_cols(membership(t, N)), grid_w=wt.astype(np.float32))
     return Plan(
         T=T, N=N, tau=tau, S=S,
         # the sparse operator tables are unused with a dense plan: empty but valid
         first_row_box=none_i, first_row_begin=none_i, first_row_end=none_i, first_box_val=zeros_n,
         inf_row_box=none_i, inf_row_begin=none_i, inf_row_end=none_i, inf_box_val=zeros_n,
-        inf_old_ptr=np.zeros(N + 1, dtype=np.int32), inf_old_slot=none_i,
-        readout_w=w.astype(np.float32), readout_w_out=float(wt[gbox < 0].sum()),
+        inf_old_ptr=np.zeros(Np + 1, dtype=np.int32), inf_old_slot=none_i,
+        readout_w=np.concatenate([w, np.zeros(Np - N)]).astype(np.float32), readout_w_out=float(wt[gbox < 0].sum()),
         edge_box=_first_box(edge_box2), edge_dx=edge_dx, bin_box=_first_box(bin_box2), uniform_idx=_first_box(uniform_box2),
-        dense=True, first_GT=_dense_operator_T(T, _positions_first(T), N),
-        inf_GT=_dense_operator_T(S + T, _positions_inf(T, tau, S), N),
+        dense=True, first_GT=pad_rows(_dense_operator_T(T, _positions_first(T), N)),
+        inf_GT=pad_rows(_dense_operator_T(S + T, _positions_inf(T, tau, S), N)),
         bin_box2=np.ascontiguousarray(bin_box2), edge_box2=np.ascontiguousarray(edge_box2),
-        uniform_box2=np.ascontiguousarray(uniform_box2))
+        uniform_box2=np.ascontiguousarray(uniform_box2), N_pad=Np if Np != N else 0, **psi_kw)
 
 
 @lru_cache(maxsize=64)
 def build_plan(T: int, N: int, tau: float, S: int = NB_SAMPLES) -> Plan:
     if T < 2:
         raise UnsupportedBasis("chunks of a single frame are empty in the reference (G[0:-0])")
+    if N % 16:
+        return _build_dense_plan(T, N, tau, S)            # (the reference takes any --num_basis: padded dense form)
     try:
         return _build_sparse_plan(T, N, tau, S)
     except OverlappingBoxes:

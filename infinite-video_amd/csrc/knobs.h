@@ -1,7 +1,7 @@
 // Environment knobs of libinfv_ltm.so.
 //
-// The shipped library reads four documented options from the environment (all parity-tested; see README.md):
-//   INFV_VPROJ_SPLIT, INFV_VQF_FP32, INFV_VQF_FUSE, INFV_VQF_SPLIT_CACHE_GB          -> plain getenv at their call sites.
+// The shipped library reads five documented options from the environment (all parity-tested; see README.md):
+//   INFV_PROJ_X6, INFV_VPROJ_SPLIT, INFV_VQF_FP32, INFV_VQF_FUSE, INFV_VQF_SPLIT_CACHE_GB   -> plain getenv at their call sites.
 // Everything else -- timing experiments that produce garbage (INFV_SKIP, INFV_S_FLAGS), in-kernel stamps, fault
 // injection, occupancy pads, stream priorities and the A/B selectors of variants that are not the default -- goes through
 // exp_env(), which only looks at the environment in the experiments build (-DINFV_EXPERIMENTS:

@@ -337,6 +337,9 @@ int dense_step(infv_ltm_handle h, const Plan& plan, const float* kbar, int T, co
     if (inf && h->cfg.sticky) {
         if (!u) return fail(INFV_ERR_INVALID, "sticky step on an existing memory needs the Gibbs uniforms u");
         if (h->parts <= 0) return fail(INFV_ERR_STATE, "no sticky histogram available (import_state or step first)");
+        // (checked BEFORE the draw consumes the one-shot masks: an unsupported request leaves the handle as it was)
+        if (h->forced_mask && h->forced_mask != (1u << h->L) - 1u)
+            return fail(INFV_ERR_UNSUPPORTED, "dense plans: infv_ltm_set_bins must force every layer of the handle or none");
         Timed t_(h->prof, INFV_KERNEL_DRAW, stream);
         HIP_TRY(launch_draw(h->bin_part[h->pc].as<float>(), h->parts, h->probs_override.as<float>(), h->override_mask,
                             plan.sticky(), u, h->S, h->L, h->probs.as<float>(), h->bins.as<int32_t>(), h->idx.as<int32_t>(),
@@ -344,8 +347,6 @@ int dense_step(infv_ltm_handle h, const Plan& plan, const float* kbar, int T, co
         h->override_mask = 0;
         // a forced draw replaces the resampled bins (infv_ltm_set_bins); get_draw still returns the step's own
         bins = h->forced_mask ? h->bins_forced.as<int32_t>() : h->bins.as<int32_t>();
-        if (h->forced_mask && h->forced_mask != (1u << h->L) - 1u)
-            return fail(INFV_ERR_UNSUPPORTED, "dense plans: infv_ltm_set_bins must force every layer of the handle or none");
         h->forced_mask = 0;
         bins_stride = h->S;
         pos_box2 = dp.bin_box2.as<int32_t>();
@@ -495,7 +496,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     if (const char* f = getenv("INFV_VPROJ_SPLIT")) h->v_split = atoi(f) != 0;
     if (const char* f = getenv("INFV_PROJ_X6")) h->proj_x6 = atoi(f) != 0;
     if (const char* f = exp_env("INFV_VPROJ_ON_UC")) h->v_on_uc_mode = atoi(f) != 0 ? 1 : 0;
-    h->ring = kPSets * h->maxC + 2;         // a slot is rewritten three sub-batches after the UC kernel that read it
+    h->ring = kPSets * h->maxC + 2;         // a slot is rewritten kPSets sub-batches after the one whose UC kernel read it
     if (e == hipSuccess) e = h->cqbuf.reserve((size_t)h->L * h->H * h->maxQ * sizeof(float));
     if (e == hipSuccess) e = h->qt_buf.reserve((size_t)h->L * h->H * h->maxQ * h->d * sizeof(float));
     if (e == hipSuccess) e = h->probs.reserve((size_t)h->L * h->n_bins * sizeof(float));

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .basis_maps import NB_BINS, NB_SAMPLES, Plan, build_gaussian_plan, build_plan
+from .basis_maps import NB_BINS, NB_SAMPLES, Plan, build_gaussian_plan, build_plan, padded_N
 
 ProjTensors = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]   # (wk, bk, wv, bv)
 
@@ -66,7 +66,12 @@ class LTMEngine:
         self.tau, self.sticky, self.L, self.S = float(tau), bool(sticky), n_layers, nb_samples
         self.max_q = max_q
         self.gaussian_sigmas = tuple(float(x) for x in gaussian_sigmas) if gaussian_sigmas else None
-        cfg = _lib.Config(num_basis, n_heads, head_size, d_in, tokens_per_frame, n_layers, nb_samples,
+        # the reference takes any --num_basis (run_inference_inf_video_llama_nextqa.py:61); the kernels tile the basis dimension
+        # by 16, so the device holds Np = the next multiple of 16 -- the extra basis functions are inert (basis_maps.padded_N)
+        self.Np = padded_N(num_basis)
+        if self.Np != num_basis and self.gaussian_sigmas:
+            raise ValueError("the Gaussian family needs num_basis to be a multiple of 16")
+        cfg = _lib.Config(self.Np, n_heads, head_size, d_in, tokens_per_frame, n_layers, nb_samples,
                           int(self.sticky), max_q, max_batch_chunks)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -140,6 +145,9 @@ class LTMEngine:
         inf = _np_f32(inf_GT) if inf_GT is not None else np.zeros((self.N, self.S + T), np.float32)
         if first.shape != (self.N, T) or inf.shape != (self.N, self.S + T):
             raise ValueError(f"operators must be [{self.N}, {T}] and [{self.N}, {self.S + T}]")
+        if self.Np != self.N:
+            first = _np_f32(np.concatenate([first, np.zeros((self.Np - self.N, T), np.float32)]))
+            inf = _np_f32(np.concatenate([inf, np.zeros((self.Np - self.N, self.S + T), np.float32)]))
         bins = torch.linspace(0, 1, _NB + 1)
         mod = bins.clone()
         mod[0] = -.000001
@@ -341,16 +349,18 @@ class LTMEngine:
     # ------------------------------------------------------------------ state
     def export_state(self, layer: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(B_past [N, d], unnormalised sticky bin masses [127]) of one layer."""
-        B = torch.empty(self.N, self.d, device=self.device, dtype=torch.float32)
+        B = torch.empty(self.Np, self.d, device=self.device, dtype=torch.float32)
         mass = torch.empty(NB_BINS, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_export_state(self._h, layer, _ptr(B), _ptr(mass), _stream(self.device)))
-        return B, mass[:NB_BINS - 1]
+        return B[:self.N], mass[:NB_BINS - 1]
 
     def import_state(self, layer: int, B: torch.Tensor, bin_mass: Optional[torch.Tensor], proj: ProjTensors):
         _check_dev(B, self.device, "B")
         if tuple(B.shape) != (self.N, self.d):
             raise ValueError(f"B must be [{self.N}, {self.d}]")
+        if self.Np != self.N:                                   # inert rows of the padding basis functions
+            B = torch.cat([B, torch.zeros(self.Np - self.N, self.d, device=B.device, dtype=B.dtype)])
         if bin_mass is not None:
             _check_dev(bin_mass, self.device, "bin_mass")
             if bin_mass.numel() != NB_BINS - 1:
@@ -398,11 +408,11 @@ class LTMEngine:
         return bins, idx, probs
 
     def last_scores(self, layer: int, Q: int) -> np.ndarray:
-        sc = np.empty((self.H, Q, self.N), np.float32)
+        sc = np.empty((self.H, Q, self.Np), np.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_get_draw(self._h, layer, None, None, None,
                                                   sc.ctypes.data_as(_lib.f32p), _stream(self.device)))
-        return sc
+        return sc[:, :, :self.N]
 
     def set_probs(self, layer: int, probs: np.ndarray):
         p = _np_f32(probs)

@@ -70,6 +70,12 @@ CASES = [
 DENSE_CASES = [
     Case("n96_dense", N=96, chunk_T=[16, 16, 12, 16], seed_base=8000, n_layers=2, dense=True),
     Case("n48_uniform_dense", N=48, sticky=False, chunk_T=[8, 8, 8], seed_base=8500, n_layers=1, dense=True),
+    # any --num_basis, as the reference takes it (run_inference_inf_video_llama_nextqa.py:61): not a multiple of the kernels'
+    # 16-wide tile (the device pads with inert basis functions) ...
+    Case("n100_any", N=100, chunk_T=[8, 8, 6, 8], seed_base=9500, n_layers=2, dense=True),
+    # ... and one whose 1000-point read-out grid has a point in two fp32 boxes (no count-weighted closed form: the general-psi
+    # step with the rectangular psi as dense 0/1 rows)
+    Case("n37_grid_overlap", N=37, chunk_T=[8, 8, 8], seed_base=9700, n_layers=1, dense=True),
 ]
 
 

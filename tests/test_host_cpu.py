@@ -214,11 +214,15 @@ def test_dense_plan_matches_reference_operators(case):
     g = load_golden(case)
     for T in sorted(set(case.chunk_T)):
         p = basis_maps.build_plan(T, case.N, case.tau)
-        assert p.dense and p.first_GT.shape == (case.N, T) and p.inf_GT.shape == (case.N, 512 + T)
+        Np = basis_maps.padded_N(case.N)                          # a num_basis that is no multiple of 16 is padded with inert rows
+        assert p.dense and p.first_GT.shape == (Np, T) and p.inf_GT.shape == (Np, 512 + T) and p.N_pad == (Np if Np != case.N else 0)
+        assert not p.first_GT[case.N:].any() and not p.inf_GT[case.N:].any() and not p.readout_w[case.N:].any()
         # (Tensor.inverse is LAPACK: allow the last bits to depend on the host's BLAS kernels)
-        np.testing.assert_allclose(p.first_GT.T, g[f"T{T}_first_G"], rtol=0, atol=1e-6)
-        np.testing.assert_allclose(p.inf_GT.T, g[f"T{T}_inf_G"], rtol=0, atol=1e-6)
-        assert int((p.inf_GT != 0).sum(0).max()) == 2            # the reason the sparse form does not apply
+        np.testing.assert_allclose(p.first_GT[:case.N].T, g[f"T{T}_first_G"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(p.inf_GT[:case.N].T, g[f"T{T}_inf_G"], rtol=0, atol=1e-6)
+        if case.N % 16 == 0:
+            assert int((p.inf_GT != 0).sum(0).max()) == 2        # the reason the sparse form does not apply
+        assert p.psi == (case.N == 37)                            # a read-out grid point in two boxes: general-psi step
         smp = g[f"T{T}_uniform_samples"]                          # [S, N] psi of the uniform resampling positions
         for s_, (a, b) in enumerate(p.uniform_box2):
             assert sorted(np.flatnonzero(smp[s_]).tolist()) == sorted(x for x in (int(a), int(b)) if x >= 0)
@@ -265,8 +269,27 @@ def test_every_multiple_of_16_has_a_plan_and_sparse_ones_stay_sparse():
         assert not basis_maps.build_plan(256, N, .75).dense
     for N in (48, 96, 192):
         assert basis_maps.build_plan(256, N, .75).dense
-    with pytest.raises(basis_maps.UnsupportedBasis):             # a read-out grid point in two boxes: no closed form
-        basis_maps.build_plan(16, 432, .75)
+    # a read-out grid point in two boxes (432, 37, ...): no closed-form read-out -- the plan carries the rectangular psi itself
+    # as dense 0/1 rows and the step takes the general-psi form (432 itself is beyond the kernels' N <= 256)
+    p = basis_maps.build_plan(16, 432, .75)
+    assert p.dense and p.psi and p.psi_grid.shape == (1000, 432) and float(p.psi_grid.sum(1).max()) == 2.0
+
+
+def test_any_num_basis_up_to_256_has_a_plan():
+    """The reference takes any ``--num_basis`` (run_inference_inf_video_llama_nextqa.py:61).  Values that are no multiple of the
+    kernels' 16-wide tile get the dense form padded with inert basis functions (zero operator rows, zero read-out weight);
+    the real ones are untouched: the tables never refer to a padding index."""
+    for N in (2, 7, 20, 37, 50, 100, 129, 250, 255):
+        for T in (6, 8, 16):
+            p = basis_maps.build_plan(T, N, .75)
+            Np = basis_maps.padded_N(N)
+            assert p.dense and p.N == N and p.N_pad == Np and Np % 16 == 0 and Np - N < 16
+            assert p.first_GT.shape == (Np, T) and not p.first_GT[N:].any() and not p.inf_GT[N:].any()
+            for tab in (p.bin_box2, p.edge_box2, p.uniform_box2):
+                assert int(tab.max()) < N
+            assert p.readout_w.shape == (Np,) and not p.readout_w[N:].any()
+            if p.psi:
+                assert p.psi_grid.shape == (1000, Np) and not p.psi_grid[:, N:].any() and not p.psi_edge[:, N:].any()
 
 
 def test_bench_gpus_flag_spawns_ranks_without_touching_the_gpu(monkeypatch):
