@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 template <int U, class Tok>
 __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict__ k_, long chunk_stride, int P, int d4, int slices,
                                                           OperatorView op, long n_rows_total, float* __restrict__ R,
-                                                          long long* __restrict__ stamps, int prio) {
+                                                          long long* __restrict__ stamps, int prio, int tid_addr) {
     typedef typename Tok::vec tvec;
     extern __shared__ __attribute__((aligned(16))) float pr2_lds[];          // [4 frames][d4] float4
     floatx4* park = reinterpret_cast<floatx4*>(pr2_lds);
@@ -181,10 +181,25 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
             const int f = f0 + fi;
             if (f < fe && col_ok) {
                 const tvec* frame = reinterpret_cast<const tvec*>(k_) + c * chunk_stride + (long)f * P * d4;       // wave-uniform
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<tvec*>(frame), 0, P * d4 * (int)sizeof(tvec), 0x00020000);
-                const int voff = c4 * (int)sizeof(tvec), row_bytes = d4 * (int)sizeof(tvec);
+                const int row_bytes = d4 * (int)sizeof(tvec);
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
                 int p = 0;
+                if (tid_addr) {
+                    // loads with NO vector address operand: the resource has ADD_TID_ENABLE (index = lane id, stride = one lane's
+                    // bytes) and starts at this wave's 64-lane column slice, the row offset is scalar -- nothing of the
+                    // instruction is read from the vector register file, whose read ports a co-resident GEMM's MFMAs keep busy
+                    __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<tvec*>(frame + sl * 64), (short)sizeof(tvec), 64, 1 << 23);
+                    for (; p + U <= P; p += U) {
+                        tvec v[U];
+#pragma unroll
+                        for (int i = 0; i < U; ++i) v[i] = Tok::load_nt(rt, 0, (p + i) * row_bytes);
+#pragma unroll
+                        for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
+                    }
+                    for (; p < P; ++p) acc += Tok::widen(Tok::load_nt(rt, 0, p * row_bytes));
+                } else {
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<tvec*>(frame), 0, P * d4 * (int)sizeof(tvec), 0x00020000);
+                const int voff = c4 * (int)sizeof(tvec);
                 for (; p + U <= P; p += U) {
                     tvec v[U];
 #pragma unroll
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
                     for (int i = 0; i < U; ++i) acc += Tok::widen(v[i]);
                 }
                 for (; p < P; ++p) acc += Tok::widen(Tok::load_nt(rs, voff, p * row_bytes));
+                }
                 acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;              // mean = sum / P, as torch does (LTM.py:304)
                 park[fi * d4 + c4] = acc;
             }
@@ -330,6 +346,8 @@ __global__ __launch_bounds__(1024) void pool_rows2_dma_kernel(const float* __res
 
 #endif
 
+constexpr int kPoolTidAddr = 0;           // pool_rows2_kernel: lane-id addressed buffer loads (no vector address operand); INFV_POOL_TID in the experiments build
+
 template <class Tok>
 static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
                                       hipStream_t stream, int u, int lds_pad, int max_wgs) {
@@ -368,8 +386,10 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     }
 #endif
     long long* stamps = exp_stamps_reserve(WG_POOL, grid);
-    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
-    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio);
+    static const int want_tid = [] { const char* e = exp_env("INFV_POOL_TID"); return e ? atoi(e) : kPoolTidAddr; }();
+    const int tid_addr = (want_tid && d4 % 64 == 0) ? 1 : 0;               // every lane of every slice holds a column
+    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
+    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
     return hipGetLastError();
 }
 

@@ -288,6 +288,7 @@ _VARIANTS = [
     {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
     {"INFV_GEMM_LW": "0"},                                     # projection GEMM without loader waves
     {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
+    {"INFV_POOL_TID": "1"},                                    # pooling kernel with lane-id addressed loads (no vector address operand)
     {"INFV_GEMM_SLICES": "2"},                                 # projection GEMM launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
 ]
