@@ -924,6 +924,9 @@ struct FastPipe {
                         (hb[7] - hb[0]) > 0 ? 0.1 * (double)(hb[15] - hb[8]) / (double)(hb[7] - hb[0]) : 0.0);
                 if (prev_n > 2) fprintf(stderr, "[batch-S avg] %.3f us per step over steps 1..%d of the previous launch\n",
                                         0.01 * (double)(hb[17] - hb[16]) / (prev_n - 2), prev_n - 1);
+                fprintf(stderr, "[batch-S launch] previous end -> entry %.2f us, set-up %.2f us, step 0 %.2f us, last step + exit %.2f us, entry -> end %.2f us\n",
+                        0.01 * (double)(hb[18] - hb[21]), 0.01 * (double)(hb[19] - hb[18]), 0.01 * (double)(hb[16] - hb[19]),
+                        0.01 * (double)(hb[20] - hb[17]), 0.01 * (double)(hb[20] - hb[18]));
             }
         }
         {
@@ -1295,16 +1298,28 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // 126 score tiles, 252 V' tiles); short ones (e.g. a 256-chunk shard of a multi-GPU run) keep 32 so that the
     // pipeline fills and drains quickly.  INFV_SUB_BATCH overrides.
     static const int sub_env = [] { const char* e = exp_env("INFV_SUB_BATCH"); return e ? atoi(e) : 0; }();
+    // (experiments) INFV_SUB_RAMP=<n>: short calls run their first sub-batch with 32 chunks (fast fill) and the following ones
+    // with n (fewer role-S launches); needs max_batch_chunks >= n
+    static const int ramp_env = [] { const char* e = exp_env("INFV_SUB_RAMP"); return e ? atoi(e) : 0; }();
     int sub = h->maxC;
     if (sub_env > 0) sub = sub_env < h->maxC ? sub_env : h->maxC;
     else if (n_chunks < 768 && sub > 32) sub = 32;             // (28 while the V' GEMM ran on the UC stream; 2.84 -> 2.68 ms per 256 chunks)
-    const int n_batches = (n_chunks - first_c + sub - 1) / sub;
+    // first chunk of every sub-batch (+ the end of the call)
+    std::vector<int> bstart;
+    {
+        int later = sub;
+        if (sub_env <= 0 && n_chunks < 768 && ramp_env > sub) later = ramp_env < h->maxC ? ramp_env : h->maxC;
+        for (int c0 = first_c, i = 0; c0 < n_chunks; ++i) { bstart.push_back(c0); c0 += (i == 0) ? sub : later; }
+        bstart.push_back(n_chunks);
+        if (later > sub) sub = later;                           // (workspaces below are sized for the largest sub-batch)
+    }
+    const int n_batches = (int)bstart.size() - 1;
     const size_t rows = plan->inf.rows;
     std::vector<int> sks(n_batches > 0 ? n_batches : 1, 1);
     std::vector<long> sss(n_batches > 0 ? n_batches : 1, 0);
     auto batch_range = [&](int b, int* c0, int* nb) {
-        *c0 = first_c + b * sub;
-        *nb = (n_chunks - *c0 < sub) ? n_chunks - *c0 : sub;
+        *c0 = bstart[b];
+        *nb = bstart[b + 1] - bstart[b];
     };
     // The pooling has its own stream so that the HBM-bound pooling of batch b+2 overlaps the MFMA-bound projection of
     // batch b+1 (pooled frames are triple-buffered either way); INFV_SPLIT_POOL=0 puts it back on the side stream.

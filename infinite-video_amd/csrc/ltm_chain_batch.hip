@@ -445,6 +445,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     if (!(a.exp_flags & 1)) __builtin_amdgcn_s_setprio(3);
     wg_stamp_begin(a.wg_stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.dbg != nullptr && l == 0 && blk == 0 && tid == 0) a.dbg[18] = wall_clock64();      // (stamps: kernel entry of workgroup 0)
     const int rows = a.op.rows, tabw = a.op.tabw;
     const Batch3Smem m = batch3_smem(N, a.S, rows, tabw, RPW);
     const int h = blk % H, qs = blk / H;
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     __syncthreads();
 
 #define B3STAMP(k) do { if (a.dbg != nullptr && b == 0 && tid == 0 && i == 5) { a.dbg[k] = wall_clock64(); a.dbg[8 + k] = clock64(); } } while (0)
+    if (a.dbg != nullptr && b == 0 && tid == 0) a.dbg[19] = wall_clock64();                 // (stamps: set-up done)
     for (int i = 0; i < a.n_steps; ++i) {
         B3STAMP(0);
         // (stamps 16 / 17: top of step 1 and of the last step -- the launch's average step without the per-phase stamps' own cost)
@@ -993,6 +995,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     }
     // (the last step's totals stay in the mailboxes: the next launch's step 0 reads them there; whoever continues without
     // mailboxes -- the next call, a per-chunk launch -- gets them from launch_mailbox_to_part)
+    if (a.dbg != nullptr && b == 0 && tid == 0) { a.dbg[21] = a.dbg[20]; a.dbg[20] = wall_clock64(); }   // (stamps: this / the previous launch's end)
     wg_stamp_end(a.wg_stamps);
 }
 

@@ -319,9 +319,9 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     wg_stamp_begin(a.wg_stamps);
 #ifdef INFV_EXPERIMENTS
-    if (a.prio == 3) __builtin_amdgcn_s_setprio(3);          // (experiment INFV_UC_PRIO: issue priority against co-resident pooling waves)
-    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    if ((a.prio & 15) == 3) __builtin_amdgcn_s_setprio(3);          // (experiment INFV_UC_PRIO: issue priority against co-resident pooling waves)
+    else if ((a.prio & 15) == 2) __builtin_amdgcn_s_setprio(2);
+    else if ((a.prio & 15) == 1) __builtin_amdgcn_s_setprio(1);
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, rows = a.op.rows;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
             for (int u = 0; u < 4; ++u)
                 if (al_lds[u] >= 0) *reinterpret_cast<floatx4*>(&Asm[al_lds[u]]) = al_reg[u];
             as0 = asv[0]; as1 = asv[1]; as2 = asv[2]; as3 = asv[3];
-            if (i + 1 < a.n_chunks) prefetch_alpha();
+            if (i + 1 < a.n_chunks && !(a.prio & 32)) prefetch_alpha();      // (prio bit 5: timing experiment, no alpha loads)
         }
         // ---- memory update: X_c[n] = val_n * sum_k X_{c-1}[tab[n][k]] + new row of n ----
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kUcNT) void uc_fast_kernel(UcArgs a) {
             }
         }
         USTAMP(3);
-        if (i + 1 < a.n_chunks) prefetch_tab_new(i + 1);
+        if (i + 1 < a.n_chunks && !(a.prio & 16)) prefetch_tab_new(i + 1);   // (prio bit 4: timing experiment, no table / new-row loads)
         lds_barrier();
         USTAMP(4);
         { floatx4* t = cur; cur = nxt; nxt = t; }
@@ -597,7 +597,8 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
         const int nblk = a.L * (a.d / kUcCols + a.dm / 16);
         b.wg_stamps = exp_stamps_reserve(WG_UC, nblk);
         static const int prio = [] { const char* e = exp_env("INFV_UC_PRIO"); return e ? atoi(e) : 0; }();
-        b.prio = prio;
+        static const int skipm = [] { const char* e = exp_env("INFV_UC_SKIPLOADS"); return e ? atoi(e) : 0; }();   // timing experiments: garbage results
+        b.prio = prio | (skipm << 4);
         const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
         const size_t lds_floats = vfl > bfl ? vfl : bfl;
         hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
