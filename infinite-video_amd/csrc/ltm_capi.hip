@@ -184,6 +184,7 @@ struct infv_ltm_s {
     DeviceBuf bins_forced; unsigned forced_mask = 0;    // one-shot forced draw of the per-call path
     DeviceBuf mass_acc[3];             // fixed-point sticky bin masses [L][kAccShards][128] u64, ring of 3 (read / accumulate / being cleared)
     DeviceBuf uf_all;                  // a consolidate call's Gibbs uniforms as fp32 round-ups [n_chunks][L][S] (chain_batch3_kernel's search)
+    DeviceBuf step_tab;                // per-call path: resolved gather table of the step [L][N][tabw] (written by the draw plane of step_project)
     DeviceBuf psi_Y, psi_E, psi_Eg, psi_alpha;   // general-psi step: resampled rows, edge scores, grid scores / probabilities, read-out weights
     DeviceBuf mbox;                    // chain_batch3_kernel: mailboxes of role S's exchange + placement handshake (chain_mailbox_bytes)
     int mbox_G = 0;                    // workgroups per layer the mailboxes are laid out for
@@ -279,7 +280,7 @@ int upload_operator(Operator& op, int N, int rows, const int32_t* row_box, const
 // draw_done: the draw already ran inside the projection launch (launch_step_project).
 int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float* Pnew, int splitk,
                long split_stride, const float* q, int Q, const ProjPtrs& pp, const double* u, float* ctx,
-               hipStream_t stream, const float* kbar_rows = nullptr, bool draw_done = false) {
+               hipStream_t stream, const float* kbar_rows = nullptr, bool draw_done = false, const int32_t* tab = nullptr) {
     const bool inf = h->has_memory;
     const Operator& op = inf ? plan.inf : plan.first;
     const int32_t* idx = nullptr;
@@ -309,11 +310,11 @@ int chain_step(infv_ltm_handle h, const Plan& plan, const float* R, const float*
     Timed t_(h->prof, INFV_KERNEL_UPDATE, stream);
     HIP_TRY(launch_update(op.view(), h->N, h->d, h->dm, h->L, h->S, idx, idx_stride, R, Pnew, splitk, split_stride,
                           h->B[h->cur].as<float>(), h->KV[h->cur].as<float>(), h->B[nxt].as<float>(),
-                          h->KV[nxt].as<float>(), stream, kbar_rows));
+                          h->KV[nxt].as<float>(), stream, kbar_rows, (inf && h->cfg.sticky && draw_done) ? tab : nullptr));
     }
     h->cur = nxt;
     h->has_memory = true;
-    const int parts = attend_parts(Q, h->H);
+    const int parts = attend_parts(Q, h->H, h->N);
     {
     Timed t_(h->prof, INFV_KERNEL_ATTEND, stream);
     HIP_TRY(launch_attend(q, Q, h->N, h->H, h->L, h->KV[h->cur].as<float>(), pp, plan.w.as<float>(), plan.w_out,
@@ -471,7 +472,7 @@ int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
     h->dm = cfg->n_heads * cfg->head_size; h->P = cfg->tokens_per_frame; h->L = cfg->n_layers;
     h->S = cfg->nb_samples; h->maxQ = cfg->max_q; h->maxC = cfg->max_batch_chunks > 0 ? cfg->max_batch_chunks : 32;
     const size_t nb = (size_t)h->L * h->N;
-    const int max_parts = h->H * ((h->maxQ + 7) / 8);      // finest partial granularity (8-row tiles of the fast path)
+    const int max_parts = h->H * ((h->maxQ + 3) / 4);      // finest partial granularity (4-row tiles of the per-call attend kernel)
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = h->B[i].reserve(nb * h->d * sizeof(float));
@@ -696,6 +697,12 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
         dr.probs_override = h->probs_override.as<float>(); dr.override_mask = h->override_mask; dr.sticky = plan->sticky();
         dr.u = u; dr.S = h->S; dr.probs_out = h->probs.as<float>(); dr.bins_out = h->bins.as<int32_t>(); dr.idx_out = h->idx.as<int32_t>();
         dr.bins_forced = h->bins_forced.as<int32_t>(); dr.forced_mask = h->forced_mask;
+        // the draw also resolves the gather table of the step (per layer: source box of every (box, slot) entry)
+        const size_t need_t = (size_t)h->L * h->N * op.tabw * sizeof(int32_t);
+        if (op.tabw > 0 && op.slot_tab.p != nullptr) {
+            if (need_t > h->step_tab.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->step_tab.reserve(need_t)); }
+            dr.slot_tab = op.slot_tab.as<int32_t>(); dr.tab_entries = h->N * op.tabw; dr.tab_out = h->step_tab.as<int32_t>();
+        }
     }
     int sk = 1;
     {
@@ -703,7 +710,7 @@ int infv_ltm_step(infv_ltm_handle h, const float* kbar, int32_t T, const float* 
         HIP_TRY(launch_step_project(kbar, h->d, h->dm, h->L, op.view(), pp, h->P_ws[0].as<float>(), &sk, dr, stream));
     }
     return chain_step(h, *plan, nullptr, h->P_ws[0].as<float>(), sk, (long)op.rows * n_cols, q, Q, pp, u, ctx, stream, kbar,
-                      dr.n_layers > 0);
+                      dr.n_layers > 0, dr.tab_out);
 }
 
 int infv_ltm_steps(infv_ltm_handle h, const float* kbar, int32_t n_chunks, int32_t T, const float* q, int32_t Q,

@@ -92,6 +92,9 @@ struct StepDraw {
     int n_layers;                   // 0: no draw (first chunk of a document / uniform resampling)
     const float* bin_part; int parts; const float* probs_override; unsigned override_mask; StickyView sticky;
     const double* u; int S; float* probs_out; int32_t* bins_out; int32_t* idx_out; const int32_t* bins_forced; unsigned forced_mask;
+    // optional: the resolved gather table of the step, tab_out[l][e] = source box of entry e of slot_tab (-1: none), so that the
+    // update kernel reads ONE table row per box instead of chasing old_ptr -> old_slot -> idx
+    const int32_t* slot_tab; int tab_entries; int32_t* tab_out;
 };
 hipError_t launch_draw(const float* bin_part, int parts, const float* probs_override, unsigned override_mask,
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
@@ -102,14 +105,15 @@ hipError_t launch_draw(const float* bin_part, int parts, const float* probs_over
 hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
                          int idx_layer_stride, const float* R, const float* Pnew, int splitk,
                          long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
-                         float* KV_next, hipStream_t stream, const float* kbar = nullptr /* R == nullptr: rows built from kbar */);
+                         float* KV_next, hipStream_t stream, const float* kbar = nullptr /* R == nullptr: rows built from kbar */,
+                         const int32_t* tab = nullptr /* [L][N * tabw] resolved source boxes (StepDraw.tab_out): replaces idx */);
 
 // per-call step, first launch: new-row projection with the rows built on the fly + the draw of every layer (one launch)
 hipError_t launch_step_project(const float* kbar, int d, int dm, int n_layers, const OperatorView& op, const ProjPtrs& proj,
                                float* Pnew, int* splitk, const StepDraw& draw, hipStream_t stream);
 
 // scores, count-weighted softmax, read-out and the next sticky histogram partials.
-int attend_parts(int Q, int H);
+int attend_parts(int Q, int H, int N);      // sticky partial rows per layer the attend launch writes (H x query tiles)
 hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, const float* KV, const ProjPtrs& proj,
                          const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
                          float* bin_part, float* scores, hipStream_t stream);

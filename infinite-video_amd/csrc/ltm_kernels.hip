@@ -591,6 +591,12 @@ __global__ __launch_bounds__(256) void step_project_kernel(RowsA ra, int M, int 
                                                 dr.probs_override + l * kBins, ovr, dr.u + (long)l * dr.S, dr.S);
         draw_finish<256, 4>(r, ovr, dr.sticky.bin_box, dr.S, cdf, sidx, gsum, dr.probs_out + l * kBins, dr.bins_out + (long)l * dr.S,
                             dr.idx_out + (long)l * dr.S, nullptr, ((dr.forced_mask >> l) & 1u) ? dr.bins_forced + (long)l * dr.S : nullptr);
+        // resolved gather table for the update kernel (draw_finish ends with a barrier: sidx holds every slot's source box)
+        if (dr.tab_out != nullptr)
+            for (int e = threadIdx.x; e < dr.tab_entries; e += 256) {
+                const int sl = dr.slot_tab[e];
+                dr.tab_out[(long)l * dr.tab_entries + e] = sl >= 0 ? sidx[sl] : -1;
+            }
         return;
     }
     gemm_nt_tile<64, 64, true>(nullptr, ra, M, K, segs, C, ldc, split_stride, k_per_split, 0, smem, smem + 64 * kLdsStride);
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
                                                      const float* __restrict__ B_prev,
                                                      const float* __restrict__ KV_prev,
                                                      float* __restrict__ B_next, float* __restrict__ KV_next,
-                                                     const float* __restrict__ kbar) {
+                                                     const float* __restrict__ kbar, const int32_t* __restrict__ tab) {
     const int n = blockIdx.x, l = blockIdx.y;
     const float val = op.box_val[n];
     const int row = op.box_row[n];
@@ -1008,7 +1014,10 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
     if (R == nullptr && row >= 0) { fb = op.row_begin[row]; fe = op.row_end[row]; }
     const floatx4* kb4 = reinterpret_cast<const floatx4*>(kbar);
     int sb = 0, se = 0;
-    if (op.old_ptr != nullptr && idx != nullptr) { sb = op.old_ptr[n]; se = op.old_ptr[n + 1]; }
+    // with a resolved table the box's sources are one row of `tab` (same slots in the same order as the CSR walk below)
+    const int32_t* my_tab = tab ? tab + ((long)l * N + n) * op.tabw : nullptr;
+    if (my_tab != nullptr) { se = op.tabw; }
+    else if (op.old_ptr != nullptr && idx != nullptr) { sb = op.old_ptr[n]; se = op.old_ptr[n + 1]; }
     const int32_t* my_idx = idx ? idx + (long)l * idx_layer_stride : nullptr;
     const int kv4 = 2 * dm4;                                   // floats4 of a [K'|V'] row
     const int total4 = d4 + kv4;
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
             int src[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                src[k] = (s0 + k < se) ? my_idx[op.old_slot[s0 + k]] : -1;
+                src[k] = (s0 + k < se) ? (my_tab != nullptr ? my_tab[s0 + k] : my_idx[op.old_slot[s0 + k]]) : -1;
                 v[k] = prev[(long)max(src[k], 0) * pitch + cc];
             }
 #pragma unroll
@@ -1072,10 +1081,10 @@ __global__ __launch_bounds__(256) void update_kernel(OperatorView op, int N, int
 hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_layers, int S, const int32_t* idx,
                          int idx_layer_stride, const float* R, const float* Pnew, int splitk,
                          long split_stride, const float* B_prev, const float* KV_prev, float* B_next,
-                         float* KV_next, hipStream_t stream, const float* kbar) {
+                         float* KV_next, hipStream_t stream, const float* kbar, const int32_t* tab) {
     hipLaunchKernelGGL(update_kernel, dim3(N, n_layers), dim3(256), 0, stream, op, N, d / 4, dm / 4, n_layers, S,
                        idx, idx_layer_stride, R, Pnew, splitk, split_stride / 4, B_prev, KV_prev, B_next,
-                       KV_next, kbar);
+                       KV_next, kbar, (op.slot_tab != nullptr && op.tabw > 0) ? tab : nullptr);
     return hipGetLastError();
 }
 
@@ -1207,6 +1216,10 @@ __global__ __launch_bounds__(256) void attend_kernel(const float* __restrict__ q
 // ------------------------------------------------------------------------------------------------------
 constexpr int kAtPitch = 80;                        // LDS pitch of the V' tile: == 16 mod 32 -> conflict-free column reads
 
+// RT = query rows per workgroup: 16 (one MFMA row tile, four rows per wave in turn: 48 workgroups at the headline shape) or 4
+// (one row per wave: 192 workgroups, the row phase -- the longest part, a dependent chain of ~250 instructions per row -- runs
+// once instead of four times per wave; the score and read-out MFMAs then carry 12 idle rows, which costs nothing here).
+template <int RT>
 __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restrict__ q, int Q, int N, int H,
                                                            const float* __restrict__ KV, ProjPtrs proj,
                                                            const float* __restrict__ readout_w, float w_out,
@@ -1245,8 +1258,8 @@ __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restri
     }
     float qa[16];
     {
-        const int row = qt * kQTile + c;
-        if (row < Q) {
+        const int row = qt * RT + c;
+        if (c < RT && row < Q) {
             const floatx4* src = reinterpret_cast<const floatx4*>(ql + (long)row * dm + h * kHeadSize + 16 * g);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -1292,8 +1305,8 @@ __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restri
                 const int row = 4 * g + r;
                 const float sv = acc[r] + cq[row];
                 Ssm[row * sstride + nt * 16 + c] = sv;
-                if (scores != nullptr && qt * kQTile + row < Q)
-                    scores[(((long)l * H + h) * Q + qt * kQTile + row) * N + nt * 16 + c] = sv;
+                if (scores != nullptr && row < RT && qt * RT + row < Q)
+                    scores[(((long)l * H + h) * Q + qt * RT + row) * N + nt * 16 + c] = sv;
             }
         }
     }
@@ -1305,11 +1318,11 @@ __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restri
         if (r < N) *reinterpret_cast<floatx4*>(&Vall[r * kAtPitch + c4 * 4]) = vreg[u];
     }
     __syncthreads();
-    // ---- row phase: wave w takes query rows 4w .. 4w+3 in turn ----
-    const int valid = min(kQTile, Q - qt * kQTile);
+    // ---- row phase: wave w takes query rows (RT / 4) w .. in turn ----
+    const int valid = min(RT, Q - qt * RT);
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * wave + r;
+    for (int r = 0; r < RT / 4; ++r) {
+        const int row = (RT / 4) * wave + r;
         row_phase_row(Ssm + row * sstride, N, row < valid, readout_w, w_out, sticky.edge_box, sticky.edge_dx,
                       Dsm + row * kDPitch, Msm + row * kMPitch, asum + row);
     }
@@ -1317,7 +1330,7 @@ __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restri
     if (tid < kBins - 1) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < kQTile; ++r) t += Msm[r * kMPitch + tid];
+        for (int r = 0; r < RT; ++r) t += Msm[r * kMPitch + tid];
         bin_part[(((long)l * H + h) * QT + qt) * kBins + tid] = t;
     }
     // ---- read-out: acc[r] = sum_n alpha[4g+r][n] * V'[n][16*wave + c], the whole tile is in LDS ----
@@ -1334,8 +1347,8 @@ __global__ __launch_bounds__(256) void attend_small_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r;
-        const int qrow = qt * kQTile + rr;
-        if (qrow < Q) {
+        const int qrow = qt * RT + rr;
+        if (rr < RT && qrow < Q) {
             const int col = 16 * wave + c;
             ctx[((long)l * Q + qrow) * dm + h * kHeadSize + col] = acc[r] + asum[rr] * bv[col];
         }
@@ -1348,7 +1361,16 @@ size_t attend_small_lds_bytes(int N) {
     return floats * sizeof(float);
 }
 
-int attend_parts(int Q, int H) { return H * ((Q + kQTile - 1) / kQTile); }
+// query rows per attend workgroup: 4 (one row per wave) where the small kernel applies, else one 16-row MFMA tile
+static bool attend_small_wanted() {
+    static const bool want_small = [] { const char* e = exp_env("INFV_ATTEND_SMALL"); return !e || atoi(e) != 0; }();
+    return want_small;
+}
+static int attend_tile_rows(int N) {
+    static const int rt_env = [] { const char* e = exp_env("INFV_ATTEND_RT"); return e ? atoi(e) : 4; }();
+    return (attend_small_wanted() && N <= 256 && N % 16 == 0 && rt_env == 4) ? 4 : kQTile;
+}
+int attend_parts(int Q, int H, int N) { const int rt = attend_tile_rows(N); return H * ((Q + rt - 1) / rt); }
 
 size_t attend_lds_bytes(int N) {
     const int sstride = N + 2;
@@ -1359,7 +1381,8 @@ size_t attend_lds_bytes(int N) {
 hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, const float* KV, const ProjPtrs& proj,
                          const float* readout_w, float readout_w_out, const StickyView& sticky, float* ctx,
                          float* bin_part, float* scores, hipStream_t stream) {
-    const int QT = (Q + kQTile - 1) / kQTile;
+    const int rt = attend_tile_rows(N);
+    const int QT = (Q + rt - 1) / rt;
     const size_t lds = attend_lds_bytes(N);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1368,17 +1391,22 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static const bool want_small = [] { const char* e = exp_env("INFV_ATTEND_SMALL"); return !e || atoi(e) != 0; }();
-    if (want_small && N <= 256 && N % 16 == 0) {
+    if (attend_small_wanted() && N <= 256 && N % 16 == 0) {
         static bool attr2 = false;
         if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_small_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_small_kernel<4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attend_small_kernel<16>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr2 = true;
         }
-        hipLaunchKernelGGL(attend_small_kernel, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
-                           KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
+        if (rt == 4)
+            hipLaunchKernelGGL(attend_small_kernel<4>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
+                               KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
+        else
+            hipLaunchKernelGGL(attend_small_kernel<16>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
+                               KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(attend_kernel, dim3(H, QT, n_layers), dim3(256), lds, stream, q, Q, N, H, KV, proj,
