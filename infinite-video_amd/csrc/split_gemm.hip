@@ -135,7 +135,209 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The same contraction with 384 x 128 x 64 tiles: 4 waves stacked along M, each a 96 x 128 block of the output
+// The same contraction with 384 x 128 x 32 tiles: 4 waves stacked along M, each a 96 x 128 block of the output (3 x 4
+// accumulators of 32 x 32, in the AGPR half of the register file; one workgroup per CU, one wave per SIMD).  H*Q = 384 query
+// rows of the video Q-former are one tile: a token row reaches the chip once for all of them.
+//   * operand tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write
+//     instructions, and the loads of k-tile t + 1 fly while the MFMAs of tile t run (two LDS buffers of 64 KB, ONE barrier
+//     per k-tile).  A load instruction lays a wave's 64 x 16 bytes down contiguously, so a tile row is 64 bytes without
+//     padding; bank conflicts are avoided by a swizzle done on the GLOBAL side: the lane that fills 16-byte slot `s` of row
+//     `r` fetches k-segment s ^ ((r >> 2) & 3), and a fragment read of segment g looks in slot g ^ ((r >> 2) & 3) -- any 16
+//     consecutive rows then cover all 64 banks.
+//   * fragments of both 16-deep k-steps of a tile are requested before the first MFMA (112 registers): with one wave per
+//     SIMD nothing else hides the LDS latency.
+// Round 2's form (64-deep tiles staged through registers, two barriers per tile) sat at 38 % MFMA-busy, issue-stalled in
+// front of the matrix pipe behind its own ds_write / ds_read bursts.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kWI = 3, kWJ = 4;                   // 32 x 32 accumulators per wave: kWI along M, kWJ along N
+constexpr int kWRowsA = 4 * 32 * kWI;             // 384 rows of A per workgroup
+constexpr int kWRowsB = 32 * kWJ;                 // 128 rows of B
+constexpr int kDBK = 32;                          // k per tile (two 32x32x16 steps)
+constexpr int kDRow = 2 * kDBK;                   // 64 bytes per tile row
+constexpr int kDArrA = kWRowsA * kDRow, kDArrB = kWRowsB * kDRow;
+constexpr int kDStageA = 2 * kDArrA, kDStageB = 2 * kDArrB;     // hi + lo planes of one k-tile: 48 KB of A, 16 KB of B
+constexpr int kDepthA = 2, kDepthB = 4;           // stages: A comes from L2 (every workgroup reads the same rows), B from HBM
+constexpr int kDLds = kDepthA * kDStageA + kDepthB * kDStageB;  // 163 840 B: all of a CU's LDS
+}  // namespace
+
+// (PROBE: experiments build only, INFV_WIDE_MODE -- 1 = no operand loads, 2 = loads only: timing probes with wrong results)
+template <int PROBE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_kernel(SplitGemm g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {   // XCD-aware tile order (see split_gemm_kernel)
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)((v / gridDim.x) % gridDim.y);
+        bz = (int)(v / (gridDim.x * gridDim.y));
+    }
+    const int m0 = bx * kWRowsA, n0 = by * kWRowsB;
+    const int b = bz / g.splitk, s = bz - b * g.splitk;
+    const int kbeg = s * g.k_per_split;
+    const int kend = (kbeg + g.k_per_split > g.K) ? g.K : kbeg + g.k_per_split;
+    const int ntiles = kend > kbeg ? (kend - kbeg) / kDBK : 0;
+    float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
+
+    // (M % 384 == 0, N % 128 == 0, K % 32 == 0: checked by the launcher -- every load is a whole in-range 16 bytes)
+    const long a0 = (long)b * g.strideA + (long)m0 * g.lda + kbeg, b0 = (long)b * g.strideB + (long)n0 * g.ldb + kbeg;
+    const int a_bytes = (int)((kWRowsA - 1) * g.lda + (kend - kbeg)) * 2, b_bytes = (int)((kWRowsB - 1) * g.ldb + (kend - kbeg)) * 2;
+    // The LDS-DMA loads are written in assembly: through the builtin the compiler knows that they write LDS, cannot tell the
+    // stage being filled from the stage being read, and drains vmcnt(0) in front of the first fragment read of every k-tile --
+    // which would take the B tiles' two-tile head start away again.  (M0 = LDS byte address of the wave's 1-KiB piece; one wait
+    // state between the M0 write and the load.)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const __bf16* p, int bytes) {
+        const unsigned long a = reinterpret_cast<unsigned long>(p);
+        v4i r = {(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), bytes, 0x00020000};
+        return r;
+    };
+    const v4i rah = make_rsrc(g.A_hi + a0, a_bytes), ral = make_rsrc(g.A_lo + a0, a_bytes);
+    const v4i rbh = make_rsrc(g.B_hi + b0, b_bytes), rbl = make_rsrc(g.B_lo + b0, b_bytes);
+    auto dma16 = [](const v4i& rsrc, unsigned lds_addr, int voff, int soff) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr)smem;
+    // one load instruction = 16 tile rows: lane -> (row lane >> 2, slot lane & 3), fetching k-segment slot ^ swizzle(row)
+    const int lrow = lane >> 2, lseg = (lane & 3) ^ ((lane >> 4) & 3);
+    const int va = (lrow * (int)g.lda + lseg * 8) * 2, vb = (lrow * (int)g.ldb + lseg * 8) * 2;
+    const int blk_a = 16 * (int)g.lda * 2, blk_b = 16 * (int)g.ldb * 2;        // bytes between 16-row blocks
+    unsigned char* const smem_b = smem + kDepthA * kDStageA;
+    auto issue_a = [&](int t) {                                                // this wave's 96 rows of A, both planes: 12 pieces
+        const unsigned base = lds0 + (t % kDepthA) * kDStageA;
+        const int kt = t * kDRow;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int blk = wave * 6 + i;
+            dma16(rah, base + blk * 1024, va, blk * blk_a + kt);
+            dma16(ral, base + kDArrA + blk * 1024, va, blk * blk_a + kt);
+        }
+    };
+    auto issue_b = [&](int t) {                                                // 32 of the 128 rows of B, both planes: 4 pieces
+        const unsigned base = lds0 + kDepthA * kDStageA + (t % kDepthB) * kDStageB;
+        const int kt = t * kDRow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = wave * 2 + i;
+            dma16(rbh, base + blk * 1024, vb, blk * blk_b + kt);
+            dma16(rbl, base + kDArrB + blk * 1024, vb, blk * blk_b + kt);
+        }
+    };
+
+    floatx16 acc[kWI][kWJ];
+#pragma unroll
+    for (int i = 0; i < kWI; ++i)
+#pragma unroll
+        for (int j = 0; j < kWJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, kh = lane >> 5;
+    const int swz = (li >> 2) & 3;
+    const int fo0 = li * kDRow + ((kh ^ swz) << 4), fo1 = li * kDRow + (((2 + kh) ^ swz) << 4);     // k-steps 0 and 1
+    const int fa = wave * (32 * kWI) * kDRow;
+    // Issue order ... A(t), B(t + 2) | A(t + 1), B(t + 3) | ...: a wave's pieces land in issue order, so "all but the 4 youngest"
+    // (vmcnt(4)) at the top of iteration t means A(t) and every B up to t + 1 are in LDS while B(t + 2) may still be on its way
+    // from HBM: a B tile has two tile times to arrive, an A tile (L2) one.
+    if (PROBE != 1 && ntiles > 0) {
+        issue_b(0);
+        if (ntiles > 1) issue_b(1);
+        issue_a(0);
+        if (ntiles > 2) issue_b(2);
+    }
+#ifdef INFV_EXPERIMENTS
+    wg_stamp_begin(g.wg_stamps);
+    const long long cyc0 = g.wg_stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#endif
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // this wave's part of A(t), B(t) has landed ...
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // ... everybody's has, and nobody still reads the stages about to be refilled
+        const unsigned char* base = smem + (t % kDepthA) * kDStageA;
+        const unsigned char* base_b = smem_b + (t % kDepthB) * kDStageB;
+        bf16x8 ah[2][kWI], al[2][kWI], bh[2][kWJ], bl[2][kWJ];
+        // fragment reads in the order their MFMAs come (lgkmcnt counts at most 15 reads: one k-step's 14 at a time)
+#define INFV_FRAGS(ks, fo)                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < kWI; ++i) al[ks][i] = *reinterpret_cast<const bf16x8*>(base + kDArrA + fa + i * 32 * kDRow + fo); \
+        _Pragma("unroll") for (int j = 0; j < kWJ; ++j) bh[ks][j] = *reinterpret_cast<const bf16x8*>(base_b + j * 32 * kDRow + fo);            \
+        _Pragma("unroll") for (int i = 0; i < kWI; ++i) ah[ks][i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 32 * kDRow + fo);          \
+        _Pragma("unroll") for (int j = 0; j < kWJ; ++j) bl[ks][j] = *reinterpret_cast<const bf16x8*>(base_b + kDArrB + j * 32 * kDRow + fo);
+        // The three products as three sweeps over the accumulators, a sweep as three rows of four MFMAs; behind row p goes
+        // piece p of the next tiles' loads (A(t + 1): 12 pieces, then B(t + 3): 4).  Issued in one burst the 16 pieces cost this
+        // wave -- the SIMD's only one -- 16 x 60-180 cycles in which the matrix pipe idles (measured: loop = compute-only loop +
+        // 1 400 cycles); one at a time, most of a piece's issue hides behind the 32 cycles of the MFMA in front of it.
+        const bool ld_a = PROBE != 1 && t + 1 < ntiles, ld_b = PROBE != 1 && t + 3 < ntiles;
+        const unsigned next_a = lds0 + ((t + 1) % kDepthA) * kDStageA, next_b = lds0 + kDepthA * kDStageA + ((t + 3) % kDepthB) * kDStageB;
+        const int kt_a = (t + 1) * kDRow, kt_b = (t + 3) * kDRow;
+        auto piece = [&](int p) {                                // p is a constant after unrolling
+            if (p < 12) {
+                const int blk = wave * 6 + (p >> 1);
+                if (ld_a) dma16((p & 1) ? ral : rah, next_a + (p & 1) * kDArrA + blk * 1024, va, blk * blk_a + kt_a);
+            } else if (p < 16) {
+                const int blk = wave * 2 + ((p - 12) >> 1);
+                if (ld_b) dma16((p & 1) ? rbl : rbh, next_b + (p & 1) * kDArrB + blk * 1024, vb, blk * blk_b + kt_b);
+            }
+        };
+#define INFV_SWEEP(X, Y, p0)                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < kWI; ++i) {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0); \
+            if (PROBE != 2) __builtin_amdgcn_sched_barrier(0);                                                                      \
+            piece(p0 + i);                                                                                                          \
+            if (PROBE != 2) __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }
+        INFV_FRAGS(0, fo0)
+        // (left alone the scheduler sinks every fragment read to just before its first use: a stall per read group)
+        __builtin_amdgcn_sched_barrier(0);
+        if (PROBE == 2) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) piece(p);
+            continue;
+        }
+        INFV_SWEEP(al[0], bh[0], 0)
+        INFV_SWEEP(ah[0], bl[0], 3)
+        INFV_FRAGS(1, fo1)                                       // in flight behind the third sweep of k-step 0
+        __builtin_amdgcn_sched_barrier(0);
+        INFV_SWEEP(ah[0], bh[0], 6)
+        INFV_SWEEP(al[1], bh[1], 9)
+        INFV_SWEEP(ah[1], bl[1], 12)
+        INFV_SWEEP(ah[1], bh[1], 15)
+#undef INFV_FRAGS
+#undef INFV_SWEEP
+    }
+#ifdef INFV_EXPERIMENTS
+    if (g.wg_stamps != nullptr) {                // loop only: start, end (100 MHz) and the shader cycles between them above the CU id
+        wg_stamp_end(g.wg_stamps);
+        if (threadIdx.x == 0) {
+            const long long cyc = (long long)__builtin_amdgcn_s_memtime() - cyc0;
+            g.wg_stamps[4 * ((long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)) + 2] |= cyc << 36;
+        }
+    }
+#endif
+    // (Issuing the products as (B fragment, A fragment) transposes the 32 x 32 blocks and gives every lane four consecutive
+    //  columns -- 16-byte stores, a quarter of the instructions -- but a store instruction then writes 32 rows x 32 bytes instead
+    //  of 2 rows x 128 bytes: the scores launch went from 404 to 487 us.  Measured, not kept.)
+#pragma unroll
+    for (int i = 0; i < kWI; ++i)
+#pragma unroll
+        for (int j = 0; j < kWJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 * kWI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int o = n0 + j * 32 + li;
+                __builtin_nontemporal_store(acc[i][j][r], C + (long)m * g.ldc + o);
+            }
+}
+
+#ifdef INFV_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------
+// (experiments build only: the round-2 form of the wide kernel, INFV_SPLIT_GEMM_WIDE=3, kept for A/B runs)
+// The same contraction with 384 x 128 x 64 tiles, operands staged through registers: 4 waves stacked along M, each a 96 x 128 block of the output
 // (3 x 4 accumulators of 32 x 32).  Why: the 128 x 128 kernel above moves as many LDS bytes per k-tile (64 KB written,
 // 128 KB read back as fragments) as its MFMAs take cycles at 128 B/clock -- it is LDS-bound near 30 % of the bf16 MFMA
 // peak.  A 3 x 4 register block reads 14 KB of fragments per 36 MFMAs instead of 8 KB per 12: LDS time is 61 % of the
@@ -143,15 +345,12 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
 // 144 KB of LDS: one workgroup per CU, accumulators in the AGPR half of the register file.
 // ------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int kWI = 3, kWJ = 4;                   // 32 x 32 accumulators per wave: kWI along M, kWJ along N
-constexpr int kWRowsA = 4 * 32 * kWI;             // 384 rows of A per workgroup
-constexpr int kWRowsB = 32 * kWJ;                 // 128 rows of B
 constexpr int kWArrA = kWRowsA * kSPitch, kWArrB = kWRowsB * kSPitch;
 constexpr int kWLds = 2 * kWArrA + 2 * kWArrB;    // A_hi, A_lo, B_hi, B_lo
 constexpr int kWVecA = kWRowsA * 8 / 256, kWVecB = kWRowsB * 8 / 256;   // 16-byte vectors per thread per array tile
 }  // namespace
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_kernel(SplitGemm g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_regs_kernel(SplitGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -264,6 +463,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef INFV_ST_B
 }
 
+#endif
+
 // the wide tiles need whole 384 x 128 tiles and enough of them to fill the chip
 bool split_gemm_wide_applies(const SplitGemm& g) {
     static const int mode = [] { const char* e = exp_env("INFV_SPLIT_GEMM_WIDE"); return e ? atoi(e) : 1; }();
@@ -305,18 +506,43 @@ int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split) {
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad) {
     if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0) return hipSuccess;
     if (lds_pad <= 0 && split_gemm_wide_applies(g)) {
-        static bool attr_w = false;
-        if (!attr_w) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_wide_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_w = true;
-        }
         if (g.K % kSBK || g.k_per_split % kSBK || g.k_per_split <= 0 || g.lda % 8 || g.ldb % 8 || g.strideA % 8 || g.strideB % 8)
             return hipErrorInvalidValue;
+        // (buffer-addressed loads: a tile's rows must lie within 2^31 bytes of its first)
+        if ((long)kWRowsA * g.lda * 2 + 2l * g.K >= (1l << 31) || (long)kWRowsB * g.ldb * 2 + 2l * g.K >= (1l << 31)) return hipErrorInvalidValue;
         dim3 grid((g.M + kWRowsA - 1) / kWRowsA, (g.N + kWRowsB - 1) / kWRowsB, g.nbatch * g.splitk);
-        hipLaunchKernelGGL(split_gemm_wide_kernel, grid, dim3(256), kWLds, stream, g);
-        return hipGetLastError();
+#ifdef INFV_EXPERIMENTS
+        static const bool regs_form = [] { const char* e = exp_env("INFV_SPLIT_GEMM_WIDE"); return e && atoi(e) == 3; }();
+        if (regs_form) {
+            static bool attr_r = false;
+            if (!attr_r) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_wide_regs_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_r = true;
+            }
+            hipLaunchKernelGGL(split_gemm_wide_regs_kernel, grid, dim3(256), kWLds, stream, g);
+            return hipGetLastError();
+        }
+#endif
+        SplitGemm gg = g;
+        gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z);
+        auto go = [&](auto kernel) {
+            static bool attr_w = false;                    // (one per instantiation)
+            if (!attr_w) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_w = true;
+            }
+            hipLaunchKernelGGL(kernel, grid, dim3(256), kDLds, stream, gg);
+            return hipGetLastError();
+        };
+#ifdef INFV_EXPERIMENTS
+        static const int probe = [] { const char* e = exp_env("INFV_WIDE_MODE"); return e ? atoi(e) : 0; }();
+        if (probe == 1) return go(split_gemm_wide_kernel<1>);
+        if (probe == 2) return go(split_gemm_wide_kernel<2>);
+#endif
+        return go(split_gemm_wide_kernel<0>);
     }
     {                                                   // tiles live in dynamic LDS; `lds_pad` more (unused) bytes cap the kernel at one workgroup per CU
         static bool attr_set = false;

@@ -58,6 +58,7 @@ struct SplitGemm {
     const __bf16* B_hi; const __bf16* B_lo; long ldb, strideB;
     float* C; long ldc, strideC, split_stride;
     int M, N, K, k_per_split, splitk, nbatch;
+    long long* wg_stamps;            // residency / loop-cycle experiment (wg_stamps.h), or nullptr
 };
 hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad = 0);
 // fp32-accurate contraction from three bf16 planes per operand (six partial products, fp32 accumulation): C = A . B^T
