@@ -135,38 +135,43 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(SplitGemm g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The same contraction with 384 x 128 x 32 tiles: 4 waves stacked along M, each a 96 x 128 block of the output (3 x 4
-// accumulators of 32 x 32, in the AGPR half of the register file; one workgroup per CU, one wave per SIMD).  H*Q = 384 query
-// rows of the video Q-former are one tile: a token row reaches the chip once for all of them.
+// The same contraction with 384 x 256 x 32 tiles: 8 waves as 4 (M) x 2 (N), each a 96 x 128 block of the output (3 x 4
+// accumulators of 32 x 32 in AGPRs; one workgroup per CU, two waves per SIMD, 256 registers each).  H*Q = 384 query rows of the
+// video Q-former are one tile: a token row reaches the chip once for all of them.
+// What sets this kernel's speed is the operand stream from L2 (measured with the probes below: with every CU pulling, a CU
+// receives 37-49 GB/s; the 128-column form of this kernel needed 64 KB per 72 MFMAs per SIMD and waited for them), so the tile is
+// as large as LDS and the register file allow: 80 KB per 144 MFMAs per SIMD.
 //   * operand tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write
-//     instructions, and the loads of k-tile t + 1 fly while the MFMAs of tile t run (two LDS buffers of 64 KB, ONE barrier
-//     per k-tile).  A load instruction lays a wave's 64 x 16 bytes down contiguously, so a tile row is 64 bytes without
+//     instructions, and the loads of k-tile t + 1 fly while the MFMAs of tile t run (two stages of 80 KB: all of a CU's LDS; ONE
+//     barrier per k-tile).  A load instruction lays a wave's 64 x 16 bytes down contiguously, so a tile row is 64 bytes without
 //     padding; bank conflicts are avoided by a swizzle done on the GLOBAL side: the lane that fills 16-byte slot `s` of row
 //     `r` fetches k-segment s ^ ((r >> 2) & 3), and a fragment read of segment g looks in slot g ^ ((r >> 2) & 3) -- any 16
 //     consecutive rows then cover all 64 banks.
-//   * fragments of both 16-deep k-steps of a tile are requested before the first MFMA (112 registers): with one wave per
-//     SIMD nothing else hides the LDS latency.
-// Round 2's form (64-deep tiles staged through registers, two barriers per tile) sat at 38 % MFMA-busy, issue-stalled in
-// front of the matrix pipe behind its own ds_write / ds_read bursts.
+//   * the loads are issued one piece (1 KiB) at a time between groups of MFMAs: issued in one burst by a SIMD's only wave they
+//     cost 60-180 cycles each in which the matrix pipe idles (measured on the 128-column form: loop = compute-only loop + 1 400
+//     cycles per tile; interleaved: + 400); here the SIMD's other wave also has MFMAs to issue meanwhile.
+// Round 2's form (384 x 128 x 64 tiles staged through registers, two barriers per tile) sat at 38 % MFMA-busy; the 384 x 128 x 32
+// LDS-DMA form of this round (four waves) at 49 % (profiles/r04_*qformer*).
 // ------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kWI = 3, kWJ = 4;                   // 32 x 32 accumulators per wave: kWI along M, kWJ along N
-constexpr int kWRowsA = 4 * 32 * kWI;             // 384 rows of A per workgroup
-constexpr int kWRowsB = 32 * kWJ;                 // 128 rows of B
+constexpr int kWRowsA = 4 * 32 * kWI;             // 384 rows of A per workgroup (4 waves along M)
+constexpr int kWRowsB = 2 * 32 * kWJ;             // 256 rows of B (2 waves along N)
 constexpr int kDBK = 32;                          // k per tile (two 32x32x16 steps)
 constexpr int kDRow = 2 * kDBK;                   // 64 bytes per tile row
 constexpr int kDArrA = kWRowsA * kDRow, kDArrB = kWRowsB * kDRow;
-constexpr int kDStageA = 2 * kDArrA, kDStageB = 2 * kDArrB;     // hi + lo planes of one k-tile: 48 KB of A, 16 KB of B
-constexpr int kDepthA = 2, kDepthB = 4;           // stages: A comes from L2 (every workgroup reads the same rows), B from HBM
-constexpr int kDLds = kDepthA * kDStageA + kDepthB * kDStageB;  // 163 840 B: all of a CU's LDS
+constexpr int kDStageA = 2 * kDArrA, kDStageB = 2 * kDArrB;     // hi + lo planes of one k-tile: 48 KB of A, 32 KB of B
+constexpr int kDLds = 2 * (kDStageA + kDStageB);  // two stages: 163 840 B, all of a CU's LDS
+constexpr int kPiecesA = 6, kPiecesB = 4;         // 1-KiB load pieces per wave and k-tile
 }  // namespace
 
 // (PROBE: experiments build only, INFV_WIDE_MODE -- 1 = no operand loads, 2 = loads only: timing probes with wrong results)
 template <int PROBE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_kernel(SplitGemm g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void split_gemm_wide_kernel(SplitGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {   // XCD-aware tile order (see split_gemm_kernel)
         const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
@@ -184,13 +189,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ntiles = kend > kbeg ? (kend - kbeg) / kDBK : 0;
     float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
 
-    // (M % 384 == 0, N % 128 == 0, K % 32 == 0: checked by the launcher -- every load is a whole in-range 16 bytes)
+    // (M % 384 == 0, N % 256 == 0, K % 32 == 0: checked by the launcher -- every load is a whole in-range 16 bytes)
     const long a0 = (long)b * g.strideA + (long)m0 * g.lda + kbeg, b0 = (long)b * g.strideB + (long)n0 * g.ldb + kbeg;
     const int a_bytes = (int)((kWRowsA - 1) * g.lda + (kend - kbeg)) * 2, b_bytes = (int)((kWRowsB - 1) * g.ldb + (kend - kbeg)) * 2;
     // The LDS-DMA loads are written in assembly: through the builtin the compiler knows that they write LDS, cannot tell the
-    // stage being filled from the stage being read, and drains vmcnt(0) in front of the first fragment read of every k-tile --
-    // which would take the B tiles' two-tile head start away again.  (M0 = LDS byte address of the wave's 1-KiB piece; one wait
-    // state between the M0 write and the load.)
+    // stage being filled from the stage being read, and drains vmcnt(0) in front of the first fragment read behind every load.
+    // (M0 = LDS byte address of the wave's 1-KiB piece; one wait state between the M0 write and the load.)
     typedef int v4i __attribute__((ext_vector_type(4)));
     auto make_rsrc = [](const __bf16* p, int bytes) {
         const unsigned long a = reinterpret_cast<unsigned long>(p);
@@ -208,25 +212,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lrow = lane >> 2, lseg = (lane & 3) ^ ((lane >> 4) & 3);
     const int va = (lrow * (int)g.lda + lseg * 8) * 2, vb = (lrow * (int)g.ldb + lseg * 8) * 2;
     const int blk_a = 16 * (int)g.lda * 2, blk_b = 16 * (int)g.ldb * 2;        // bytes between 16-row blocks
-    unsigned char* const smem_b = smem + kDepthA * kDStageA;
-    auto issue_a = [&](int t) {                                                // this wave's 96 rows of A, both planes: 12 pieces
-        const unsigned base = lds0 + (t % kDepthA) * kDStageA;
+    // piece p of k-tile t: 48 of the 384 rows of A (3 blocks x 2 planes), then 32 of the 256 rows of B (2 blocks x 2 planes)
+    auto piece = [&](int t, int p) {                             // p is a constant after unrolling
         const int kt = t * kDRow;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int blk = wave * 6 + i;
-            dma16(rah, base + blk * 1024, va, blk * blk_a + kt);
-            dma16(ral, base + kDArrA + blk * 1024, va, blk * blk_a + kt);
-        }
-    };
-    auto issue_b = [&](int t) {                                                // 32 of the 128 rows of B, both planes: 4 pieces
-        const unsigned base = lds0 + kDepthA * kDStageA + (t % kDepthB) * kDStageB;
-        const int kt = t * kDRow;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int blk = wave * 2 + i;
-            dma16(rbh, base + blk * 1024, vb, blk * blk_b + kt);
-            dma16(rbl, base + kDArrB + blk * 1024, vb, blk * blk_b + kt);
+        if (p < kPiecesA) {
+            const int blk = wave * 3 + (p >> 1);
+            dma16((p & 1) ? ral : rah, lds0 + (t & 1) * kDStageA + (p & 1) * kDArrA + blk * 1024, va, blk * blk_a + kt);
+        } else {
+            const int blk = wave * 2 + ((p - kPiecesA) >> 1);
+            dma16((p & 1) ? rbl : rbh, lds0 + 2 * kDStageA + (t & 1) * kDStageB + (p & 1) * kDArrB + blk * 1024, vb, blk * blk_b + kt);
         }
     };
 
@@ -241,74 +235,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int li = lane & 31, kh = lane >> 5;
     const int swz = (li >> 2) & 3;
     const int fo0 = li * kDRow + ((kh ^ swz) << 4), fo1 = li * kDRow + (((2 + kh) ^ swz) << 4);     // k-steps 0 and 1
-    const int fa = wave * (32 * kWI) * kDRow;
-    // Issue order ... A(t), B(t + 2) | A(t + 1), B(t + 3) | ...: a wave's pieces land in issue order, so "all but the 4 youngest"
-    // (vmcnt(4)) at the top of iteration t means A(t) and every B up to t + 1 are in LDS while B(t + 2) may still be on its way
-    // from HBM: a B tile has two tile times to arrive, an A tile (L2) one.
+    const int fa = wm * (32 * kWI) * kDRow, fb = wn * (32 * kWJ) * kDRow;
     if (PROBE != 1 && ntiles > 0) {
-        issue_b(0);
-        if (ntiles > 1) issue_b(1);
-        issue_a(0);
-        if (ntiles > 2) issue_b(2);
+#pragma unroll
+        for (int p = 0; p < kPiecesA + kPiecesB; ++p) piece(0, p);
     }
 #ifdef INFV_EXPERIMENTS
     wg_stamp_begin(g.wg_stamps);
     const long long cyc0 = g.wg_stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #endif
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // this wave's part of A(t), B(t) has landed ...
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                         // ... everybody's has, and nobody still reads the stages about to be refilled
-        const unsigned char* base = smem + (t % kDepthA) * kDStageA;
-        const unsigned char* base_b = smem_b + (t % kDepthB) * kDStageB;
-        bf16x8 ah[2][kWI], al[2][kWI], bh[2][kWJ], bl[2][kWJ];
-        // fragment reads in the order their MFMAs come (lgkmcnt counts at most 15 reads: one k-step's 14 at a time)
-#define INFV_FRAGS(ks, fo)                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < kWI; ++i) al[ks][i] = *reinterpret_cast<const bf16x8*>(base + kDArrA + fa + i * 32 * kDRow + fo); \
-        _Pragma("unroll") for (int j = 0; j < kWJ; ++j) bh[ks][j] = *reinterpret_cast<const bf16x8*>(base_b + j * 32 * kDRow + fo);            \
-        _Pragma("unroll") for (int i = 0; i < kWI; ++i) ah[ks][i] = *reinterpret_cast<const bf16x8*>(base + fa + i * 32 * kDRow + fo);          \
-        _Pragma("unroll") for (int j = 0; j < kWJ; ++j) bl[ks][j] = *reinterpret_cast<const bf16x8*>(base_b + kDArrB + j * 32 * kDRow + fo);
-        // The three products as three sweeps over the accumulators, a sweep as three rows of four MFMAs; behind row p goes
-        // piece p of the next tiles' loads (A(t + 1): 12 pieces, then B(t + 3): 4).  Issued in one burst the 16 pieces cost this
-        // wave -- the SIMD's only one -- 16 x 60-180 cycles in which the matrix pipe idles (measured: loop = compute-only loop +
-        // 1 400 cycles); one at a time, most of a piece's issue hides behind the 32 cycles of the MFMA in front of it.
-        const bool ld_a = PROBE != 1 && t + 1 < ntiles, ld_b = PROBE != 1 && t + 3 < ntiles;
-        const unsigned next_a = lds0 + ((t + 1) % kDepthA) * kDStageA, next_b = lds0 + kDepthA * kDStageA + ((t + 3) % kDepthB) * kDStageB;
-        const int kt_a = (t + 1) * kDRow, kt_b = (t + 3) * kDRow;
-        auto piece = [&](int p) {                                // p is a constant after unrolling
-            if (p < 12) {
-                const int blk = wave * 6 + (p >> 1);
-                if (ld_a) dma16((p & 1) ? ral : rah, next_a + (p & 1) * kDArrA + blk * 1024, va, blk * blk_a + kt_a);
-            } else if (p < 16) {
-                const int blk = wave * 2 + ((p - 12) >> 1);
-                if (ld_b) dma16((p & 1) ? rbl : rbh, next_b + (p & 1) * kDArrB + blk * 1024, vb, blk * blk_b + kt_b);
-            }
-        };
-#define INFV_SWEEP(X, Y, p0)                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < kWI; ++i) {                                                                           \
-            _Pragma("unroll") for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0); \
-            if (PROBE != 2) __builtin_amdgcn_sched_barrier(0);                                                                      \
-            piece(p0 + i);                                                                                                          \
-            if (PROBE != 2) __builtin_amdgcn_sched_barrier(0);                                                                      \
-        }
-        INFV_FRAGS(0, fo0)
-        // (left alone the scheduler sinks every fragment read to just before its first use: a stall per read group)
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's part of tile t has landed ...
+        __syncthreads();                                         // ... everybody's has, and nobody still reads the other stage
+        const unsigned char* base = smem + (t & 1) * kDStageA + fa;
+        const unsigned char* base_b = smem + 2 * kDStageA + (t & 1) * kDStageB + fb;
+        const bool ld = PROBE != 1 && t + 1 < ntiles;
         if (PROBE == 2) {
+            if (ld) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) piece(p);
+                for (int p = 0; p < kPiecesA + kPiecesB; ++p) piece(t + 1, p);
+            }
             continue;
         }
-        INFV_SWEEP(al[0], bh[0], 0)
-        INFV_SWEEP(ah[0], bl[0], 3)
-        INFV_FRAGS(1, fo1)                                       // in flight behind the third sweep of k-step 0
-        __builtin_amdgcn_sched_barrier(0);
-        INFV_SWEEP(ah[0], bh[0], 6)
-        INFV_SWEEP(al[1], bh[1], 9)
-        INFV_SWEEP(ah[1], bl[1], 12)
-        INFV_SWEEP(ah[1], bh[1], 15)
-#undef INFV_FRAGS
-#undef INFV_SWEEP
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            bf16x8 al[kWI], ah[kWI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < kWI; ++i) {
+                al[i] = *reinterpret_cast<const bf16x8*>(base + kDArrA + i * 32 * kDRow + fo);
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + i * 32 * kDRow + fo);
+            }
+            bh[0] = *reinterpret_cast<const bf16x8*>(base_b + fo);
+            bl[0] = *reinterpret_cast<const bf16x8*>(base_b + kDArrB + fo);
+#pragma unroll
+            for (int j = 0; j < kWJ; ++j) {
+                if (j + 1 < kWJ) {                               // the next 32-column block's fragments, one block ahead
+                    bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(base_b + (j + 1) * 32 * kDRow + fo);
+                    bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(base_b + kDArrB + (j + 1) * 32 * kDRow + fo);
+                }
+                // the three products on three accumulators each; behind them one load piece of the next k-tile (8 slots, 10 pieces:
+                // the first two slots take two)
+                const int slot = ks * kWJ + j;
+#pragma unroll
+                for (int i = 0; i < kWI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                if (ld && slot < 2) piece(t + 1, 8 + slot);
+#pragma unroll
+                for (int i = 0; i < kWI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < kWI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                if (ld) piece(t + 1, slot);
+            }
+        }
     }
 #ifdef INFV_EXPERIMENTS
     if (g.wg_stamps != nullptr) {                // loop only: start, end (100 MHz) and the shader cycles between them above the CU id
@@ -321,151 +299,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     // (Issuing the products as (B fragment, A fragment) transposes the 32 x 32 blocks and gives every lane four consecutive
     //  columns -- 16-byte stores, a quarter of the instructions -- but a store instruction then writes 32 rows x 32 bytes instead
-    //  of 2 rows x 128 bytes: the scores launch went from 404 to 487 us.  Measured, not kept.)
+    //  of 2 rows x 128 bytes: the scores launch of the 128-column form went from 404 to 487 us.  Measured, not kept.)
+    // Non-temporal: the output is read by another kernel, the operands should stay in L2.
 #pragma unroll
     for (int i = 0; i < kWI; ++i)
 #pragma unroll
         for (int j = 0; j < kWJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 * kWI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int o = n0 + j * 32 + li;
+                const int m = m0 + wm * 32 * kWI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int o = n0 + wn * 32 * kWJ + j * 32 + li;
                 __builtin_nontemporal_store(acc[i][j][r], C + (long)m * g.ldc + o);
             }
 }
 
-#ifdef INFV_EXPERIMENTS
-// ------------------------------------------------------------------------------------------------------
-// (experiments build only: the round-2 form of the wide kernel, INFV_SPLIT_GEMM_WIDE=3, kept for A/B runs)
-// The same contraction with 384 x 128 x 64 tiles, operands staged through registers: 4 waves stacked along M, each a 96 x 128 block of the output
-// (3 x 4 accumulators of 32 x 32).  Why: the 128 x 128 kernel above moves as many LDS bytes per k-tile (64 KB written,
-// 128 KB read back as fragments) as its MFMAs take cycles at 128 B/clock -- it is LDS-bound near 30 % of the bf16 MFMA
-// peak.  A 3 x 4 register block reads 14 KB of fragments per 36 MFMAs instead of 8 KB per 12: LDS time is 61 % of the
-// MFMA time, and a B row reaches the chip once for all 384 rows of A (H*Q = 384 query rows in the video Q-former).
-// 144 KB of LDS: one workgroup per CU, accumulators in the AGPR half of the register file.
-// ------------------------------------------------------------------------------------------------------
-namespace {
-constexpr int kWArrA = kWRowsA * kSPitch, kWArrB = kWRowsB * kSPitch;
-constexpr int kWLds = 2 * kWArrA + 2 * kWArrB;    // A_hi, A_lo, B_hi, B_lo
-constexpr int kWVecA = kWRowsA * 8 / 256, kWVecB = kWRowsB * 8 / 256;   // 16-byte vectors per thread per array tile
-}  // namespace
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void split_gemm_wide_regs_kernel(SplitGemm g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {   // XCD-aware tile order (see split_gemm_kernel)
-        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
-        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = (int)(v % gridDim.x);
-        by = (int)((v / gridDim.x) % gridDim.y);
-        bz = (int)(v / (gridDim.x * gridDim.y));
-    }
-    const int m0 = bx * kWRowsA, n0 = by * kWRowsB;
-    const int b = bz / g.splitk, s = bz - b * g.splitk;
-    const int kbeg = s * g.k_per_split;
-    const int kend = (kbeg + g.k_per_split > g.K) ? g.K : kbeg + g.k_per_split;
-    const int ntiles = kend > kbeg ? (kend - kbeg) / kSBK : 0;
-    float* C = g.C + (long)b * g.strideC + (long)s * g.split_stride;
-
-    // staging: 8 lanes per row (one 128-B line of a row's k-tile per 8 lanes); vector e = tid + 256 * v -> (row e >> 3, seg e & 7)
-    const int seg = tid & 7, r8 = tid >> 3;                       // rows r8, r8 + 32, ...
-    const __bf16* a_hi = g.A_hi + (long)b * g.strideA + kbeg + seg * 8;
-    const __bf16* a_lo = g.A_lo + (long)b * g.strideA + kbeg + seg * 8;
-    const __bf16* b_hi = g.B_hi + (long)b * g.strideB + kbeg + seg * 8;
-    const __bf16* b_lo = g.B_lo + (long)b * g.strideB + kbeg + seg * 8;
-    // Named registers, not arrays: hipcc (ROCm 7.2) leaves a 512-B staging array in scratch memory even when every index is
-    // a constant after unrolling, which turns the prefetch into load -> wait -> scratch store -> scratch load -> ds_write.
-#define INFV_WA(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
-#define INFV_WB(X) X(0) X(1) X(2) X(3)
-    static_assert(kWVecA == 12 && kWVecB == 4, "staging macros are written for 384 x 128 x 64 tiles");
-#define INFV_DECL_A(v) uint4 rah##v, ral##v;
-#define INFV_DECL_B(v) uint4 rbh##v, rbl##v;
-    INFV_WA(INFV_DECL_A) INFV_WB(INFV_DECL_B)
-    // (M % 384 == 0 and N % 128 == 0, checked by the launcher: every load is unconditional and its address affine in v --
-    // a conditional load makes the compiler branch, and drain vmcnt, around every pair of loads)
-    const long oa = (long)(m0 + r8) * g.lda, ob = (long)(n0 + r8) * g.ldb;
-    const long sa = 32 * g.lda, sb = 32 * g.ldb;
-#define INFV_LD_A(v) rah##v = *reinterpret_cast<const uint4*>(a_hi + oa + v * sa + kt); ral##v = *reinterpret_cast<const uint4*>(a_lo + oa + v * sa + kt);
-#define INFV_LD_B(v) rbh##v = *reinterpret_cast<const uint4*>(b_hi + ob + v * sb + kt); rbl##v = *reinterpret_cast<const uint4*>(b_lo + ob + v * sb + kt);
-#define INFV_WIDE_LOAD(t) { const long kt = (long)(t) * kSBK; INFV_WA(INFV_LD_A) INFV_WB(INFV_LD_B) }
-    const int st0 = r8 * kSPitch + seg * 16;
-#define INFV_ST_A(v) *reinterpret_cast<uint4*>(smem + st0 + v * 32 * kSPitch) = rah##v; *reinterpret_cast<uint4*>(smem + kWArrA + st0 + v * 32 * kSPitch) = ral##v;
-#define INFV_ST_B(v) *reinterpret_cast<uint4*>(smem + 2 * kWArrA + st0 + v * 32 * kSPitch) = rbh##v; *reinterpret_cast<uint4*>(smem + 2 * kWArrA + kWArrB + st0 + v * 32 * kSPitch) = rbl##v;
-#define INFV_WIDE_STORE() { INFV_WA(INFV_ST_A) INFV_WB(INFV_ST_B) }
-
-    floatx16 acc[kWI][kWJ];
-#pragma unroll
-    for (int i = 0; i < kWI; ++i)
-#pragma unroll
-        for (int j = 0; j < kWJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int li = lane & 31, kh = lane >> 5;
-    if (ntiles > 0) INFV_WIDE_LOAD(0);
-    for (int t = 0; t < ntiles; ++t) {
-        INFV_WIDE_STORE();
-        __syncthreads();
-        INFV_WIDE_LOAD(t + 1 < ntiles ? t + 1 : t);   // (the last iteration re-reads its own tile: no branch around the loads)
-#pragma unroll
-        for (int ks = 0; ks < kSBK / 16; ++ks) {
-            bf16x8 ah[kWI], al[kWI], bh[kWJ], bl[kWJ];
-#pragma unroll
-            for (int i = 0; i < kWI; ++i) {
-                const int off = (wave * 32 * kWI + i * 32 + li) * kSPitch + ks * 32 + kh * 16;
-                ah[i] = *reinterpret_cast<const bf16x8*>(smem + off);
-                al[i] = *reinterpret_cast<const bf16x8*>(smem + kWArrA + off);
-            }
-#pragma unroll
-            for (int j = 0; j < kWJ; ++j) {
-                const int off = (j * 32 + li) * kSPitch + ks * 32 + kh * 16;
-                bh[j] = *reinterpret_cast<const bf16x8*>(smem + 2 * kWArrA + off);
-                bl[j] = *reinterpret_cast<const bf16x8*>(smem + 2 * kWArrA + kWArrB + off);
-            }
-            // the three products as three sweeps over the accumulators: consecutive MFMAs never share an accumulator
-#pragma unroll
-            for (int i = 0; i < kWI; ++i)
-#pragma unroll
-                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < kWI; ++i)
-#pragma unroll
-                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < kWI; ++i)
-#pragma unroll
-                for (int j = 0; j < kWJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < kWI; ++i)
-#pragma unroll
-        for (int j = 0; j < kWJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 * kWI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int o = n0 + j * 32 + li;
-                C[(long)m * g.ldc + o] = acc[i][j][r];
-            }
-#undef INFV_WIDE_LOAD
-#undef INFV_WIDE_STORE
-#undef INFV_WA
-#undef INFV_WB
-#undef INFV_DECL_A
-#undef INFV_DECL_B
-#undef INFV_LD_A
-#undef INFV_LD_B
-#undef INFV_ST_A
-#undef INFV_ST_B
-}
-
-#endif
-
-// the wide tiles need whole 384 x 128 tiles and enough of them to fill the chip
+// the wide tiles need whole 384 x 256 tiles and enough of them to fill the chip
 bool split_gemm_wide_applies(const SplitGemm& g) {
     static const int mode = [] { const char* e = exp_env("INFV_SPLIT_GEMM_WIDE"); return e ? atoi(e) : 1; }();
     if (!mode) return false;
@@ -473,6 +321,11 @@ bool split_gemm_wide_applies(const SplitGemm& g) {
     const long mt = g.M / kWRowsA;
     const long wgs = mt * ((g.N + kWRowsB - 1) / kWRowsB) * g.nbatch * g.splitk;
     return mode > 1 || wgs >= 192;
+}
+
+// tiles of the wide kernel for an [M x N] output per batch entry, 0 if the shape has no whole wide tiles
+long split_gemm_wide_tile_count(int M, int N) {
+    return (M <= 0 || N <= 0 || M % kWRowsA || N % kWRowsB) ? 0 : (long)(M / kWRowsA) * (N / kWRowsB);
 }
 
 // split-K count (and k per split, a multiple of 64) that fills the 256 CUs best with whichever tile shape will run
@@ -511,20 +364,6 @@ hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad
         // (buffer-addressed loads: a tile's rows must lie within 2^31 bytes of its first)
         if ((long)kWRowsA * g.lda * 2 + 2l * g.K >= (1l << 31) || (long)kWRowsB * g.ldb * 2 + 2l * g.K >= (1l << 31)) return hipErrorInvalidValue;
         dim3 grid((g.M + kWRowsA - 1) / kWRowsA, (g.N + kWRowsB - 1) / kWRowsB, g.nbatch * g.splitk);
-#ifdef INFV_EXPERIMENTS
-        static const bool regs_form = [] { const char* e = exp_env("INFV_SPLIT_GEMM_WIDE"); return e && atoi(e) == 3; }();
-        if (regs_form) {
-            static bool attr_r = false;
-            if (!attr_r) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_wide_regs_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr_r = true;
-            }
-            hipLaunchKernelGGL(split_gemm_wide_regs_kernel, grid, dim3(256), kWLds, stream, g);
-            return hipGetLastError();
-        }
-#endif
         SplitGemm gg = g;
         gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z);
         auto go = [&](auto kernel) {
@@ -534,7 +373,7 @@ hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad
                 if (e != hipSuccess) return e;
                 attr_w = true;
             }
-            hipLaunchKernelGGL(kernel, grid, dim3(256), kDLds, stream, gg);
+            hipLaunchKernelGGL(kernel, grid, dim3(512), kDLds, stream, gg);
             return hipGetLastError();
         };
 #ifdef INFV_EXPERIMENTS

@@ -1,6 +1,7 @@
 // C ABI of the video Q-former path (include/infv_vqf.h): workspace + launch sequence of one chunk.
 #include "../../include/infv_vqf.h"
 #include "capi_common.h"
+#include <algorithm>
 #include "vqf_internal.h"
 
 #include <cstdlib>
@@ -441,11 +442,22 @@ int infv_vqf_encode_video(infv_vqf_handle h, const infv_ltm_handle* ltm, const f
     // of the 256 CUs (16 chunks = 288 tiles ran at 56 % of 14 chunks' rate per tile)
     int NB = C;
     if (C > 8) {
+        auto fill = [](long wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); };
+        // with the 384 x 256 kernel (split path, whole tiles): workgroups of the scores contraction, and of the read-out with the
+        // split-K count that fills best -- both should come out as whole rounds (headline: 32 chunks = 1024 and 96 x 8)
+        const long ts = split_path(h, n_tokens) ? split_gemm_wide_tile_count(c.n_heads * Q, n_tokens) : 0;
+        const long tr = split_path(h, n_tokens) ? split_gemm_wide_tile_count(c.n_heads * Q, c.enc_width) : 0;
         const int tiles = ((c.n_heads * Q + 127) / 128) * ((c.enc_width + 127) / 128);
         double best = -1.0;
         for (int nb = 8; nb <= 32 && nb <= C; ++nb) {
-            const long t = (long)tiles * nb;
-            const double eff = (double)t / (double)(((t + 255) / 256) * 256);
+            double eff;
+            if (ts > 0 && tr > 0) {
+                double er = 0.0;
+                for (int sk = 1; sk <= 16; ++sk) er = std::max(er, fill(tr * nb * sk) - 0.004 * sk);
+                eff = 0.5 * (fill(ts * nb) + er);
+            } else {
+                eff = fill((long)tiles * nb);
+            }
             if (eff >= best - 1e-9) { best = eff; NB = nb; }
         }
     }

@@ -75,7 +75,8 @@ hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream);
 hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, void* p0, void* p1, void* p2, long row0, long rows_total,
                               hipStream_t stream);
 int shared_worker_stream(hipStream_t* out);   // ltm_capi.hip: the process-wide worker streams
-int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split);   // fills the chip with the tile shape that will run
+int split_gemm_pick_splitk(int M, int N, int K, int nbatch, int* k_per_split);
+long split_gemm_wide_tile_count(int M, int N);   // tiles of the 384 x 256 kernel per batch entry, 0 if the shape has no whole ones   // fills the chip with the tile shape that will run
 // x [rows][cols] fp32 -> hi = bf16(x), lo = bf16(x - hi)
 hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, void* hi, void* lo, long ld_out, hipStream_t stream);
 // F [nb][n][d] fp32 -> Fh/Fl [nb][n][d] and Th/Tl [nb][d][n] (bf16 hi/lo)

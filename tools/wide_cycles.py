@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Main-loop cycles of split_gemm_wide_kernel in situ (experiments build, INFV_WG_STAMPS=1): every workgroup stamps the 100 MHz
 clock and the shader clock around its k-loop.  Prints, per contraction (24 k-tiles: scores, 84-86: read-out), the shader cycles per
-32-deep k-tile (72 MFMAs per SIMD = 2304 cycles at the matrix pipe's rate) and the clock the chip held inside the loop.
+32-deep k-tile (144 MFMAs per SIMD = 4608 cycles at the matrix pipe's rate) and the clock the chip held inside the loop.
 usage (GPU box): INFV_LTM_LIBRARY=exp INFV_WG_STAMPS=1 python tools/wide_cycles.py [chunks]"""
 import ctypes as C
 import os
@@ -44,6 +44,6 @@ for name, lo, hi, tiles in (("scores   (K = 768, 24 k-tiles)", 0, 100 * 2304, 24
         continue
     c, d = cyc[sel], dt_us[sel]
     print(f"{name}: {sel.sum()} workgroups, loop {np.median(d):.1f} us (p10 {np.percentile(d, 10):.1f}, p90 {np.percentile(d, 90):.1f}), "
-          f"{np.median(c) / tiles:.0f} cycles per k-tile (2304 = matrix pipe busy all the time: {100 * 2304 * tiles / np.median(c):.0f} %), "
+          f"{np.median(c) / tiles:.0f} cycles per k-tile (4608 = matrix pipe busy all the time: {100 * 4608 * tiles / np.median(c):.0f} %), "
           f"clock in the loop {np.median(c / d) / 1e3:.2f} GHz")
 del m          # (before interpreter teardown)
