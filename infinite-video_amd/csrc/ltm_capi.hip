@@ -145,11 +145,11 @@ struct infv_ltm_s {
     DeviceBuf kbar_all;                // pooled frames of a whole consolidate_q call
     DeviceBuf wv_hi, wv_lo, R_hi, R_lo;  // split-bf16 operands of the V' half of the new-row projection (fast path)
     bool wv_split_valid = false;         // the value weights of this consolidate call have been split
-    // INFV_PROJ_X6=1 at create: the projection GEMM of the whole-video path on the bf16 MFMA pipe, fp32-accurate (three exact
-    // bf16 pieces per operand, six products, fp32 accumulation: split_gemm.hip) instead of gemm_nt_lw_kernel's fp32 MFMAs.
-    // Planes of [Wv ; q~] are made once per call, of a sub-batch's new rows per launch.
+    // The projection GEMM of the whole-video path runs on the bf16 MFMA pipe, fp32-accurate (three exact bf16 pieces per operand,
+    // six products, fp32 accumulation: split_gemm.hip, gemm_x6_wide_kernel); INFV_PROJ_X6=0 at create selects gemm_nt_lw_kernel's
+    // fp32 MFMAs instead (rounds 1-3's default).  Planes of [Wv ; q~] are made once per call, of a sub-batch's new rows per launch.
     DeviceBuf w3[3], r3[3];
-    bool proj_x6 = false, w3_valid = false;
+    bool proj_x6 = true, w3_valid = false;
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
     hipEvent_t ev_pool[kPSets] = {};

@@ -1028,7 +1028,53 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     const long slot = (a.slot0 + i) % a.ring;
     const long pslot = (a.slot0 + i + a.ring - 1) % a.ring;
     const int32_t* tb = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;
-    for (int e = tid; e < N * tabw / 4; e += kA2NT) reinterpret_cast<int4*>(tabb)[e] = reinterpret_cast<const int4*>(tb)[e];
+    // Every global load of the workgroup is issued before the first wait: the table, the static operator entries, and the first
+    // pass's previous point scores and S'new tile (beside the pooling stream a round trip to L2 takes microseconds, and a
+    // workgroup that makes four of them one after the other holds its CU slot four times as long: 18.5 us per workgroup in round 3).
+    const int n_tb = N * tabw / 4;
+    const bool regs_ok = n_tb <= 2 * kA2NT && rows * kA2Q <= 8 * kA2NT && a.prio != 9;       // (N <= 256 with tabw <= 8, rows <= 64: the register stage fits)
+    int4 r_tb[2]; floatx4 r_prev[4]; float r_sn[8];
+    auto load_pass = [&](int q0, int qn) {
+        const long row0 = (long)lh * Q + q0;
+        const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * kA2NT;
+            if (e < qn * (kBins / 4)) r_prev[j] = reinterpret_cast<const floatx4*>(cp)[e];
+        }
+        const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + j * kA2NT;
+            const int r = e / kA2Q, qq = e - r * kA2Q;
+            float v = 0.f;
+            if (e < rows * kA2Q && qq < qn) {
+                v = sb[(long)r * a.snew_ld + qq];
+                for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+            }
+            r_sn[j] = v;
+        }
+    };
+    auto store_pass = [&](int qn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * kA2NT;
+            if (e < qn * (kBins / 4)) {
+                const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
+                *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = r_prev[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + j * kA2NT;
+            if (e < rows * kA2Q) { const int r = e / kA2Q, qq = e - r * kA2Q; snew[r * snp + qq] = r_sn[j]; }
+        }
+    };
+    if (regs_ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) r_tb[j] = reinterpret_cast<const int4*>(tb)[e]; }
+        load_pass(0, min(kA2Q, Q));
+    }
     // static operator entries of this lane's boxes
     float val[4]; int brow[4]; float wn[4];
 #pragma unroll
@@ -1038,31 +1084,48 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
         brow[k] = (n < N) ? a.box_row[n] : -1;
         wn[k] = (n < N) ? a.w[n] : 0.f;
     }
+    if (regs_ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) reinterpret_cast<int4*>(tabb)[e] = r_tb[j]; }
+    } else {
+        for (int e = tid; e < n_tb; e += kA2NT) reinterpret_cast<int4*>(tabb)[e] = reinterpret_cast<const int4*>(tb)[e];
+    }
     const bool write_sp = a.Sp_out != nullptr && i == a.n_steps - 1;
     for (int q0 = 0; q0 < Q; q0 += kA2Q) {
         const int qn = min(kA2Q, Q - q0);
         const long row0 = (long)lh * Q + q0;                               // first row of the pass in [L][H][Q] order
+        float cq_r[kA2Q / (kA2NT / 64)];                                    // this wave's rows' bias terms, loaded together
+#pragma unroll
+        for (int j = 0; j < kA2Q / (kA2NT / 64); ++j) cq_r[j] = (wave + j * (kA2NT / 64) < qn) ? a.cq[row0 + wave + j * (kA2NT / 64)] : 0.f;
         __syncthreads();
         // previous point scores of the pass's rows (contiguous in the ring) and the S'new tile [rows][qn]
-        const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
-        for (int e = tid; e < qn * (kBins / 4); e += kA2NT) {
-            const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
-            *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = reinterpret_cast<const floatx4*>(cp)[e];
-        }
-        const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
-        for (int e = tid; e < rows * kA2Q; e += kA2NT) {
-            const int r = e / kA2Q, qq = e - r * kA2Q;
-            float v = 0.f;
-            if (qq < qn) {
-                v = sb[(long)r * a.snew_ld + qq];
-                for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+        if (regs_ok) {
+            if (q0 > 0) load_pass(q0, qn);
+            store_pass(qn);
+        } else {
+            const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
+            for (int e = tid; e < qn * (kBins / 4); e += kA2NT) {
+                const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
+                *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = reinterpret_cast<const floatx4*>(cp)[e];
             }
-            snew[r * snp + qq] = v;
+            const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
+            for (int e = tid; e < rows * kA2Q; e += kA2NT) {
+                const int r = e / kA2Q, qq = e - r * kA2Q;
+                float v = 0.f;
+                if (qq < qn) {
+                    v = sb[(long)r * a.snew_ld + qq];
+                    for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+                }
+                snew[r * snp + qq] = v;
+            }
         }
         __syncthreads();
-        for (int qq = wave; qq < qn; qq += kA2NT / 64) {
+#pragma unroll
+        for (int j = 0; j < kA2Q / (kA2NT / 64); ++j) {
+            const int qq = wave + j * (kA2NT / 64);
+            if (qq >= qn) break;
             const float* pr = prev + qq * kScPitch;
-            const float cqv = a.cq[row0 + qq];
+            const float cqv = cq_r[j];
             float sv[4];
             float mx = -INFINITY;
 #pragma unroll

@@ -360,6 +360,10 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef INFV_EXPERIMENTS
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<16, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<32, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -388,6 +392,10 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     long long* stamps = exp_stamps_reserve(WG_POOL, grid);
     static const int want_tid = [] { const char* e = exp_env("INFV_POOL_TID"); return e ? atoi(e) : kPoolTidAddr; }();
     const int tid_addr = (want_tid && d4 % 64 == 0) ? 1 : 0;               // every lane of every slice holds a column
+#ifdef INFV_EXPERIMENTS
+    if (u >= 32 && P % 32 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<32, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr); return hipGetLastError(); }
+    if (u >= 16 && P % 16 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<16, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr); return hipGetLastError(); }
+#endif
     if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
     else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
     return hipGetLastError();

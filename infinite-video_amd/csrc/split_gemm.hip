@@ -204,8 +204,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const v4i rah = make_rsrc(g.A_hi + a0, a_bytes), ral = make_rsrc(g.A_lo + a0, a_bytes);
     const v4i rbh = make_rsrc(g.B_hi + b0, b_bytes), rbl = make_rsrc(g.B_lo + b0, b_bytes);
     auto dma16 = [](const v4i& rsrc, unsigned lds_addr, int voff, int soff) {
+        // (readfirstlane: the "s" constraint alone does not move a value the compiler holds in a vector register)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+                     :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
     };
     const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr)smem;
     // one load instruction = 16 tile rows: lane -> (row lane >> 2, slot lane & 3), fetching k-segment slot ^ swizzle(row)
@@ -539,8 +540,150 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(SplitGemm6 g) {
     wg_stamp_end(g.wg_stamps);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same six-product contraction with 384 x 256 x 16 tiles, built like split_gemm_wide_kernel: 8 waves as 4 (M) x 2 (N), each a
+// 96 x 128 block of the output (12 accumulators), two waves per SIMD, operand planes streamed global -> LDS by `buffer_load ... lds`
+// one 1-KiB piece at a time between the MFMAs (a piece = 32 consecutive rows of one k-tile of one plane: 1 KiB of consecutive
+// memory in the k-tile-major planes), two stages of 60 KB, one barrier per k-tile.  120 KB of LDS: the workgroup has its CU to
+// itself -- in the consolidation pipeline no pooling workgroup sits beside it, whose streaming loads made every vector-memory
+// instruction of the 128 x 128 kernel above cost 0.2 us at issue (and whose own loads completed three times slower there), and the
+// tile needs 60 KB of operands per 144 MFMAs per SIMD where the 128 x 128 tile needs 48 KB per 48.
+// Same products in the same order per accumulator as gemm_x6_kernel: the same bits.
+// A tile row is 32 bytes (16 bf16); bank conflicts of the fragment reads are avoided by a swizzle done on the global side: the lane
+// that fills 16-byte slot s of row r fetches k-half s ^ ((r >> 3) & 1).
+// ------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kYRowsA = 384, kYRowsB = 256;
+constexpr int kYPlaneA = kYRowsA * 32, kYPlaneB = kYRowsB * 32;          // bytes of one plane's k-tile
+constexpr int kYStage = 3 * kYPlaneA + 3 * kYPlaneB;                      // 61 440 B
+constexpr int kYLds = 2 * kYStage;
+constexpr int kYPiecesA = 3 * (kYRowsA / 32), kYPieces = kYPiecesA + 3 * (kYRowsB / 32);   // 36 + 24 pieces of 1 KiB per k-tile
+}  // namespace
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6_wide_kernel(SplitGemm6 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    wg_stamp_begin(g.wg_stamps);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware tile order (see split_gemm_kernel): the tiles that share B rows run on one XCD at the same time
+        const unsigned nwg = gridDim.x * gridDim.y;
+        const unsigned orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)(v / gridDim.x);
+    }
+    const int m0 = bx * kYRowsA, n0 = by * kYRowsB;
+    const int ntiles = g.K / 16;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const __bf16* p, int bytes) {
+        const unsigned long a = reinterpret_cast<unsigned long>(p);
+        v4i r = {(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), bytes, 0x00020000};
+        return r;
+    };
+    const int a_bytes = ntiles * g.M * 32, b_bytes = ntiles * g.N * 32;         // (below 2^31: checked by the launcher)
+    const v4i ra0 = make_rsrc(g.A[0], a_bytes), ra1 = make_rsrc(g.A[1], a_bytes), ra2 = make_rsrc(g.A[2], a_bytes);
+    const v4i rb0 = make_rsrc(g.B[0], b_bytes), rb1 = make_rsrc(g.B[1], b_bytes), rb2 = make_rsrc(g.B[2], b_bytes);
+    auto dma16 = [](const v4i& rsrc, unsigned lds_addr, int voff, int soff) {   // (assembly: see split_gemm_wide_kernel)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+    };
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr)smem;
+    // one load instruction = 32 tile rows: lane -> (row lane >> 1, slot lane & 1), fetching k-half slot ^ ((row >> 3) & 1)
+    const int lv = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    // Load pieces of k-tile t, by slot (a compile-time constant): slots 0..2 = planes 0..2 of B's 32-row block `wave`; 3..5 = of A's
+    // block `wave`; 6..8 = of A's block 8 + wave (waves 0..3: 12 blocks of A on 8 waves; the two waves of a SIMD, w and w + 4, issue 15
+    // pieces between them).  M is a multiple of 32 (launcher): a block of A rows is wholly inside the operand or wholly outside
+    // (then skipped: its outputs are never stored).
+    auto piece = [&](int t, int slot) {
+        const unsigned stage = lds0 + (t & 1) * kYStage;
+        if (slot < 3) {
+            dma16(slot == 0 ? rb0 : slot == 1 ? rb1 : rb2, stage + 3 * kYPlaneA + slot * kYPlaneB + wave * 1024, lv, (t * g.N + n0 + wave * 32) * 32);
+        } else {
+            const int pl = slot < 6 ? slot - 3 : slot - 6, blk = slot < 6 ? wave : 8 + wave;
+            if (blk < 12 && m0 + blk * 32 < g.M)
+                dma16(pl == 0 ? ra0 : pl == 1 ? ra1 : ra2, stage + pl * kYPlaneA + blk * 1024, lv, (t * g.M + m0 + blk * 32) * 32);
+        }
+    };
+
+    floatx16 acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int li = lane & 31, kh = lane >> 5;
+    const int fo = li * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+    const int fa = wm * 96 * 32 + fo, fb = 3 * kYPlaneA + wn * 128 * 32 + fo;
+    if (ntiles > 0) {
+#pragma unroll
+        for (int sl = 0; sl < 9; ++sl) piece(0, sl);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile t have landed ...
+        __syncthreads();                                         // ... everybody's have, and nobody still reads the other stage
+        const unsigned char* base = smem + (t & 1) * kYStage;
+        const bool ld = t + 1 < ntiles;
+        // row block i of A against column blocks 2 jp, 2 jp + 1 of B: the six products, smallest partial product first (the order of
+        // gemm_x6_kernel), on two accumulators alternately; between the MFMAs the load pieces of the next tile
+        // (6 groups of twelve MFMAs, 9 pieces: one or two per group).  The B fragments are read again for every i (45 fragment reads per k-tile instead of 21): holding
+        // all of A's (36 registers) beside the 192 accumulators does not fit two waves per SIMD.
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bf16x8 a[3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(base + pl * kYPlaneA + fa + i * 32 * 32);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) b[jj][pl] = *reinterpret_cast<const bf16x8*>(base + pl * kYPlaneB + fb + (2 * jp + jj) * 32 * 32);
+#define INFV_Y_SWEEP(pa, pb) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) acc[i][2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[jj][pb], acc[i][2 * jp + jj], 0, 0, 0);
+                INFV_Y_SWEEP(2, 0) INFV_Y_SWEEP(0, 2) INFV_Y_SWEEP(1, 1)
+                if (ld) piece(t + 1, (2 * i + jp) * 3 / 2);
+                INFV_Y_SWEEP(1, 0) INFV_Y_SWEEP(0, 1) INFV_Y_SWEEP(0, 0)
+                if (ld && ((2 * i + jp) & 1)) piece(t + 1, (2 * i + jp) * 3 / 2 + 1);
+#undef INFV_Y_SWEEP
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int o = n0 + wn * 128 + j * 32 + li;
+                if (m < g.M) __builtin_nontemporal_store(acc[i][j][r], &g.C[(long)m * g.ldc + o]);
+            }
+    wg_stamp_end(g.wg_stamps);
+}
+
+bool gemm_x6_wide_applies(const SplitGemm6& g) {
+    return g.M > 0 && g.M % 32 == 0 && g.N % kYRowsB == 0 && g.K % 16 == 0 && (long)(g.K / 16) * g.M * 32 < (1l << 31) &&
+           (long)(g.K / 16) * g.N * 32 < (1l << 31) && g.M >= 1024;
+}
+
 hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (!g.narrow && gemm_x6_wide_applies(g)) {
+        static bool attr_y = false;
+        if (!attr_y) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_y = true;
+        }
+        dim3 grid((g.M + kYRowsA - 1) / kYRowsA, g.N / kYRowsB);
+        SplitGemm6 gg = g;
+        gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y);
+        hipLaunchKernelGGL(gemm_x6_wide_kernel, grid, dim3(512), kYLds, stream, gg);
+        return hipGetLastError();
+    }
     if (g.K % kXBK) return hipErrorInvalidValue;
     static bool attr = false;
     if (!attr) {
@@ -591,7 +734,8 @@ hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, v
 #ifdef INFV_EXPERIMENTS
 }  // namespace infv
 // test hook (experiments build only, tests/test_ltm_gpu.py): C [M][N] = A [M][K] . B [N][K]^T through the bf16x6 path (which = 0) or
-// through the fp32-MFMA kernel the whole-video path used before (which = 1); device pointers, synchronous
+// through the fp32-MFMA kernel the whole-video path used before (which = 1); which = 2: the bf16x6 path's 128 x 128 kernel even where
+// the 384 x 256 one applies; device pointers, synchronous
 extern "C" int infv_exp_gemm(int which, const float* A, const float* B, float* C, int M, int N, int K) {
     using namespace infv;
     if (which == 1) {
@@ -606,7 +750,7 @@ extern "C" int infv_exp_gemm(int which, const float* A, const float* B, float* C
     if (launch_split3_rows(B, K, N, K, pl[3], pl[4], pl[5], 0, N, nullptr) != hipSuccess) rc = -1;
     SplitGemm6 g{};
     for (int i = 0; i < 3; ++i) { g.A[i] = pl[i]; g.B[i] = pl[3 + i]; }
-    g.lda = K; g.ldb = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.narrow = which == 2;
     if (rc == 0 && launch_gemm_x6(g, nullptr) != hipSuccess) rc = -1;
     if (hipDeviceSynchronize() != hipSuccess) rc = -1;
     for (int i = 0; i < 6; ++i) (void)hipFree(pl[i]);

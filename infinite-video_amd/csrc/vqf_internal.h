@@ -68,6 +68,7 @@ struct SplitGemm6 {
     float* C; long ldc;
     int M, N, K;
     long long* wg_stamps;            // residency experiment (wg_stamps.h), or nullptr
+    int narrow;                      // 1: the 128 x 128 kernel even where the 384 x 256 one applies (tests: the two agree bit for bit)
 };
 hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream);
 // x [rows][cols] fp32 = rows row0.. of an operand with rows_total rows -> p0 + p1 + p2 = x, bf16 planes in k-tile-major order

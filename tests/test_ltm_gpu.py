@@ -92,7 +92,8 @@ fn.restype = C.c_int
 fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
 dev = torch.device("cuda:0")
 out = {}
-for name, M, N, K, scale in [("unit", 2688, 2304, 768, 1.0), ("ragged", 1100, 640, 768, 1.0), ("wide_range", 1344, 1152, 768, None)]:
+for name, M, N, K, scale in [("unit", 2688, 2304, 768, 1.0), ("ragged", 1100, 640, 768, 1.0), ("wide_range", 1344, 1152, 768, None),
+                             ("shard_rows", 2048, 2304, 768, 1.0), ("wide_range_big_tiles", 1344, 1280, 768, None)]:
     g = torch.Generator(device=dev).manual_seed(M)
     A = torch.randn(M, K, device=dev, generator=g)
     B = torch.randn(N, K, device=dev, generator=g)
@@ -102,10 +103,13 @@ for name, M, N, K, scale in [("unit", 2688, 2304, 768, 1.0), ("ragged", 1100, 64
     ref = A.double() @ B.double().T
     mag = (A.double().abs() @ B.double().abs().T)           # sum_k |a_k b_k|: what rounding errors scale with
     errs = {}
-    for which, tag in [(0, "x6"), (1, "f32")]:
+    keep = {}
+    for which, tag in [(0, "x6"), (1, "f32"), (2, "x6_small_tiles")]:
         Cc = torch.zeros(M, N, device=dev)
         assert fn(which, A.data_ptr(), B.data_ptr(), Cc.data_ptr(), M, N, K) == 0
         errs[tag] = float(((Cc.double() - ref).abs() / mag).max())
+        keep[tag] = Cc
+    errs["same_bits"] = bool(torch.equal(keep["x6"], keep["x6_small_tiles"]))
     out[name] = errs
 json.dump(out, open(sys.argv[1], "w"))
 '''
@@ -114,7 +118,9 @@ json.dump(out, open(sys.argv[1], "w"))
 def test_bf16x6_projection_gemm_is_as_accurate_as_the_fp32_mfma_gemm(dev, tmp_path):
     """The whole-video path's projection GEMM runs as six bf16 MFMA products of exact three-piece splits with fp32 accumulation
     (split_gemm.hip).  Against fp64, relative to sum |a_k b_k|: its worst element error must not exceed the fp32-MFMA kernel's
-    (the round-2 GEMM, same operands) by more than a rounding unit, on unit-scale, ragged and wide-dynamic-range operands."""
+    (the round-2 GEMM, same operands) by more than a rounding unit, on unit-scale, ragged and wide-dynamic-range operands.  Shapes
+    with whole 256-column tiles and >= 1024 rows run the 384 x 256 kernel (gemm_x6_wide_kernel), the others the 128 x 128 one: same
+    products in the same order, the same bits."""
     import json
     import subprocess
     path = str(tmp_path / "x6.json")
@@ -124,6 +130,7 @@ def test_bf16x6_projection_gemm_is_as_accurate_as_the_fp32_mfma_gemm(dev, tmp_pa
     for name, e in res.items():
         assert e["f32"] < 2e-6, (name, e)                             # sanity of the yardstick: K = 768 fp32 roundings
         assert e["x6"] <= e["f32"] + 6e-8, (name, e)
+        assert e["same_bits"], (name, e)                                # 384 x 256 tiles (where they apply) == 128 x 128 tiles
 
 
 def test_pool_rows_bf16_tokens_and_dense_plan_refusal(dev):

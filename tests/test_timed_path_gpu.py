@@ -128,14 +128,15 @@ def _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast=Non
     return worst, flips
 
 
-@pytest.mark.parametrize("n_chunks,x6", [(64, False), (256, False), (2048, False), (256, True), (2048, True)])
+@pytest.mark.parametrize("n_chunks,x6", [(64, True), (256, True), (2048, True), (256, False), (2048, False)])
 def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
-    """64 chunks: two 28-chunk sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
-    shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call.  x6: the same with INFV_PROJ_X6=1, the projection GEMM
-    as six bf16 MFMA products of exact three-piece splits -- same goldens, same oracle, same budgets as the fp32-MFMA GEMM."""
+    """64 chunks: two sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
+    shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call.  x6 (the default): the projection GEMM as six bf16 MFMA
+    products of exact three-piece splits; not x6 (INFV_PROJ_X6=0): the fp32-MFMA GEMM of rounds 1-3 -- same goldens, same oracle,
+    same budgets."""
     k, q, projs, u, ws, qs = _video(dev, n_chunks)
-    if x6:
-        monkeypatch.setenv("INFV_PROJ_X6", "1")
+    if not x6:
+        monkeypatch.setenv("INFV_PROJ_X6", "0")
     fast = _engine(dev, max_batch_chunks=42)
     monkeypatch.delenv("INFV_PROJ_X6", raising=False)
     bins_all, probs_all = fast.set_trace(n_chunks)
@@ -284,28 +285,30 @@ _VARIANTS = [
     {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
     {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
     {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
-    {"INFV_VPROJ_ON_UC": "1"},                                 # V' half of the projection as its own GEMM on the UC stream
+    {"INFV_PROJ_X6": "0", "INFV_VPROJ_ON_UC": "1"},            # (fp32-MFMA GEMM) V' half of the projection as its own GEMM on the UC stream
     {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
-    {"INFV_GEMM_LW": "0"},                                     # projection GEMM without loader waves
+    {"INFV_PROJ_X6": "0", "INFV_GEMM_LW": "0"},                # (fp32-MFMA GEMM) without loader waves
     {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
     {"INFV_POOL_TID": "1"},                                    # pooling kernel with lane-id addressed loads (no vector address operand)
-    {"INFV_GEMM_SLICES": "2"},                                 # projection GEMM launched as two column slices
+    {"INFV_PROJ_X6": "0", "INFV_GEMM_SLICES": "2"},            # (fp32-MFMA GEMM) launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
 ]
 
 
 def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
     """A 70-chunk call (two 32-chunk sub-batches + a short one: split-K slabs) and a 5-chunk continuation, once with the
-    shipped library and once per variant with the experiments build: contexts, memory and draws identical bit for bit."""
+    shipped library and once per variant with the experiments build: contexts, memory and draws identical bit for bit (variants of
+    the fp32-MFMA projection GEMM against the shipped library with INFV_PROJ_X6=0)."""
     def run(env_add, name):
         path = str(tmp_path / name)
         _run_child(_VARIANT_CHILD, env_add, path)
         return {k_: v for k_, v in np.load(path).items()}
-    base = run({}, "base.npz")
+    base = {"": run({}, "base.npz"), "0": run({"INFV_PROJ_X6": "0"}, "base_f32mfma.npz")}   # shipped library: default, and the fp32-MFMA GEMM
     for i, v in enumerate(_VARIANTS):
         got = run(dict(v, INFV_LTM_LIBRARY="exp"), f"v{i}.npz")
-        for key in base:
-            np.testing.assert_array_equal(base[key], got[key], err_msg=f"{v}: {key}")
+        want = base[v.get("INFV_PROJ_X6", "")]
+        for key in want:
+            np.testing.assert_array_equal(want[key], got[key], err_msg=f"{v}: {key}")
 
 
 def test_xcd_local_mailbox_exchange_variant(dev, tmp_path):
