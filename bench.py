@@ -135,10 +135,17 @@ def pmc_mfma_busy():
         return None
     d = json.load(open(files[-1]))
     out = {"source": os.path.basename(files[-1])}
-    for key, frag in (("projection_gemm", "gemm_nt_lw_kernel"), ("uc_readout", "uc_fast_kernel")):
-        hit = [v for k_, v in d.items() if frag in k_ and "mfma_util_pct" in v]
-        if hit:
-            out[key] = round(float(hit[0]["mfma_util_pct"]), 1)
+    for key, frags in (("projection_gemm", ("gemm_x6_wide_kernel", "gemm_nt_lw_kernel")), ("uc_readout", ("uc_fast_kernel",))):
+        for frag in frags:                                   # (the default GEMM first; the fp32-MFMA one in profiles of rounds 1-3)
+            hit = [v for k_, v in d.items() if frag in k_ and "mfma_util_pct" in v]
+            if hit:
+                out[key] = round(float(hit[0]["mfma_util_pct"]), 1)
+                out[key + "_kernel"] = frag
+                if frag == "gemm_x6_wide_kernel":
+                    # the counter quotient is per chip (1024 SIMDs); this GEMM runs 63 workgroups (7 x 9 tiles of 384 x 256 per
+                    # 42-chunk sub-batch), one per CU, beside the other kernels of the pipeline: busy share of the CUs it occupies
+                    out[key + "_on_its_63_cus"] = round(float(hit[0]["mfma_util_pct"]) * 256.0 / 63.0, 1)
+                break
     return out
 
 
