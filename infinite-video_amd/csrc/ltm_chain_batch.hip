@@ -1010,11 +1010,14 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 constexpr int kA2NT = 256;
 constexpr int kA2Q = 32;                  // query rows staged per pass
 
+// (TW4 = int4 entries per box of the gather table as a compile-time constant, 0 = read it from the arguments: with a run-time trip
+//  count hipcc unrolls the gather loop four ways with remainder loops for every one of the 32 (row, box) positions -- 12 000
+//  instructions, 16 us of arithmetic per unit; with the constant, 1.)
+template <int TW4>
 __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
-    const int i = blockIdx.x, lh = blockIdx.y, l = lh / H;
     const int snp = kA2Q + 1;
     wg_stamp_begin(a.wg_stamps);
 #ifdef INFV_EXPERIMENTS
@@ -1022,120 +1025,154 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
 #endif
-    int32_t* tabb = reinterpret_cast<int32_t*>(lds);                       // [N * tabw]
+    int4* tabb = reinterpret_cast<int4*>(lds);                             // [tabw / 4][4][N / 4]: box n's j-th int4 at (4 j + (n & 3)) * (N / 4) + (n >> 2)
+    const int nq = N / 4;                                                  // lanes in use
     float* prev = lds + ((N * tabw + 3) & ~3);                             // [kA2Q][kScPitch]
     float* snew = prev + kA2Q * kScPitch;                                  // [rows][kA2Q + 1]
-    const long slot = (a.slot0 + i) % a.ring;
-    const long pslot = (a.slot0 + i + a.ring - 1) % a.ring;
-    const int32_t* tb = a.tabb_ring + slot * a.tab_slot + (long)l * N * tabw;
-    // Every global load of the workgroup is issued before the first wait: the table, the static operator entries, and the first
-    // pass's previous point scores and S'new tile (beside the pooling stream a round trip to L2 takes microseconds, and a
-    // workgroup that makes four of them one after the other holds its CU slot four times as long: 18.5 us per workgroup in round 3).
-    const int n_tb = N * tabw / 4;
-    const bool regs_ok = n_tb <= 2 * kA2NT && rows * kA2Q <= 8 * kA2NT && a.prio != 9;       // (N <= 256 with tabw <= 8, rows <= 64: the register stage fits)
-    int4 r_tb[2]; floatx4 r_prev[4]; float r_sn[8];
-    auto load_pass = [&](int q0, int qn) {
-        const long row0 = (long)lh * Q + q0;
-        const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
+    // Work unit = (step i, layer-head lh, pass of kA2Q query rows); a workgroup walks units blockIdx.x, + gridDim.x, ... and holds
+    // the NEXT unit's inputs in registers while it computes the present one.  Lane = boxes 4 lane .. 4 lane + 3, so that a row's
+    // weights leave as ONE 16-byte store per lane, the S'new tile arrives as 16-byte loads and the bias terms as one load per wave:
+    // beside a streaming pooling workgroup every vector-memory instruction costs its wave ~0.2 us at issue (round 3, GEMM stamps),
+    // and this kernel issued 55 of them per wave and unit (18.5 us per unit for ~3 us of arithmetic); now 18.
+    const int n_pass = (Q + kA2Q - 1) / kA2Q, LH = a.L * H;
+    const long n_units = (long)a.n_steps * LH * n_pass;
+    const int tw4 = TW4 > 0 ? TW4 : tabw / 4, n_tb = N * tw4;                  // int4s per box / per table
+    constexpr int kRpw = kA2Q / (kA2NT / 64);                                  // query rows per wave and pass
+    int4 r_tb[2]; floatx4 r_prev[4]; floatx4 r_sn[2]; float r_cq;
+    struct Unit { int i, lh, l, q0, qn; long slot, pslot, row0; };
+    auto unit_of = [&](long u) {
+        Unit t;
+        const int pass = (int)(u % n_pass); const long il = u / n_pass;
+        t.lh = (int)(il % LH); t.i = (int)(il / LH); t.l = t.lh / H;
+        t.q0 = pass * kA2Q; t.qn = min(kA2Q, Q - t.q0);
+        t.slot = (a.slot0 + t.i) % a.ring; t.pslot = (a.slot0 + t.i + a.ring - 1) % a.ring;
+        t.row0 = (long)t.lh * Q + t.q0;                                      // first row of the pass in [L][H][Q] order
+        return t;
+    };
+    // (launcher: N % 4 == 0, n_tb <= 512, rows * kA2Q / 4 <= 512, Q % 4 == 0 and 16-byte aligned S'new rows)
+    auto load_unit = [&](const Unit& t) {                                   // global -> registers: 9 load instructions per wave
+        const int32_t* tb = a.tabb_ring + t.slot * a.tab_slot + (long)t.l * N * tabw;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) r_tb[j] = reinterpret_cast<const int4*>(tb)[e]; }
+        const float* cp = a.crit_ring + t.pslot * a.crit_slot + t.row0 * kBins;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = tid + j * kA2NT;
-            if (e < qn * (kBins / 4)) r_prev[j] = reinterpret_cast<const floatx4*>(cp)[e];
+            if (e < t.qn * (kBins / 4)) r_prev[j] = reinterpret_cast<const floatx4*>(cp)[e];
         }
-        const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
+        const float* sb = a.Snew + (long)t.i * rows * a.snew_ld + t.row0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = tid + j * kA2NT;
-            const int r = e / kA2Q, qq = e - r * kA2Q;
-            float v = 0.f;
-            if (e < rows * kA2Q && qq < qn) {
-                v = sb[(long)r * a.snew_ld + qq];
-                for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + j * kA2NT;                                   // (row e / 8, query rows 4 (e % 8) ..)
+            const int r = e / (kA2Q / 4), c4 = e - r * (kA2Q / 4);
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < rows && 4 * c4 < t.qn) {
+                v = *reinterpret_cast<const floatx4*>(sb + (long)r * a.snew_ld + 4 * c4);
+                for (int x = 1; x < a.snew_splitk; ++x) v += *reinterpret_cast<const floatx4*>(sb + (long)r * a.snew_ld + 4 * c4 + x * a.snew_split_stride);
             }
             r_sn[j] = v;
         }
+        r_cq = (lane < t.qn) ? a.cq[t.row0 + lane] : 0.f;                   // bias term of pass row `lane`
     };
-    auto store_pass = [&](int qn) {
+    auto store_unit = [&](const Unit& t) {                                  // registers -> LDS
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + j * kA2NT;
+            if (e < n_tb) { const int n = e / tw4, jj = e - n * tw4; tabb[(4 * jj + (n & 3)) * nq + (n >> 2)] = r_tb[j]; }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = tid + j * kA2NT;
-            if (e < qn * (kBins / 4)) {
+            if (e < t.qn * (kBins / 4)) {
                 const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
                 *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = r_prev[j];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int e = tid + j * kA2NT;
-            if (e < rows * kA2Q) { const int r = e / kA2Q, qq = e - r * kA2Q; snew[r * snp + qq] = r_sn[j]; }
+            const int r = e / (kA2Q / 4), c4 = e - r * (kA2Q / 4);
+            if (r < rows) {
+                snew[r * snp + 4 * c4] = r_sn[j].x; snew[r * snp + 4 * c4 + 1] = r_sn[j].y;
+                snew[r * snp + 4 * c4 + 2] = r_sn[j].z; snew[r * snp + 4 * c4 + 3] = r_sn[j].w;
+            }
         }
     };
-    if (regs_ok) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) r_tb[j] = reinterpret_cast<const int4*>(tb)[e]; }
-        load_pass(0, min(kA2Q, Q));
-    }
-    // static operator entries of this lane's boxes
-    float val[4]; int brow[4]; float wn[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int n = lane + 64 * k;
-        val[k] = (n < N) ? a.box_val[n] : 0.f;
-        brow[k] = (n < N) ? a.box_row[n] : -1;
-        wn[k] = (n < N) ? a.w[n] : 0.f;
-    }
-    if (regs_ok) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) reinterpret_cast<int4*>(tabb)[e] = r_tb[j]; }
-    } else {
-        for (int e = tid; e < n_tb; e += kA2NT) reinterpret_cast<int4*>(tabb)[e] = reinterpret_cast<const int4*>(tb)[e];
-    }
-    const bool write_sp = a.Sp_out != nullptr && i == a.n_steps - 1;
-    for (int q0 = 0; q0 < Q; q0 += kA2Q) {
-        const int qn = min(kA2Q, Q - q0);
-        const long row0 = (long)lh * Q + q0;                               // first row of the pass in [L][H][Q] order
-        float cq_r[kA2Q / (kA2NT / 64)];                                    // this wave's rows' bias terms, loaded together
-#pragma unroll
-        for (int j = 0; j < kA2Q / (kA2NT / 64); ++j) cq_r[j] = (wave + j * (kA2NT / 64) < qn) ? a.cq[row0 + wave + j * (kA2NT / 64)] : 0.f;
-        __syncthreads();
-        // previous point scores of the pass's rows (contiguous in the ring) and the S'new tile [rows][qn]
-        if (regs_ok) {
-            if (q0 > 0) load_pass(q0, qn);
-            store_pass(qn);
-        } else {
-            const float* cp = a.crit_ring + pslot * a.crit_slot + row0 * kBins;
-            for (int e = tid; e < qn * (kBins / 4); e += kA2NT) {
-                const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
-                *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = reinterpret_cast<const floatx4*>(cp)[e];
-            }
-            const float* sb = a.Snew + (long)i * rows * a.snew_ld + row0;
-            for (int e = tid; e < rows * kA2Q; e += kA2NT) {
-                const int r = e / kA2Q, qq = e - r * kA2Q;
-                float v = 0.f;
-                if (qq < qn) {
-                    v = sb[(long)r * a.snew_ld + qq];
-                    for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
-                }
-                snew[r * snp + qq] = v;
-            }
+    auto stage_unit_direct = [&](const Unit& t) {                           // shapes beyond the register stage: global -> LDS in loops
+        const int32_t* tb = a.tabb_ring + t.slot * a.tab_slot + (long)t.l * N * tabw;
+        for (int e = tid; e < n_tb; e += kA2NT) { const int n = e / tw4, jj = e - n * tw4; tabb[(4 * jj + (n & 3)) * nq + (n >> 2)] = reinterpret_cast<const int4*>(tb)[e]; }
+        const float* cp = a.crit_ring + t.pslot * a.crit_slot + t.row0 * kBins;
+        for (int e = tid; e < t.qn * (kBins / 4); e += kA2NT) {
+            const int r = e / (kBins / 4), c4 = e - r * (kBins / 4);
+            *reinterpret_cast<floatx4*>(&prev[r * kScPitch + 4 * c4]) = reinterpret_cast<const floatx4*>(cp)[e];
         }
+        const float* sb = a.Snew + (long)t.i * rows * a.snew_ld + t.row0;
+        for (int e = tid; e < rows * kA2Q; e += kA2NT) {
+            const int r = e / kA2Q, qq = e - r * kA2Q;
+            float v = 0.f;
+            if (qq < t.qn) {
+                v = sb[(long)r * a.snew_ld + qq];
+                for (int x = 1; x < a.snew_splitk; ++x) v += sb[(long)r * a.snew_ld + qq + x * a.snew_split_stride];
+            }
+            snew[r * snp + qq] = v;
+        }
+        r_cq = (lane < t.qn) ? a.cq[t.row0 + lane] : 0.f;
+    };
+    const bool regs_ok = a.regs_ok != 0;                                    // (launcher: the register stage fits and the rows are 16-byte aligned)
+    long u = blockIdx.x;
+    if (u >= n_units) { wg_stamp_end(a.wg_stamps); return; }
+    Unit cur = unit_of(u);
+    if (regs_ok) load_unit(cur);
+    // static operator entries of this lane's four boxes
+    float val[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
+    int brow[4] = {-1, -1, -1, -1};
+    const bool lane_ok = 4 * lane < N;
+    if (lane_ok) {
+        const floatx4 v4 = reinterpret_cast<const floatx4*>(a.box_val)[lane], w4 = reinterpret_cast<const floatx4*>(a.w)[lane];
+        const int4 b4 = reinterpret_cast<const int4*>(a.box_row)[lane];
+        val[0] = v4.x; val[1] = v4.y; val[2] = v4.z; val[3] = v4.w;
+        wn[0] = w4.x; wn[1] = w4.y; wn[2] = w4.z; wn[3] = w4.w;
+        brow[0] = b4.x; brow[1] = b4.y; brow[2] = b4.z; brow[3] = b4.w;
+    }
+#ifdef INFV_EXPERIMENTS
+    long long t_wg0 = a.dbg ? wall_clock64() : 0, t_stage = 0, t_comp = 0, t_issue = 0; int n_done = 0;
+#endif
+    for (; u < n_units; u += gridDim.x) {
+        cur = unit_of(u);
+#ifdef INFV_EXPERIMENTS
+        const long long t0 = a.dbg ? wall_clock64() : 0;
+#endif
+        __syncthreads();                                                    // the previous unit's rows are done with the LDS tiles
+        if (regs_ok) store_unit(cur); else stage_unit_direct(cur);
+        const float cq_lane = r_cq;
         __syncthreads();
+#ifdef INFV_EXPERIMENTS
+        const long long t1 = a.dbg ? wall_clock64() : 0;
+#endif
+        if (regs_ok && u + gridDim.x < n_units) load_unit(unit_of(u + gridDim.x));     // in flight behind this unit's arithmetic
+#ifdef INFV_EXPERIMENTS
+        if (a.dbg) { const long long t1b = wall_clock64(); t_issue += t1b - t1; }
+#endif
+        const bool write_sp = a.Sp_out != nullptr && cur.i == a.n_steps - 1;
+        const int qn = cur.qn;
+        const long row0 = cur.row0, slot = cur.slot;
+        float asum_mine = 0.f;                                              // lane j keeps the weight sum of this wave's j-th row
 #pragma unroll
-        for (int j = 0; j < kA2Q / (kA2NT / 64); ++j) {
+        for (int j = 0; j < kRpw; ++j) {
             const int qq = wave + j * (kA2NT / 64);
             if (qq >= qn) break;
             const float* pr = prev + qq * kScPitch;
-            const float cqv = cq_r[j];
+            const float cqv = __shfl(cq_lane, qq);
             float sv[4];
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int n = lane + 64 * k;
                 sv[k] = -INFINITY;
-                if (n < N) {
+                if (lane_ok) {
                     float acc = 0.f;
-                    for (int k0 = 0; k0 < tabw; k0 += 4) {
-                        const int4 src = *reinterpret_cast<const int4*>(&tabb[n * tabw + k0]);
+#pragma unroll (TW4 > 0 ? TW4 : 1)
+                    for (int jj = 0; jj < tw4; ++jj) {
+                        const int4 src = tabb[(4 * jj + k) * nq + lane];
                         const float v0 = pr[max(src.x, 0)], v1 = pr[max(src.y, 0)];
                         const float v2 = pr[max(src.z, 0)], v3 = pr[max(src.w, 0)];
                         if (src.x >= 0) acc = fmaf(val[k], v0, acc);
@@ -1144,43 +1181,77 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
                         if (src.w >= 0) acc = fmaf(val[k], v3, acc);
                     }
                     if (brow[k] >= 0) acc += snew[brow[k] * snp + qq];
-                    if (write_sp) a.Sp_out[(row0 + qq) * N + n] = acc;     // bias-free scores of the call's last step (diagnostics)
+                    if (write_sp) a.Sp_out[(row0 + qq) * N + 4 * lane + k] = acc;   // bias-free scores of the call's last step (diagnostics)
                     sv[k] = acc + cqv;
                 }
                 mx = fmaxf(mx, sv[k]);
             }
             mx = wave_max(mx);
-            float e[4];
-            float esum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int n = lane + 64 * k;
-                e[k] = (n < N) ? wn[k] * __expf(sv[k] - mx) : 0.f;
-                esum += e[k];
-            }
+            floatx4 e = {0.f, 0.f, 0.f, 0.f};
+            if (lane_ok) { e.x = wn[0] * __expf(sv[0] - mx); e.y = wn[1] * __expf(sv[1] - mx); e.z = wn[2] * __expf(sv[2] - mx); e.w = wn[3] * __expf(sv[3] - mx); }
+            float esum = (e.x + e.y) + (e.z + e.w);
             esum = wave_sum(esum);
             const float inv = 1.0f / (esum + a.w_out * __expf(-mx));
-            float* al = a.alpha_ring + slot * a.alpha_slot + (row0 + qq) * N;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int n = lane + 64 * k;
-                if (n < N) al[n] = e[k] * inv;
+            if (lane_ok) {
+                e.x *= inv; e.y *= inv; e.z *= inv; e.w *= inv;
+                *reinterpret_cast<floatx4*>(a.alpha_ring + slot * a.alpha_slot + (row0 + qq) * N + 4 * lane) = e;
             }
-            if (lane == 0) a.asum_ring[slot * a.asum_slot + row0 + qq] = esum * inv;
+            if (lane == j) asum_mine = esum * inv;
         }
+        if (lane < kRpw && wave + lane * (kA2NT / 64) < qn) a.asum_ring[slot * a.asum_slot + row0 + wave + lane * (kA2NT / 64)] = asum_mine;
+#ifdef INFV_EXPERIMENTS
+        if (a.dbg) { const long long t2 = wall_clock64(); t_stage += t1 - t0; t_comp += t2 - t1; ++n_done; }
+#endif
     }
+#ifdef INFV_EXPERIMENTS
+    if (a.dbg && tid == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 0), (unsigned long long)n_done);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 1), (unsigned long long)t_stage);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 2), (unsigned long long)t_comp);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 3), (unsigned long long)(wall_clock64() - t_wg0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 4), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.dbg + 5), (unsigned long long)t_issue);
+    }
+#endif
     wg_stamp_end(a.wg_stamps);
 }
 
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
     if (a_.n_steps <= 0) return hipSuccess;
-    if (a_.N > 256 || (a_.N * a_.tabw) % 4) return hipErrorInvalidValue;
+    // (one lane per four boxes: 16-byte stores of the weight rows)
+    if (a_.N > 256 || a_.N % 4 || a_.tabw % 4 || (reinterpret_cast<unsigned long>(a_.alpha_ring) & 15) || a_.alpha_slot % 4) return hipErrorInvalidValue;
     AlphaRows2Args a = a_;
-    a.wg_stamps = exp_stamps_reserve(WG_ALPHA, (long)a.n_steps * a.L * a.H);
     static const int prio = [] { const char* e = exp_env("INFV_ALPHA_PRIO"); return e ? atoi(e) : 0; }();
     a.prio = prio;
+    // the register stage of the next unit: the table and the S'new tile fit two 16-byte vectors per thread, rows 16-byte aligned
+    a.regs_ok = a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
+                a.snew_split_stride % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0;
     const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + a.rows * (kA2Q + 1)) * sizeof(float);
-    hipLaunchKernelGGL(alpha_rows2_kernel, dim3(a.n_steps, a.L * a.H), dim3(kA2NT), lds, stream, a);
+    // two work units per workgroup (experiments build: INFV_ALPHA_UPW; 1 / 2 / 4 on one box: 14.1 / 13.8 / 15.1 ms per video): the next unit's loads fly behind the present one's arithmetic
+    static const int upw = [] { const char* e = exp_env("INFV_ALPHA_UPW"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 1; }();
+    const long n_units = (long)a.n_steps * a.L * a.H * ((a.Q + kA2Q - 1) / kA2Q);
+    const unsigned grid = (unsigned)((n_units + upw - 1) / upw);
+    a.wg_stamps = exp_stamps_reserve(WG_ALPHA, (long)grid);
+    a.dbg = nullptr;
+#ifdef INFV_EXPERIMENTS
+    {   // INFV_ALPHA_STAMPS=1: phase time sums over all workgroups, printed every 64 launches
+        static long long* dbg = [] { long long* p = nullptr; if (exp_env("INFV_ALPHA_STAMPS")) { (void)hipMalloc(&p, 8 * sizeof(long long)); (void)hipMemset(p, 0, 8 * sizeof(long long)); } return p; }();
+        a.dbg = dbg;
+        static int calls = 0;
+        if (dbg && (++calls % 64) == 0) {
+            long long hb[8];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+            (void)hipMemset(dbg, 0, 8 * sizeof(long long));
+            if (hb[0] > 0 && hb[4] > 0)
+                fprintf(stderr, "[alpha stamps] units %lld workgroups %lld: per unit stage (sync + registers -> LDS, incl. waiting for the loads) %.2f us, issue of the next unit's loads %.2f us, arithmetic + stores %.2f us; per workgroup %.2f us\n",
+                        hb[0], hb[4], hb[1] / 100.0 / hb[0], hb[5] / 100.0 / hb[0], (hb[2] - hb[5]) / 100.0 / hb[0], hb[3] / 100.0 / hb[4]);
+        }
+    }
+#endif
+    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -204,6 +204,8 @@ struct AlphaRows2Args {
     float* Sp_out;                  // full bias-free score rows of the LAST step [L][H][Q][N], or nullptr
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
     int prio;                       // experiments build: s_setprio level of the kernel's waves (0 = leave)
+    int regs_ok;                    // set by the launcher: the next unit's inputs fit the kernel's register stage
+    long long* dbg;                 // experiments build, INFV_ALPHA_STAMPS: phase time sums (100 MHz ticks), or nullptr
 };
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
 bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int draw_mode, int points_ok, int Q);   // all workgroups of the kernel the launch will use fit on the device at once
