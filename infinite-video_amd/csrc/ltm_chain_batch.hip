@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
         r_cq = (lane < t.qn) ? a.cq[t.row0 + lane] : 0.f;
     };
     const bool regs_ok = a.regs_ok != 0;                                    // (launcher: the register stage fits and the rows are 16-byte aligned)
+    if (tid < snp) snew[rows * snp + tid] = 0.f;                          // the zero row (read by boxes without a new row)
     long u = blockIdx.x;
     if (u >= n_units) { wg_stamp_end(a.wg_stamps); return; }
     Unit cur = unit_of(u);
@@ -1158,6 +1159,29 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
         const int qn = cur.qn;
         const long row0 = cur.row0, slot = cur.slot;
         float asum_mine = 0.f;                                              // lane j keeps the weight sum of this wave's j-th row
+        // The gather table is the same for all rows of the unit: resolve this lane's 4 x tabw entries ONCE into LDS addresses of
+        // the wave's first row (row j of the wave is a constant 4 kScPitch floats further: an immediate offset of the read) and
+        // into coefficients that are 0 for an empty slot (fma(0, finite, acc) = acc: the same bits as skipping it); a box without
+        // a new row reads the zero row behind the S'new tile.  Per row that leaves the reads, the fma chain and the softmax.
+        constexpr int kSl = TW4 > 0 ? 4 * TW4 : 4;                          // resolved slots per box held in registers
+        const float* gp[4][kSl]; float gv[4][kSl]; const float* sp[4];
+        if (TW4 > 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int jj = 0; jj < TW4; ++jj) {
+                    int4 src = make_int4(-1, -1, -1, -1);
+                    if (lane_ok) src = tabb[(4 * jj + k) * nq + lane];
+                    const int sx[4] = {src.x, src.y, src.z, src.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        gp[k][4 * jj + c] = prev + wave * kScPitch + max(sx[c], 0);
+                        gv[k][4 * jj + c] = sx[c] >= 0 ? val[k] : 0.f;
+                    }
+                }
+                sp[k] = snew + (brow[k] >= 0 ? brow[k] : rows) * snp + wave;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < kRpw; ++j) {
             const int qq = wave + j * (kA2NT / 64);
@@ -1171,17 +1195,23 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
                 sv[k] = -INFINITY;
                 if (lane_ok) {
                     float acc = 0.f;
-#pragma unroll (TW4 > 0 ? TW4 : 1)
-                    for (int jj = 0; jj < tw4; ++jj) {
-                        const int4 src = tabb[(4 * jj + k) * nq + lane];
-                        const float v0 = pr[max(src.x, 0)], v1 = pr[max(src.y, 0)];
-                        const float v2 = pr[max(src.z, 0)], v3 = pr[max(src.w, 0)];
-                        if (src.x >= 0) acc = fmaf(val[k], v0, acc);
-                        if (src.y >= 0) acc = fmaf(val[k], v1, acc);
-                        if (src.z >= 0) acc = fmaf(val[k], v2, acc);
-                        if (src.w >= 0) acc = fmaf(val[k], v3, acc);
+                    if (TW4 > 0) {
+#pragma unroll
+                        for (int c = 0; c < kSl; ++c) acc = fmaf(gv[k][c], gp[k][c][j * (kA2NT / 64) * kScPitch], acc);
+                        acc += sp[k][j * (kA2NT / 64)];
+                    } else {
+#pragma unroll 1
+                        for (int jj = 0; jj < tw4; ++jj) {
+                            const int4 src = tabb[(4 * jj + k) * nq + lane];
+                            const float v0 = pr[max(src.x, 0)], v1 = pr[max(src.y, 0)];
+                            const float v2 = pr[max(src.z, 0)], v3 = pr[max(src.w, 0)];
+                            if (src.x >= 0) acc = fmaf(val[k], v0, acc);
+                            if (src.y >= 0) acc = fmaf(val[k], v1, acc);
+                            if (src.z >= 0) acc = fmaf(val[k], v2, acc);
+                            if (src.w >= 0) acc = fmaf(val[k], v3, acc);
+                        }
+                        if (brow[k] >= 0) acc += snew[brow[k] * snp + qq];
                     }
-                    if (brow[k] >= 0) acc += snew[brow[k] * snp + qq];
                     if (write_sp) a.Sp_out[(row0 + qq) * N + 4 * lane + k] = acc;   // bias-free scores of the call's last step (diagnostics)
                     sv[k] = acc + cqv;
                 }
@@ -1227,7 +1257,7 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
     // the register stage of the next unit: the table and the S'new tile fit two 16-byte vectors per thread, rows 16-byte aligned
     a.regs_ok = a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
                 a.snew_split_stride % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0;
-    const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + a.rows * (kA2Q + 1)) * sizeof(float);
+    const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1)) * sizeof(float);   // (+ a zero row behind the S'new tile)
     // two work units per workgroup (experiments build: INFV_ALPHA_UPW; 1 / 2 / 4 on one box: 14.1 / 13.8 / 15.1 ms per video): the next unit's loads fly behind the present one's arithmetic
     static const int upw = [] { const char* e = exp_env("INFV_ALPHA_UPW"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 1; }();
     const long n_units = (long)a.n_steps * a.L * a.H * ((a.Q + kA2Q - 1) / kA2Q);
