@@ -235,12 +235,18 @@ int infv_ltm_import_state(infv_ltm_handle h, int32_t layer, const float* B, cons
                           const infv_ltm_proj* proj, void* stream);
 /* Exact hand-off of the memory chain between handles (multi-GPU correctness mode: rank r continues where rank r-1
  * stopped, reference semantics of one process walking the whole video, long_term_attention_gibbs.py:194-222).
- * The blob is everything infv_ltm_consolidate carries from chunk to chunk, in fp32:
+ * The blob is a 64-byte header (magic, version, L, N, d, dm, H, Q, n_bins as int32) and everything infv_ltm_consolidate
+ * carries from chunk to chunk, in fp32:
  *   B [L][N][d] | projected memory [L][N][2][dm] | bias-free scores under the call's query [L][H][Q][N] | sticky bin
  *   masses [L][n_bins]
- * so a consolidate call that follows an import (same q and proj, new_doc = 0) continues BIT FOR BIT as if the exporting
- * handle had gone on itself -- unlike export_state/import_state, which hand over B and the masses only and re-derive the
- * rest (same values up to fp32 rounding).  export needs a memory whose last step ran in infv_ltm_consolidate with query
+ * so a consolidate call that follows an import (new_doc = 0) continues BIT FOR BIT as if the exporting handle had gone on
+ * itself -- unlike export_state/import_state, which hand over B and the masses only and re-derive the rest (same values up
+ * to fp32 rounding).  Conditions, none of which the library can check for the caller: the SAME q and proj on both sides (the
+ * blob carries the scores under the exporter's query), and blocks that do not end in a short sub-batch -- a sub-batch of
+ * fewer than 1024 new rows (16 chunks at the headline shape) takes the split-K form of the projection, whose sums are
+ * ordered differently (same values to fp32 rounding, not the same bits; tests/test_sharding_gpu.py cuts 129 chunks as 65 + 64).
+ * import checks the header on the device: a blob of another shape latches an error that the next entry point returns as
+ * INFV_ERR_STATE (the memory is reset).  export needs a memory whose last step ran in infv_ltm_consolidate with query
  * length Q; blob = DEVICE buffer of infv_ltm_chain_state_bytes(h, Q) bytes; both are asynchronous on `stream`. */
 int64_t infv_ltm_chain_state_bytes(infv_ltm_handle h, int32_t Q);
 int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* stream);

@@ -217,10 +217,27 @@ int check_handle(infv_ltm_handle h) {
 
 // A time-out of the persistent chain kernel leaves garbage in the memory: report it once (at the next entry point
 // that would use or extend the memory, or at infv_ltm_sync) and forget the memory.
+// header of a chain-state blob (infv_ltm_export_chain_state): 16 int32 in front of the fp32 payload
+constexpr int kBlobHeaderInts = 16;
+constexpr int kBlobMagic = 0x43464E49;             // "INFC"
+constexpr int kBlobVersion = 1;
+constexpr unsigned int kErrBlobMismatch = 0x100u;  // error-latch code (1 = chain time-out)
+struct BlobHeader { int v[kBlobHeaderInts]; };
+__global__ void blob_header_write_kernel(int* out, BlobHeader hd) { if (threadIdx.x < kBlobHeaderInts) out[threadIdx.x] = hd.v[threadIdx.x]; }
+__global__ void blob_header_check_kernel(const int* in, BlobHeader hd, unsigned int* err) {
+    bool bad = false;
+    for (int i = 0; i < kBlobHeaderInts; ++i) bad = bad || in[i] != hd.v[i];
+    if (bad) __hip_atomic_store(err, kErrBlobMismatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int check_chain_error(infv_ltm_handle h) {
     if (h->err_host && *reinterpret_cast<volatile unsigned int*>(h->err_host)) {
+        const unsigned int code = *reinterpret_cast<volatile unsigned int*>(h->err_host);
         *reinterpret_cast<volatile unsigned int*>(h->err_host) = 0;
         h->has_memory = false; h->parts = 0; h->k_stale = false;
+        if (code == kErrBlobMismatch)
+            return fail(INFV_ERR_STATE, "the blob handed to an earlier infv_ltm_import_chain_state was not exported by a handle of "
+                                        "this shape (magic / version / L, N, d, dm, H, Q, n_bins in its header); the memory has been reset");
         return fail(INFV_ERR_STATE, "the persistent chain kernel of an earlier infv_ltm_consolidate timed out waiting for the "
                                     "other workgroups of its layer (not all co-resident: partitioned or shared GPU?); "
                                     "its outputs and the memory are invalid, the memory has been reset");
@@ -1568,9 +1585,18 @@ int infv_ltm_export_state(infv_ltm_handle h, int32_t layer, float* B, float* bin
 
 int64_t infv_ltm_chain_state_bytes(infv_ltm_handle h, int32_t Q) {
     if (!h || Q <= 0 || Q > h->maxQ) return -1;
-    return (int64_t)sizeof(float) * ((int64_t)h->L * h->N * h->d + (int64_t)h->L * h->N * 2 * h->dm +
+    return (int64_t)sizeof(float) * (kBlobHeaderInts + (int64_t)h->L * h->N * h->d + (int64_t)h->L * h->N * 2 * h->dm +
                                      (int64_t)h->L * h->H * Q * h->N + (int64_t)h->L * h->n_bins);
 }
+
+namespace {
+BlobHeader blob_header(infv_ltm_handle h, int Q) {
+    BlobHeader hd{};
+    const int v[] = {kBlobMagic, kBlobVersion, h->L, h->N, h->d, h->dm, h->H, Q, h->n_bins};
+    for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); ++i) hd.v[i] = v[i];
+    return hd;
+}
+}  // namespace
 
 int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* stream_) {
     if (int rc = check_handle(h)) return rc;
@@ -1580,7 +1606,9 @@ int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* 
     if (!h->has_memory || !h->last_fast || h->lastQ != Q || h->parts != 1)
         return fail(INFV_ERR_STATE, "export_chain_state: the memory's last step must come from infv_ltm_consolidate with Q=%d", Q);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    float* out = static_cast<float*>(blob);
+    hipLaunchKernelGGL(blob_header_write_kernel, dim3(1), dim3(64), 0, stream, static_cast<int*>(blob), blob_header(h, Q));
+    HIP_TRY(hipGetLastError());
+    float* out = static_cast<float*>(blob) + kBlobHeaderInts;
     const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,
                  nM = (size_t)h->L * h->n_bins;
     HIP_TRY(hipMemcpyAsync(out, h->B[h->cur].p, nB * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1596,7 +1624,10 @@ int infv_ltm_import_chain_state(infv_ltm_handle h, int32_t Q, const void* blob, 
     if (int rc = check_q(h, Q)) return rc;
     if (int rc = check_chain_error(h)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const float* in = static_cast<const float*>(blob);
+    // the header is checked on the device (the call stays asynchronous): a mismatch latches an error that the next entry point reports
+    hipLaunchKernelGGL(blob_header_check_kernel, dim3(1), dim3(1), 0, stream, static_cast<const int*>(blob), blob_header(h, Q), h->err_dev);
+    HIP_TRY(hipGetLastError());
+    const float* in = static_cast<const float*>(blob) + kBlobHeaderInts;
     const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,
                  nM = (size_t)h->L * h->n_bins;
     HIP_TRY(hipMemcpyAsync(h->B[h->cur].p, in, nB * sizeof(float), hipMemcpyDeviceToDevice, stream));

@@ -18,8 +18,9 @@ The Gibbs uniforms are keyed by GLOBAL chunk index, so rank r's result equals a 
 run on the sub-video made of rank r's chunks.
 
 Correctness mode (``consolidate_video(..., handoff=True)``): the ranks hand the memory chain on from block to block
-(point-to-point send/recv of ~5.5 MB at the headline shape) and reproduce the single-stream run bit for bit; they
-run one after the other.
+(point-to-point send/recv of ~5.5 MB at the headline shape) and reproduce the single-stream run -- bit for bit when every
+rank uses the same q / projections and no block ends in a short sub-batch (see ``consolidate_video``); they run one after
+the other.
 """
 from __future__ import annotations
 
@@ -130,7 +131,12 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
     sticky bin masses: ``engine.export_chain_state``), imports it and runs its block with ``new_doc=False``, then
     passes its own state on to rank r+1.  Every chunk then sees the memory of all earlier chunks exactly as in the
     reference's one-process loop (long_term_attention_gibbs.py:194-222): the outputs equal the single-stream run bit
-    for bit -- and the ranks run one after the other, so it does not scale.
+    for bit -- and the ranks run one after the other, so it does not scale.  Bit for bit holds when (a) every rank passes
+    the same ``q`` and ``projs`` (the blob carries the scores under the exporter's query; nothing checks this) and (b) no
+    block but the last ends in a sub-batch of fewer than 1024 new rows (16 chunks at the headline shape): such a tail takes
+    the split-K form of the projection, whose partial sums are ordered differently -- same values to fp32 rounding, a draw
+    may then differ by an index (tests/test_sharding_gpu.py cuts 129 chunks as 65 + 64 for this reason).  The blob has a
+    header (shape of the exporting handle); importing one of another shape fails at the next library call.
 
     This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
     raises if the persistent chain kernel reported a failure instead of passing an invalid memory on.

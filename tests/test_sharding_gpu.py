@@ -80,3 +80,35 @@ def test_handoff_mode_reproduces_the_single_stream_run_bit_for_bit(single, tmp_p
     np.testing.assert_array_equal(got, single["whole"])
     np.testing.assert_array_equal(ranks[1]["B"][1], single["whole_B"])      # the last rank ends with the single-stream memory
     np.testing.assert_array_equal(ranks[1]["bins"], single["whole_bins"])
+
+
+def test_chain_state_blob_of_another_shape_is_refused():
+    """The blob of infv_ltm_export_chain_state starts with a header (magic, version, L, N, d, dm, H, Q, n_bins).  import checks it on
+    the device, so the call stays asynchronous: a blob exported by a handle of another shape latches an error that the next
+    entry point returns (INFV_ERR_STATE), and the importing handle's memory is reset; a matching blob continues the chain."""
+    from infinite_video_amd import _lib
+    from infinite_video_amd.engine import LTMEngine
+    from tests.test_timed_path_gpu import L, _engine, _video
+    dev = torch.device("cuda:0")
+    k, q, projs, u, _, _ = _video(dev, 64)                                # (blocks of 32 chunks = the call's sub-batches: see consolidate_video)
+    a = _engine(dev, max_batch_chunks=42)
+    a.consolidate(k[:32], q, projs, u[:32], new_doc=True)
+    a.sync()
+    Q = q.shape[1]
+    blob = a.export_chain_state(Q)
+    hdr = blob[:16].view(torch.int32).cpu().numpy()
+    assert hdr[0] == 0x43464E49 and hdr[1] == 1 and list(hdr[2:4]) == [L, 256] and hdr[7] == Q
+    ok = _engine(dev, max_batch_chunks=42)
+    ok.import_chain_state(Q, blob)
+    cont = ok.consolidate(k[32:], q, projs, u[32:], new_doc=False)
+    whole = _engine(dev, max_batch_chunks=42).consolidate(k, q, projs, u, new_doc=True)    # one call over all 64 chunks
+    assert torch.equal(cont, whole[32:])
+    bad = blob.clone()
+    bad[:16].view(torch.int32)[3] = 128                                  # "exported by a handle with N = 128"
+    other = _engine(dev, max_batch_chunks=42)
+    other.import_chain_state(Q, bad)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.LTMError) as ei:
+        other.consolidate(k[32:], q, projs, u[32:], new_doc=False)
+    assert ei.value.code == -4 or "blob" in str(ei.value)                # INFV_ERR_STATE
+    assert not other.has_memory
