@@ -33,6 +33,10 @@ import ctypes as C
 
 from .engine import TOKEN_DTYPES, LTMEngine
 
+# raw current-stream handle / current device index: torch's C bindings when present (torch >= 1.10), the public API otherwise
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
 # one-entry cache of pooled frames: the Q-former calls every layer's LTM with the same
 # encoder_hidden_states tensor OBJECT, so the frame tokens (25 MB at the headline shape) are read once per
 # chunk.  Keyed by a weak reference to that object (an address could be recycled by the allocator) + its version.
@@ -260,7 +264,11 @@ class LongTermAttention(nn.Module):
         eng = self._get_engine(k.device, qlen)
         if new_doc or not self.infinite_memory:
             eng.reset()                                   # :300-302 (and the non-infinite branch :310)
-        stream = C.c_void_p(torch.cuda.current_stream(k.device).cuda_stream)
+        # (raw handle of the device's current stream and the current-device check through torch._C: the public wrappers cost 2 us
+        #  and 1 us per use on a path whose whole host side is ~35 us)
+        dev_index = k.device.index if k.device.index is not None else torch.cuda.current_device()
+        stream = C.c_void_p(_raw_stream(dev_index))
+        other_device = _cur_device() != dev_index
         ref = _pool_cache["ref"]
         if ref is not None and ref() is k and _pool_cache["version"] == k._version:
             kbar = _pool_cache["kbar"]
@@ -271,8 +279,11 @@ class LongTermAttention(nn.Module):
             if not kf.is_contiguous():
                 kf = kf.contiguous()
             kbar = torch.empty(klen, self.encoder_width, device=k.device, dtype=torch.float32)
-            with torch.cuda.device(k.device):
-                eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)           # :304
+            if other_device:
+                with torch.cuda.device(k.device):
+                    eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)       # :304
+            else:
+                eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)
             _pool_cache["ref"], _pool_cache["version"], _pool_cache["kbar"] = weakref.ref(k), k._version, kbar
         sticky_step = eng.has_memory and self.sticky_memories
         # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
@@ -281,7 +292,11 @@ class LongTermAttention(nn.Module):
         if qf.dtype != torch.float32 or not qf.is_contiguous():
             qf = qf.float().contiguous()
         ctx = torch.empty(1, qlen, self.n_head * self.head_size, device=k.device, dtype=torch.float32)
-        with torch.cuda.device(k.device):
+        if other_device:
+            with torch.cuda.device(k.device):
+                eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, eng._proj_array([self._proj(k.device)]), u_addr,
+                             ctx.data_ptr(), stream)
+        else:
             eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, eng._proj_array([self._proj(k.device)]), u_addr,
                          ctx.data_ptr(), stream)
         if sticky_step:

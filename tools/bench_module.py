@@ -22,17 +22,23 @@ m = LongTermAttention(head_size=64, length=768, target_len=768, attn_func="softm
 ks = [torch.randn(1, 256 * 32, 768, device=dev) for _ in range(8)]
 q = torch.randn(1, 32, 768, device=dev)
 torch.manual_seed(0)
-for c in range(4):
+for c in range(300):                       # warm-up: one-time costs of a fresh process (code-object loads, pinned ring, clock ramp) stay outside
     m(ks[c % 8], q, new_doc=(c == 0), layer_n=0)
 torch.cuda.synchronize()
 n = 200
-t0 = time.perf_counter()
-for c in range(n):
-    m(ks[c % 8], q, new_doc=False, layer_n=0)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"LongTermAttention.forward, T=256 N=256: host issue {1e6 * (t1 - t0) / n:.1f} us/call, end to end {1e6 * (t2 - t0) / n:.1f} us/call")
+res = []
+for rep in range(5):                       # five blocks of 200 calls, the median block is reported
+    t0 = time.perf_counter()
+    for c in range(n):
+        m(ks[c % 8], q, new_doc=False, layer_n=0)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    res.append((t2 - t0, t1 - t0))
+res.sort()
+e2e, host = res[len(res) // 2]
+print(f"LongTermAttention.forward, T=256 N=256: host issue {1e6 * host / n:.1f} us/call, end to end {1e6 * e2e / n:.1f} us/call "
+      f"(median of 5 blocks of {n} calls; best {1e6 * res[0][0] / n:.1f}, worst {1e6 * res[-1][0] / n:.1f})")
 if "--profile" in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile()
