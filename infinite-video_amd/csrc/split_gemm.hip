@@ -735,12 +735,30 @@ hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, v
 }  // namespace infv
 // test hook (experiments build only, tests/test_ltm_gpu.py): C [M][N] = A [M][K] . B [N][K]^T through the bf16x6 path (which = 0) or
 // through the fp32-MFMA kernel the whole-video path used before (which = 1); which = 2: the bf16x6 path's 128 x 128 kernel even where
-// the 384 x 256 one applies; device pointers, synchronous
+// the 384 x 256 one applies; which = 3 / 4: the split-bf16 (three-product) contraction, wide tiles / 128 x 128 tiles; device pointers, synchronous
 extern "C" int infv_exp_gemm(int which, const float* A, const float* B, float* C, int M, int N, int K) {
     using namespace infv;
     if (which == 1) {
         if (launch_project_scores(M, K, N, B, A, C, N, nullptr, 0) != hipSuccess) return -1;
         return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+    }
+    if (which == 3 || which == 4) {
+        // split-bf16 (hi/lo, three products) contraction of the video Q-former: 3 = whichever kernel the launcher picks (the
+        // 384 x 256 one where whole tiles fit), 4 = the 128 x 128 kernel on the same operands
+        __bf16* sp[4] = {};
+        for (int i = 0; i < 4; ++i)
+            if (hipMalloc(&sp[i], (size_t)(i < 2 ? M : N) * K * sizeof(__bf16)) != hipSuccess) return -1;
+        int rc3 = 0;
+        if (launch_split_rows(A, K, M, K, sp[0], sp[1], K, nullptr) != hipSuccess) rc3 = -1;
+        if (launch_split_rows(B, K, N, K, sp[2], sp[3], K, nullptr) != hipSuccess) rc3 = -1;
+        SplitGemm sg{};
+        sg.A_hi = sp[0]; sg.A_lo = sp[1]; sg.lda = K; sg.strideA = 0; sg.B_hi = sp[2]; sg.B_lo = sp[3]; sg.ldb = K; sg.strideB = 0;
+        sg.C = C; sg.ldc = N; sg.strideC = 0; sg.split_stride = 0; sg.M = M; sg.N = N; sg.K = K; sg.k_per_split = K; sg.splitk = 1; sg.nbatch = 1;
+        if (rc3 == 0 && which == 3 && !split_gemm_wide_applies(sg)) rc3 = -2;        // (the test wants to know that the wide kernel ran)
+        if (rc3 == 0 && launch_split_gemm(sg, nullptr, which == 4 ? 1 : 0) != hipSuccess) rc3 = -1;
+        if (hipDeviceSynchronize() != hipSuccess) rc3 = -1;
+        for (int i = 0; i < 4; ++i) (void)hipFree(sp[i]);
+        return rc3;
     }
     __bf16* pl[6] = {};
     for (int i = 0; i < 6; ++i)

@@ -133,6 +133,52 @@ def test_bf16x6_projection_gemm_is_as_accurate_as_the_fp32_mfma_gemm(dev, tmp_pa
         assert e["same_bits"], (name, e)                                # 384 x 256 tiles (where they apply) == 128 x 128 tiles
 
 
+_SPLIT_CHILD = r'''
+import ctypes as C, sys, json
+import numpy as np, torch
+from infinite_video_amd import _lib
+lib = _lib.load()
+fn = lib.infv_exp_gemm
+fn.restype = C.c_int
+fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+dev = torch.device("cuda:0")
+out = {}
+# (M, N, K): one / two / three row tiles of 384, 2 .. 40 column tiles of 256, K from 4 to 128 k-tiles of 32 (192 workgroups or more)
+for name, M, N, K in [("scores_like", 384, 49152, 768), ("three_row_tiles", 1152, 16384, 128), ("long_k", 768, 24576, 4096)]:
+    g = torch.Generator(device=dev).manual_seed(N)
+    A = torch.randn(M, K, device=dev, generator=g)
+    B = torch.randn(N, K, device=dev, generator=g)
+    ref = A.double() @ B.double().T
+    mag = A.double().abs() @ B.double().abs().T
+    res = {}
+    keep = {}
+    for which, tag in [(3, "wide"), (4, "tiles128")]:
+        Cc = torch.zeros(M, N, device=dev)
+        rc = fn(which, A.data_ptr(), B.data_ptr(), Cc.data_ptr(), M, N, K)
+        assert rc == 0, (name, tag, rc)
+        res[tag] = float(((Cc.double() - ref).abs() / mag).max())
+        keep[tag] = Cc
+    res["same_bits"] = bool(torch.equal(keep["wide"], keep["tiles128"]))
+    out[name] = res
+json.dump(out, open(sys.argv[1], "w"))
+'''
+
+
+def test_split_bf16_wide_contraction_equals_the_128_tile_kernel(dev, tmp_path):
+    """split_gemm_wide_kernel (384 x 256 x 32 tiles streamed global -> LDS, two waves per SIMD) against split_gemm_kernel (128 x 128
+    tiles through registers) on the same hi/lo operands: the same three products per 16-deep k-step in the same order on every
+    accumulator, so the same bits; both within the split's 2^-16 relative error of fp64."""
+    import json
+    import subprocess
+    path = str(tmp_path / "split.json")
+    env = dict(os.environ, INFV_LTM_LIBRARY="exp")
+    subprocess.run([sys.executable, "-c", _SPLIT_CHILD, path], check=True, env=env, cwd=ROOT)
+    res = json.load(open(path))
+    for name, e in res.items():
+        assert e["wide"] < 4e-5 and e["tiles128"] < 4e-5, (name, e)
+        assert e["same_bits"], (name, e)
+
+
 def test_pool_rows_bf16_tokens_and_dense_plan_refusal(dev):
     """bf16 frame tokens through the one-pass kernel equal the fp32 run on the same (bf16-representable) values bit for bit;
     a num_basis whose plan is dense has no box rows: the entry point refuses it instead of returning something."""
