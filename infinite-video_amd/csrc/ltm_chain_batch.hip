@@ -1255,7 +1255,8 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
     static const int prio = [] { const char* e = exp_env("INFV_ALPHA_PRIO"); return e ? atoi(e) : 0; }();
     a.prio = prio;
     // the register stage of the next unit: the table and the S'new tile fit two 16-byte vectors per thread, rows 16-byte aligned
-    a.regs_ok = a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
+    static const bool force_direct = [] { const char* e = exp_env("INFV_ALPHA_DIRECT"); return e && atoi(e) != 0; }();   // (tests: the fallback staging)
+    a.regs_ok = !force_direct && a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
                 a.snew_split_stride % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0;
     const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1)) * sizeof(float);   // (+ a zero row behind the S'new tile)
     // two work units per workgroup (experiments build: INFV_ALPHA_UPW; 1 / 2 / 4 on one box: 14.1 / 13.8 / 15.1 ms per video): the next unit's loads fly behind the present one's arithmetic
