@@ -101,6 +101,50 @@ def pmc_traffic_per_full_launch():
     return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
 
 
+HBM_ACHIEVABLE_GBS = 6290.0    # what a pure streaming kernel reaches on this part (MI355X_MICROARCH.md, HBM section)
+
+
+def pmc_fabric_bytes_per_chunk(batch_chunks: int):
+    """Bytes that crossed the fabric (L2 <-> Infinity Cache / HBM) per chunk for EVERY kernel of the whole-video pipeline, from the
+    committed PMC summary (full sub-batch launches only).  FETCH_SIZE undercounts 128-B requests of a wide coalesced stream by
+    2x on gfx950 (MI355X_MICROARCH.md): the pooling stream is doubled (its traffic then equals its algorithmic bytes); for the
+    other kernels, whose request mix is not known, the figure is given both ways (low: as counted, high: doubled).  Unlike the
+    section-8d formula this charges what the memory system really moved: weights / B / scores that live in L2 cost nothing."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    frags = ("pool_rows2_kernel<", "split3_rows_kernel", "gemm_x6_wide_kernel", "gemm_nt_lw_kernel", "chain_batch3_kernel<",
+             "chain_call_kernel", "alpha_rows2_kernel<", "uc_fast_kernel<")
+    per = {}
+    try:
+        for frag in frags:
+            best = None
+            for k_, v in d["fetch"].items():
+                if frag in k_ and "grid=" in k_:
+                    g = int(k_.rsplit("grid=", 1)[1])
+                    if best is None or (v[0], g) > (best[0], best[1]):     # the most frequent launch shape = the full sub-batch
+                        best = (v[0], g, k_)
+            if best is None:
+                continue
+            key = best[2]
+            f, w = d["fetch"][key][1] * 1024.0, d["write"].get(key, [0, 0.0])[1] * 1024.0
+            pool = frag.startswith("pool_rows2")
+            per[frag.rstrip("<")] = ((2.0 * f if pool else f) + w, 2.0 * f + w)
+    except (KeyError, IndexError, ValueError):
+        return None
+    if "pool_rows2_kernel" not in per:
+        return None
+    # a call-long chain kernel is one launch per video, every other kernel one per sub-batch
+    def per_chunk(name, v, chunks_per_video=2048.0):
+        return v / (chunks_per_video if name == "chain_call_kernel" else float(batch_chunks))
+    lo = sum(per_chunk(n_, v[0]) for n_, v in per.items())
+    hi = sum(per_chunk(n_, v[1]) for n_, v in per.items())
+    return {"low": lo, "high": hi, "source": os.path.basename(files[-1]),
+            "per_kernel_high": {n_: round(per_chunk(n_, v[1])) for n_, v in per.items()}}
+
+
 class _StubEngine:
     """Stand-in for LTMEngine in --stub-engine runs: same surface (consolidate / export_state / sync), trivial arithmetic on the CPU.
     It exists so that the multi-rank plumbing of this file can be exercised where there is no GPU."""
@@ -125,7 +169,7 @@ class _StubEngine:
         pass
 
 
-def pmc_mfma_busy():
+def pmc_mfma_busy(batch_chunks: int = 42):
     """MFMA-pipe busy share of the projection GEMM (the path's MFMA kernel) and of the UC kernel's read-out from the committed
     rocprofv3 PMC pass (profiles/*_pmc_mfma_ltm.json: SQ_VALU_MFMA_BUSY_CYCLES against the kernel's busy cycles, tools/pmc_mfma.sh).
     Like ``traffic`` it is read from a committed profile of the same code, not collected live (counters need their own run)."""
@@ -141,7 +185,7 @@ def pmc_mfma_busy():
             if hit:
                 out[key] = round(float(hit[0]["mfma_util_pct"]), 1)
                 out[key + "_kernel"] = frag
-                if frag == "gemm_x6_wide_kernel":
+                if frag == "gemm_x6_wide_kernel" and batch_chunks == 42:
                     # the counter quotient is per chip (1024 SIMDs); this GEMM runs 63 workgroups (7 x 9 tiles of 384 x 256 per
                     # 42-chunk sub-batch), one per CU, beside the other kernels of the pipeline: busy share of the CUs it occupies
                     out[key + "_on_its_63_cus"] = round(float(hit[0]["mfma_util_pct"]) * 256.0 / 63.0, 1)
@@ -254,6 +298,46 @@ def cpu_baselines(budget_s: float):
                     f"{sum(t for _, t in closed.values()):.1f}s"}
     torch.set_num_threads(saved)
     return base, cf
+
+
+def module_forward_us(dev, k):
+    """Per-call latency of the drop-in ``LongTermAttention`` module (the reference's operator surface, long_term_attention_gibbs.py:
+    288-346 called from Qformer.py:221) at the headline shape: steady-state sticky calls on one layer, host issue and end-to-end
+    time per call, median of five blocks of 200 calls; plus the kernel launches per call."""
+    import torch
+    from infinite_video_amd import _lib as _libmod
+    from infinite_video_amd import synth
+    from infinite_video_amd.long_term_attention_gibbs import LongTermAttention
+    wk, bk, wv, bv = synth.layer_projections(0, D, DM)
+    pk, pv = torch.nn.Linear(D, DM), torch.nn.Linear(D, DM)
+    with torch.no_grad():
+        pk.weight.copy_(torch.from_numpy(wk)); pk.bias.copy_(torch.from_numpy(bk))
+        pv.weight.copy_(torch.from_numpy(wv)); pv.bias.copy_(torch.from_numpy(bv))
+    m = LongTermAttention(head_size=DH, length=D, target_len=D, attn_func="softmax", attn_num_basis=N, continuous=True,
+                          attn_drop=0.1, infinite_memory=True, n_layers=L, n_heads=H, affines=True, mask=True, mask_type="cnn",
+                          kl_regularizer=False, proj_key=pk.to(dev), proj_value=pv.to(dev), sigma_0=None, mu_0=None,
+                          sticky_memories=True, sigmas=None, tau=TAU, d_model=DM)
+    ks = [k[c].unsqueeze(0) for c in range(min(8, k.shape[0]))]
+    qq = torch.randn(1, Q, DM, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    torch.manual_seed(0)
+    for c in range(300):                   # one-time costs of a fresh module (code objects, pinned ring, clock ramp) stay outside
+        m(ks[c % len(ks)], qq, new_doc=(c == 0), layer_n=0)
+    torch.cuda.synchronize()
+    n, res = 200, []
+    launches0 = int(_libmod.load().infv_ltm_launch_count())
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for c in range(n):
+            m(ks[c % len(ks)], qq, new_doc=False, layer_n=0)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0, t1 - t0))
+    launches = (int(_libmod.load().infv_ltm_launch_count()) - launches0) / (5 * n)
+    res.sort()
+    e2e, host = res[len(res) // 2]
+    return {"what": "LongTermAttention.forward (drop-in module), T=256 N=256 Q=32, steady-state sticky calls, one layer",
+            "end_to_end_us": 1e6 * e2e / n, "host_issue_us": 1e6 * host / n, "best_block_us": 1e6 * res[0][0] / n,
+            "launches_per_call": launches, "layer_steps_per_s": n / e2e}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -398,9 +482,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx, mem = one_step(tim)
+        ctx, mem = one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    # shard / all-gather split of a step: a separate short pass (its extra device-wide sync behind the collective is not part of
+    # the timed region above, so a multi-GPU run overlaps step i's all-gather with step i+1's consolidation as a caller would)
+    for _ in range(min(5, args.steps)):
+        one_step(tim)
+    fence()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -422,14 +511,29 @@ def main():
         return
 
     # ---- self-check of the code path that was just timed (same engine, same call, plus a draw trace) ----
-    check = None
+    check, bins_default = None, None
     if not args.no_selfcheck:
         trace = eng.set_trace(c_local)
         ctx_chk, _ = one_step()
         eng.set_trace(0)
         assert torch.equal(ctx_chk, ctx), "the consolidation is not reproducible run to run"
         check = selfcheck(LTMEngine, dev, k, q, projs, u, ctx_chk, trace, args.batch_chunks)
+        bins_default = trace[0].clone()
         del trace
+
+    def draw_flips(engine, tokens):
+        """Draws of `engine`'s call over the same video that differ from the default line's (both free-running): how many of the
+        call's (C-1) x L x S draws, how many chunks hold at least one, and the largest bin distance."""
+        if bins_default is None:
+            return None
+        tr = engine.set_trace(c_local)
+        consolidate_video(engine, tokens, q, projs, u)
+        torch.cuda.synchronize()
+        engine.set_trace(0)
+        diff = tr[0] != bins_default
+        dist_max = int((tr[0] - bins_default).abs().max()) if bool(diff.any()) else 0
+        return {"draws_differing": int(diff.sum()), "of": int((c_local - 1) * L * S),
+                "chunks_with_a_differing_draw": int(diff.flatten(1).any(1).sum()), "max_bin_distance": dist_max}
 
     # ---- secondary line (N = 1): the same call with the V' half of the projection as three bf16 MFMA products
     #      (INFV_VPROJ_SPLIT=1 at engine creation).  V' only feeds the read-out (1e-3 budget); the draw is unchanged. ----
@@ -451,7 +555,8 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
         vsplit = {"dtype": "f32 (V' projection bf16x3)", "value": args.chunks * n2 / dt2, "unit": "frame-chunks/s",
-                  "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "max_abs_diff_vs_f32": float((ctx2 - ctx).abs().max())}
+                  "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "max_abs_diff_vs_f32": float((ctx2 - ctx).abs().max()),
+                  "draw_flips": draw_flips(eng2, k)}
         del eng2, ctx2
 
     # ---- secondary line (N = 1): the projection GEMM on the fp32 MFMA pipe (INFV_PROJ_X6=0 at engine creation: gemm_nt_lw_kernel,
@@ -477,7 +582,7 @@ def main():
         dt4 = time.perf_counter() - t1
         proj_f32mfma = {"dtype": "f32 MFMA (32x32x2) projection GEMM instead of the six-product bf16 form",
                         "value": args.chunks * n4 / dt4, "unit": "frame-chunks/s", "steps": n4, "ms_per_step": 1e3 * dt4 / n4,
-                        "max_abs_diff_vs_default": float((ctx4 - ctx).abs().max())}
+                        "max_abs_diff_vs_default": float((ctx4 - ctx).abs().max()), "draw_flips": draw_flips(eng4, k)}
         del eng4, ctx4
 
     # ---- secondary line (N = 1): the optional bf16 producer layout of the frame tokens (infv_ltm_set_token_dtype; half the
@@ -500,7 +605,7 @@ def main():
         dt3 = time.perf_counter() - t1
         bf16_tokens = {"dtype": "f32 arithmetic on bf16-rounded frame tokens", "value": args.chunks * n3 / dt3,
                        "unit": "frame-chunks/s", "steps": n3, "ms_per_step": 1e3 * dt3 / n3,
-                       "max_abs_diff_vs_f32_tokens": float((ctx3 - ctx).abs().max())}
+                       "max_abs_diff_vs_f32_tokens": float((ctx3 - ctx).abs().max()), "draw_flips": draw_flips(eng3, k16)}
         del eng3, ctx3, k16
 
     # ---- one multi-GPU shard on this GPU: a 256-chunk consolidate_video including the packing AND the collective: a
@@ -567,8 +672,18 @@ def main():
         "bytes_per_full_launch": nb * BYTES_POOL_PER_CHUNK,
         "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
         "kernel_ms_per_pass": {name: round(ms, 3) for name, (n, ms) in prof.items()},
-        "mfma_busy_pct": pmc_mfma_busy(), "mfma_busy_from_committed_profile": True,
+        "mfma_busy_pct": pmc_mfma_busy(args.batch_chunks), "mfma_busy_from_committed_profile": True,
     }
+    fabric = pmc_fabric_bytes_per_chunk(args.batch_chunks)
+    if fabric is not None:
+        cps = args.chunks * args.steps / elapsed / world            # chunks/s of ONE GPU
+        roofline["fabric_bytes_per_chunk"] = fabric
+        # the honest ceiling: what the memory system really moved per chunk (PMC) against what a streaming kernel can reach
+        roofline["frac_of_achievable"] = {"low": cps * fabric["low"] / 1e9 / HBM_ACHIEVABLE_GBS,
+                                          "high": cps * fabric["high"] / 1e9 / HBM_ACHIEVABLE_GBS,
+                                          "achievable_gbs": HBM_ACHIEVABLE_GBS,
+                                          "note": "chunks/s x fabric_bytes_per_chunk / 6.29 TB/s; whole_path_frac uses the section-8d formula "
+                                                  "(39.7 MB/chunk incl. L2-resident weights / B / scores) against the 8 TB/s spec peak"}
 
     # ---- secondary leg (rank 0, N = 1): the same chunk shape through the whole video Q-former (encode_video
     #      counterpart: short-term cross-attention + LTM + merge + query FFN + llama_proj), per-chunk calls ----
@@ -583,15 +698,19 @@ def main():
         for c in range(2):
             model.encode_frames(k[c % c_local].unsqueeze(0), new_video=(c == 0), u=uu[c])
         torch.cuda.synchronize()
+        from infinite_video_amd import _lib as _libmod
+        launches0 = int(_libmod.load().infv_ltm_launch_count())
         t1 = time.perf_counter()
         for c in range(n_enc):
             model.encode_frames(k[c % c_local].unsqueeze(0), new_video=False, u=uu[2 + c])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        launches_per_chunk = (int(_libmod.load().infv_ltm_launch_count()) - launches0) / n_enc
         flop = L * 2 * (2 * H * Q * D * T * P)                       # two [H*Q x d x T*P] contractions per layer
         encode_video = {"what": "per-chunk encode_video counterpart (2-layer video Q-former + LTM + llama_proj), alpha=0.9",
                         "dtype": "f32 (short-term attention contractions as 3 bf16 MFMA products, ~1e-5 relative; LTM exact f32)",
                         "chunks_per_s": n_enc / dt, "ms_per_chunk": 1e3 * dt / n_enc, "chunks": n_enc,
+                        "launches_per_chunk": launches_per_chunk,
                         "short_attention_gflop_per_chunk": flop / 1e9,
                         "short_attention_tflops_over_whole_chunk_time": flop * n_enc / dt / 1e12}
         # the same model, layer-major over a whole video (infv_vqf_encode_video: frame tokens read once per chunk)
@@ -627,6 +746,11 @@ def main():
         encode_video["exact_f32"] = {"dtype": "f32", "ms_per_chunk": 1e3 * dt / n_enc, "layer_major_ms_per_chunk": 1e3 * dt_lm / n_lm}
         del model
 
+    # ---- the drop-in operator (what the unchanged reference drivers call, Qformer.py:216-223): LongTermAttention.forward per call ----
+    module_forward = None
+    if rank == 0 and world == 1 and not args.no_encode_video:
+        module_forward = module_forward_us(dev, k)
+
     if rank == 0:
         value = args.chunks * args.steps / elapsed
         v_split = os.environ.get("INFV_VPROJ_SPLIT", "0") not in ("", "0")
@@ -640,6 +764,10 @@ def main():
             # three-piece bf16 splits (8 + 8 + 8 significand bits) -- six partial products, each exact, accumulated in f32 on the
             # bf16 MFMA pipe: error against f64 at or below the f32-MFMA GEMM's (tests/test_ltm_gpu.py), same goldens, same drawn
             # bins.  INFV_PROJ_X6=0 runs that GEMM as f32 MFMAs instead: timed below as secondary_proj_f32_mfma.
+            "dtype_detail": {"tokens": "f32", "pooling": "f32", "state_and_scores": "f32", "draw": "f32 cdf vs f64 uniforms (torch CPU semantics)",
+                             "projection_gemm": ("f32 MFMA" if os.environ.get("INFV_PROJ_X6", "") == "0" else
+                                                 "bf16x3-split operands (exact 24-bit), 6 MFMA products, f32 accumulate"),
+                             "value_projection": "bf16x3 (3 products)" if v_split else "same GEMM as the scores"},
             "dtype_note": ("projection GEMM: f32 MFMA (INFV_PROJ_X6=0)" if os.environ.get("INFV_PROJ_X6", "") == "0" else
                            "projection GEMM: f32 operands as exact 3-piece bf16 splits, 6 MFMA products, f32 accumulation (f32-accurate)"),
             "config": {"workload": f"{args.chunks}-chunk synthetic video, max_int=256 frames x 32 tokens x 768, "
@@ -664,7 +792,18 @@ def main():
             out["shard256_ms"] = shard256_ms
             out["shard256_includes_rccl_all_gather"] = shard256_rccl
             # what the 1 -> 8 GPU curve can be at best: the whole video on one GPU against one 256-chunk shard (+ its all-gather)
-            out["predicted_speedup_8"] = (1e3 * elapsed / args.steps) / shard256_ms if world == 1 else None
+            # the world-of-one collective inside shard256_ms is a no-op; an 8-rank all-gather of 1.77 MB per rank is not.  It cannot be
+            # measured on one GPU (two ranks cannot share a device under RCCL), so the prediction carries a stated ASSUMPTION:
+            # RCCL small-message latency (~20 us for a one-node all-gather launch + ring set-up) + 7 ring steps x 1.77 MB at ~64 GB/s per
+            # link direction (xGMI: 7 links x ~153 GB/s bidirectional per GPU; ring collectives are per-link bound)
+            payload_mb = 4.0 * (L * N * D + L * 127 + L * Q * DM + 1) / 1e6
+            allgather_assumed = 0.020 + 7 * payload_mb / 64.0e3 * 1e3
+            out["allgather_payload_mb_per_rank"] = payload_mb
+            out["allgather_ms_assumed_8"] = allgather_assumed
+            out["allgather_ms_assumed_8_note"] = ("assumed, not measured (one GPU): 20 us RCCL launch/latency + 7 ring steps of the "
+                                                  "per-rank payload at 64 GB/s per xGMI link direction")
+            out["predicted_speedup_8"] = (1e3 * elapsed / args.steps) / (shard256_ms + allgather_assumed) if world == 1 else None
+            out["predicted_speedup_8_without_allgather"] = (1e3 * elapsed / args.steps) / shard256_ms if world == 1 else None
         if vsplit is not None:
             out["secondary_vproj_bf16x3"] = vsplit
         if proj_f32mfma is not None:
@@ -673,6 +812,9 @@ def main():
             out["secondary_bf16_tokens"] = bf16_tokens
         if encode_video is not None:
             out["encode_video"] = encode_video
+        if module_forward is not None:
+            out["forward_us"] = module_forward["end_to_end_us"]
+            out["module_forward"] = module_forward
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_closed_form"] = cpu_baselines(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

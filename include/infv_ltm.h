@@ -294,6 +294,9 @@ typedef enum {
 } infv_kernel;
 int infv_ltm_profile_enable(infv_ltm_handle h, int32_t on);
 int infv_ltm_profile_read(infv_ltm_handle h, int32_t kernel, int64_t* launches, double* total_ms);
+/* Kernel launches this library has issued in this process so far (every handle, both headers' entry points): a
+ * benchmark reads it before and after a call to state "launches per chunk".  Host-side counter, no device work. */
+int64_t infv_ltm_launch_count(void);
 
 #ifdef __cplusplus
 }

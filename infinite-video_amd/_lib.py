@@ -141,6 +141,7 @@ _SIGNATURES = {
     "infv_ltm_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "infv_ltm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "infv_ltm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "infv_ltm_launch_count": (C.c_int64, []),
     # include/infv_vqf.h
     "infv_vqf_create": (C.c_int, [C.POINTER(VqfConfig), C.POINTER(C.c_void_p)]),
     "infv_vqf_destroy": (C.c_int, [C.c_void_p]),

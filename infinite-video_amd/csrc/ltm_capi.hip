@@ -18,6 +18,7 @@ using namespace infv;
 
 namespace infv {
 thread_local char g_err[512] = "";
+std::atomic<long long> g_kernel_launches{0};
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -163,7 +164,7 @@ struct infv_ltm_s {
     DeviceBuf crit_ring, tabb_ring;              // chain_batch3_kernel -> alpha_rows2_kernel: point scores, drawn-bin tables
     int ring = 0;
     hipStream_t ucs = nullptr;          // stream of the UC kernels (state update + read-out of a sub-batch)
-    hipStream_t chain_s = nullptr;      // CU-mask experiment: role S's own (masked) stream, else nullptr
+    hipStream_t chain_s = nullptr;      // role S's own stream (highest priority: a hardware queue it shares with no worker stream), where the call-long launch lives
     hipEvent_t ev_s[kPSets] = {}, ev_uc[kPSets] = {};
     DeviceBuf sync_words;              // [0..7] arrival counters per layer
     // error word of the persistent chain kernel: pinned host memory mapped into the device, so a time-out is
@@ -186,6 +187,10 @@ struct infv_ltm_s {
     DeviceBuf uf_all;                  // a consolidate call's Gibbs uniforms as fp32 round-ups [n_chunks][L][S] (chain_batch3_kernel's search)
     DeviceBuf step_tab;                // per-call path: resolved gather table of the step [L][N][tabw] (written by the draw plane of step_project)
     DeviceBuf psi_Y, psi_E, psi_Eg, psi_alpha;   // general-psi step: resampled rows, edge scores, grid scores / probabilities, read-out weights
+    DeviceBuf call_flags;              // call-long role S: [0] sub-batches projected (GEMM stream -> role S), [64] workgroup x sub-batch completions (role S -> UC stream); words 256 B apart
+    DeviceBuf call_stats;              // call-long role S: [0] ticks (100 MHz) workgroup 0 waited for projections, [1] how many sub-batches it waited for
+    hipEvent_t ev_chain = nullptr;     // the call-long role-S launch has finished (recorded on its stream)
+    std::mutex* issue_mu = nullptr;    // the device's consolidate-issue lock (SharedStreams::issue)
     DeviceBuf mbox;                    // chain_batch3_kernel: mailboxes of role S's exchange + placement handshake (chain_mailbox_bytes)
     int mbox_G = 0;                    // workgroups per layer the mailboxes are laid out for
     int sc = 0;
@@ -197,12 +202,14 @@ struct infv_ltm_s {
         if (side) (void)hipStreamSynchronize(side);
         if (ucs) (void)hipStreamSynchronize(ucs);
         if (pools) (void)hipStreamSynchronize(pools);
+        if (chain_s) (void)hipStreamSynchronize(chain_s);
         for (int i = 0; i < kPSets; ++i) if (ev_pool[i]) (void)hipEventDestroy(ev_pool[i]);
         for (int i = 0; i < kRSets; ++i) if (ev_r[i]) (void)hipEventDestroy(ev_r[i]);
         for (int i = 0; i < kPSets; ++i) { if (ev_s[i]) (void)hipEventDestroy(ev_s[i]); if (ev_uc[i]) (void)hipEventDestroy(ev_uc[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_q) (void)hipEventDestroy(ev_q);
+        if (ev_chain) (void)hipEventDestroy(ev_chain);
         for (int i = 0; i < kPSets; ++i) { if (ev_p[i]) (void)hipEventDestroy(ev_p[i]); }
         if (err_host) (void)hipHostFree(err_host);
     }
@@ -471,6 +478,7 @@ int project_chunks(infv_ltm_handle h, const Plan& plan, bool inf, const float* k
 extern "C" {
 
 int infv_ltm_abi_version(void) { return INFV_LTM_ABI_VERSION; }
+int64_t infv_ltm_launch_count(void) { return (int64_t)::infv::g_kernel_launches.load(std::memory_order_relaxed); }
 const char* infv_ltm_last_error(void) { return g_err; }
 
 int infv_ltm_create(const infv_ltm_config* cfg, infv_ltm_handle* out) {
@@ -881,11 +889,27 @@ struct FastPipe {
         return INFV_OK;
     }
 
+    // role S of the WHOLE call in one launch: `n` steps in `n_batches` sub-batches of `sub` (the last may be shorter) whose S'new
+    // rows arrive in workspace set (sub-batch % n_sets)
+    struct CallLong { int sub, n_batches; const float* const* sets; int n_sets; int sk_last; long ss_last; };
+    int launch_s_call(int n, int sub, int n_batches, const float* const* sets, int n_sets, int sk_main, long ss_main, int sk_last, long ss_last,
+                      const double* u, const float* uf) {
+        const CallLong cl{sub, n_batches, sets, n_sets, sk_last, ss_last};
+        return launch_s_batch(n, sets[0], sk_main, ss_main, u, uf, &cl);
+    }
+
     // role S of `n` consecutive infinite-memory chunks in one persistent launch
-    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u, const float* uf) {
+    int launch_s_batch(int n, const float* Snew, int sk, long ss, const double* u, const float* uf, const CallLong* cl = nullptr) {
         static int prev_n = 0;                     // (experiments: steps of the previous launch, for the stamps' average)
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
+        if (cl != nullptr) {
+            b.ready = h->call_flags.as<unsigned int>(); b.done = h->call_flags.as<unsigned int>() + 64;
+            b.call_sub = cl->sub; b.call_batches = cl->n_batches; b.call_sets = cl->n_sets;
+            for (int i = 0; i < cl->n_sets && i < kCallSets; ++i) b.snew_set[i] = cl->sets[i];
+            b.sk_last = cl->sk_last; b.ss_last = cl->ss_last;
+            b.call_stats = h->call_stats.as<long long>();
+        }
         const int QS = chain_s_tiles(Q);
         b.N = h->N; b.H = h->H; b.Q = Q; b.QS = QS; b.L = h->L; b.S = h->S;
         b.st = plan.sticky();
@@ -1100,9 +1124,10 @@ int batch_scores(infv_ltm_handle h, const Operator& op, int n_chunks, const floa
 // the first one's and its pipeline ran 12 % slower (107 k against 120 k chunks/s for the second engine of bench.py).
 // Handles are not re-entrant and their calls are issued from one host thread at a time, so FIFO order within a shared
 // stream is the order the host issued the work in; cross-stream dependencies are events, as before.
-struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr, chain = nullptr; };   // chain: CU-mask experiment only
+struct SharedStreams { hipStream_t side = nullptr, pools = nullptr, ucs = nullptr, chain = nullptr; std::mutex issue; };   // issue: one consolidate call enqueues at a time
 // experiment INFV_CU_MASK=K: the first K CUs (in the runtime's CU-mask bit order) belong to role S alone -- its launches go to a
 // stream masked to them, the three worker streams are masked to the rest.  0 = no masks (default).
+bool host_serial() { static const bool v = exp_env("INFV_SERIAL") != nullptr; return v; }   // timing experiments: the host synchronises the streams (no overlap)
 int cu_mask_k() { static const int k = [] { const char* e = exp_env("INFV_CU_MASK"); return e ? atoi(e) : 0; }(); return k; }
 int shared_streams(int dev, SharedStreams** out) {
     static std::mutex mu;
@@ -1130,6 +1155,10 @@ int shared_streams(int dev, SharedStreams** out) {
             *out = &p;
             return INFV_OK;
         }
+        // Role S's stream: the call-long launch spin-waits on work of the three worker streams, so it must not sit in front of them
+        // in a hardware queue.  The runtime keeps separate queues per priority level: highest priority for role S alone, normal
+        // for the UC stream, lowest for pooling and GEMM.
+        HIP_TRY(hipStreamCreateWithPriority(&p.chain, hipStreamNonBlocking, hi));
         HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio_ucs));
         HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio_pool));
         HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio_side));   // last: marks the set complete
@@ -1171,6 +1200,11 @@ int ensure_side_stream(infv_ltm_handle h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
+    HIP_TRY(h->call_flags.reserve(512));
+    HIP_TRY(h->call_stats.reserve(64));
+    HIP_TRY(hipMemset(h->call_stats.p, 0, 64));
+    h->issue_mu = &sh->issue;
     h->side = sh->side;                                       // last: h->side != nullptr means "streams and events exist"
     return INFV_OK;
 }
@@ -1212,6 +1246,9 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         return INFV_OK;
     }
     if (int rc = ensure_side_stream(h)) return rc;
+    // One call enqueues at a time per device: the worker streams are shared by every handle, and a call-long role-S launch
+    // spin-waits on work that must not end up behind another call's hand-off kernels in a shared stream.
+    std::lock_guard<std::mutex> issue_lock(*h->issue_mu);
     // Padding LDS caps the pooling kernel's occupancy at ONE 512-thread workgroup (84 KB: two do not fit, one leaves room for
     // a 74 KB workgroup of the loader-wave GEMM) per CU, so a role-S workgroup
     // always finds LDS and wave slots and the pool's bytes in flight stay bounded.  The GEMMs carry no padding any more
@@ -1224,6 +1261,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
     HIP_TRY(hipEventRecord(h->ev_start, stream));
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
+    HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));                      // call-long role S: projected / completed counts restart with the call
     {   // rings of role S's per-chunk outputs (sized for this call's Q)
         const size_t need_a = (size_t)h->ring * pipe.alpha_slot() * sizeof(float);
         if (need_a > h->alpha_ring.bytes) {
@@ -1384,6 +1422,53 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             for (int i = 0; i < kRSets; ++i) HIP_TRY(h->R_ws[i].reserve(needR));
         }
     }
+    // ---- ONE role-S launch for the whole call (round 5).  It goes out FIRST -- before any pooling, GEMM or UC launch of the call,
+    // while its CUs are free: 24 workgroups per layer on one XCD each, where the step's exchange stays in that XCD's L2 -- and
+    // stays resident to the call's last step.  Sub-batches reach it through `ready` (raised behind each projection GEMM), it
+    // hands them on through `done` (flag_wait_kernel holds the UC stream).  Its ring slots and workspace sets need no wait of
+    // their own: the GEMM of sub-batch b is itself ordered behind the UC kernel of sub-batch b - kPSets.
+    const long call_slot0 = pipe.counter;                     // ring slot of the call-long launch's first step
+    const int call_wgs = chain_batch_blocks(h->H, Q, h->L, 1, plan->sticky().points_ok, plan->inf.rows, h->S);   // role-S workgroups that count a sub-batch in
+    const bool use_call = persistent && uf != nullptr && chain_call_long() && n_batches > 0 && h->chain_s != nullptr && cu_mask_k() == 0 &&
+                          !(sub_env <= 0 && n_chunks < 768 && ramp_env > 0) && kPSets <= kCallSets && !host_serial() && !(skip_mask() & 8);
+    const int v_cols_all = h->L * h->dm;
+    auto predict_split = [&](int nb, int* sk, long* ss) {       // the split-K form project_chunks_fast will choose for a sub-batch of nb chunks
+        const long M = (long)nb * plan->inf.rows;
+        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
+        const bool defer = h->vproj_on_uc(n_chunks);
+        if (skip_mask() & 2) *sk = project_splitk((int)M, h->d);
+        else if (defer && M >= 1024) *sk = 1;
+        else if (h->proj_x6 && h->w3_valid && M >= 1024 && h->d % 32 == 0 && !defer) *sk = 1;
+        else *sk = project_splitk((int)M, h->d);
+        *ss = M * ld;
+    };
+    if (use_call) {
+        // every workspace the loop would grow (a growth synchronises the device: fatal beside a kernel that waits for the loop's work)
+        const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
+        size_t needP = 0;
+        for (int b = 0; b < n_batches; ++b) {
+            int c0, nb; batch_range(b, &c0, &nb);
+            const size_t M = (size_t)nb * rows;
+            const size_t np = M * ld * sizeof(float) * (M < 1024 ? 8 : 1);
+            if (np > needP) needP = np;
+        }
+        const size_t need3 = (size_t)(h->maxC > sub ? h->maxC : sub) * rows * h->d * sizeof(__bf16);
+        const size_t szW = (size_t)v_cols_all * h->d * 2, szR = (size_t)(h->maxC > sub ? h->maxC : sub) * rows * h->d * 2;
+        bool grow = false;
+        for (int i = 0; i < kPSets; ++i) grow = grow || needP > h->P_ws[i].bytes;
+        if (h->proj_x6) for (int i = 0; i < 3; ++i) grow = grow || need3 > h->r3[i].bytes;
+        if (h->v_split) grow = grow || szW > h->wv_hi.bytes || szR > h->R_hi.bytes;
+        if (grow) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < kPSets; ++i) HIP_TRY(h->P_ws[i].reserve(needP));
+            if (h->proj_x6) for (int i = 0; i < 3; ++i) HIP_TRY(h->r3[i].reserve(need3));
+            if (h->v_split) {
+                HIP_TRY(h->wv_hi.reserve(szW)); HIP_TRY(h->wv_lo.reserve(szW));
+                HIP_TRY(h->R_hi.reserve(szR)); HIP_TRY(h->R_lo.reserve(szR));
+                h->wv_split_valid = false;
+            }
+        }
+    }
     auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
         if (kbar_pre) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
@@ -1419,10 +1504,31 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                          h->vproj_on_uc(n_chunks), rset, use_pr)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
+        if (use_call) {
+            int sk = 1; long ss = 0;
+            predict_split(nb, &sk, &ss);
+            if (sk != sks[b] || ss != sss[b]) return fail(INFV_ERR_STATE, "consolidate: sub-batch %d was projected in a split-K form the resident chain kernel was not told about", b);
+            HIP_TRY(launch_flag_set(h->call_flags.as<unsigned int>(), (unsigned int)(b + 1), side));
+        }
         return INFV_OK;
     };
     if (n_batches > 0) {
         HIP_TRY(hipEventRecord(h->ev_in, stream));            // inputs, cq and the first chunk's set are ordered before
+        if (use_call) {
+            int sk_main = 1, sk_last = 1; long ss_main = 0, ss_last = 0;
+            int c0l, nbl; batch_range(n_batches - 1, &c0l, &nbl);
+            predict_split(sub, &sk_main, &ss_main);
+            predict_split(nbl, &sk_last, &ss_last);
+            if (n_batches == 1) { sk_main = sk_last; ss_main = ss_last; }
+            HIP_TRY(hipStreamWaitEvent(h->chain_s, h->ev_in, 0));
+            pipe.stream = h->chain_s;
+            const float* sets[kCallSets] = {};
+            for (int i = 0; i < kPSets; ++i) sets[i] = h->P_ws[i].as<float>() + (size_t)v_cols_all;
+            if (int rc = pipe.launch_s_call(n_chunks - first_c, sub, n_batches, sets, kPSets, sk_main, ss_main, sk_last, ss_last,
+                                            u + (size_t)first_c * chunk_u, uf + (size_t)first_c * chunk_u)) return rc;
+            HIP_TRY(hipEventRecord(h->ev_chain, h->chain_s));
+            pipe.stream = stream;
+        }
         HIP_TRY(hipStreamWaitEvent(side, h->ev_q, 0));
         if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_start, 0));
         if (int rc = stage_pool(0)) return rc;
@@ -1441,7 +1547,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // (CU-mask experiment: role S's launches go to the stream that owns the reserved CUs; it starts behind everything the caller's
     //  stream has done so far and the caller's stream picks up behind it at the join)
     hipStream_t ls = stream;
-    if (h->chain_s != nullptr && persistent && n_batches > 0) {
+    if (h->chain_s != nullptr && cu_mask_k() > 0 && persistent && n_batches > 0) {
         ls = h->chain_s;
         HIP_TRY(hipStreamWaitEvent(ls, h->ev_in, 0));
         pipe.stream = ls;
@@ -1450,13 +1556,19 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         if (host_trace) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % kPSets, rset = b % kRSets;
-        HIP_TRY(hipStreamWaitEvent(ls, h->ev_p[set], 0));
-        // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
-        if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
-        const long slot0 = pipe.counter;
-        static const bool serial = exp_env("INFV_SERIAL") != nullptr;   // timing experiments: no overlap between the streams
+        if (!use_call) {
+            HIP_TRY(hipStreamWaitEvent(ls, h->ev_p[set], 0));
+            // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
+            if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
+        }
+        const long slot0 = use_call ? call_slot0 + (long)(c0 - first_c) : pipe.counter;
+        const bool serial = host_serial();                              // timing experiments: no overlap between the streams
         if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
-        if (persistent) {
+        if (use_call) {
+            // role S is resident: only the chunk-parallel stage of the next sub-batch goes out here
+            if (b + 1 < n_batches)
+                if (int rc = stage_parallel(b + 1)) return rc;
+        } else if (persistent) {
             // the chunk-parallel stage of the next batch goes out first so it overlaps this batch's chain
             if (b + 1 < n_batches)
                 if (int rc = stage_parallel(b + 1)) return rc;
@@ -1512,8 +1624,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
-        HIP_TRY(hipEventRecord(h->ev_s[set], ls));
-        HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
+        if (use_call) {
+            // the UC stream holds until every role-S workgroup has written sub-batch b's steps back
+            HIP_TRY(launch_flag_wait(h->call_flags.as<unsigned int>() + 64, (unsigned int)(b + 1) * (unsigned int)call_wgs, h->spin_limit, h->err_dev, ucs));
+            pipe.last_snew = h->P_ws[set].as<float>() + (size_t)v_cols_all; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
+        } else {
+            HIP_TRY(hipEventRecord(h->ev_s[set], ls));
+            HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
+        }
         if (persistent)
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[rset].as<float>(), h->P_ws[set].as<float>(),
@@ -1535,6 +1653,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         HIP_TRY(hipStreamWaitEvent(stream, h->ev_in, 0));
         pipe.stream = stream;
     }
+    if (use_call) HIP_TRY(hipStreamWaitEvent(stream, h->ev_chain, 0));
     for (int i = 0; i < kPSets; ++i)
         if (uc_pending[i]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[i], 0));
     if (pipe.counter > 0) {

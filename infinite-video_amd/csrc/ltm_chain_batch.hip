@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch_kernel(ChainBatchArgs a) {
 constexpr int kB2Ld = 4;                  // float4 pieces of the new-row score tile the loader holds per lane (2 * rows <= 64 * kB2Ld)
 constexpr int kScPitch = kBins + 4;
 typedef unsigned int uintx4_t __attribute__((ext_vector_type(4)));
+__device__ inline floatx4 as_floatx4(uintx4_t v) { return __builtin_bit_cast(floatx4, v); }
 
 // LDS written by some lanes of this wave is read by others: release / barrier / acquire at wavefront scope (no instruction
 // beyond the waits the hardware needs anyway; it pins the compiler's ordering across divergent code)
@@ -398,7 +399,6 @@ __device__ inline float mailbox_total(const unsigned long long* mbox, int L, int
     return t;
 }
 
-#ifdef INFV_EXPERIMENTS
 // part[l][0][j] = total of bin j of the step whose mailboxes have parity `parity` (fast path -> per-call path hand-over)
 __global__ void mailbox_to_part_kernel(const unsigned long long* __restrict__ mbox, int L, int G, int parity, int parts_pitch, float* __restrict__ part) {
     const int l = blockIdx.x, j = threadIdx.x;
@@ -409,9 +409,6 @@ hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, 
     hipLaunchKernelGGL(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
     return hipGetLastError();
 }
-#else
-hipError_t launch_mailbox_to_part(const unsigned long long*, int, int, int, int, float*, hipStream_t) { return hipErrorNotSupported; }
-#endif
 
 __device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 
@@ -531,19 +528,46 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     // row e4 / PPR, piece e4 % PPR;   uniforms: S floats -> two float4 per lane
     struct LdSet { floatx4 sn[kB2Ld]; floatx4 u[2]; };
     LdSet ldA, ldB;
+    // Call-long launch: step i belongs to sub-batch i / call_sub, whose S'new rows sit in workspace set (sub-batch % call_sets) once
+    // the GEMM stream has raised `ready` past it.  The rows were written by ANOTHER kernel while this one was running, possibly
+    // over lines this XCD's L2 still holds from the set's previous use: every load of them is an sc1 load (served by the
+    // memory side; the producer's end-of-kernel release has written them back before its flag kernel ran).
+    const bool call_long = a.ready != nullptr;
+    unsigned int ready_seen = 0;                                              // (loader wave) sub-batches known to be projected
     auto ld_request = [&](int i, LdSet& r) {
-        const float* sb = a.Snew + (long)i * tile_snew + tile;
-        const int splitk = a.snew_splitk;
-        const long split_stride = a.snew_split_stride;
+        const float* sb;
+        int splitk = a.snew_splitk;
+        long split_stride = a.snew_split_stride;
+        if (call_long) {
+            const int cb = i / a.call_sub, li = i - cb * a.call_sub;
+            if ((unsigned int)cb >= ready_seen) {
+                long long t0 = 0;
+                int spins = 0;
+                for (;;) {
+                    const unsigned int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (v > (unsigned int)cb) { ready_seen = v; break; }
+                    if (spins == 0 && a.call_stats != nullptr && b == 0) t0 = wall_clock64();
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ready_seen = 0xffffffffu; break; }   // (failed: no further waits)
+                }
+                if (spins > 0 && a.call_stats != nullptr && b == 0 && lane == 0) { a.call_stats[0] += wall_clock64() - t0; a.call_stats[1] += 1; }
+            }
+            sb = a.snew_set[cb % a.call_sets] + (long)li * tile_snew + tile;
+            if (cb == a.call_batches - 1) { splitk = a.sk_last; split_stride = a.ss_last; }
+        } else {
+            sb = a.Snew + (long)i * tile_snew + tile;
+        }
+        __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int k = 0; k < kB2Ld; ++k) {
             const int e4 = lane + 64 * k;
             const int nr = e4 / PPR, hf = e4 % PPR;
             floatx4 v = {0.f, 0.f, 0.f, 0.f};
             if (nr < rows && 4 * hf < valid) {
-                const float* src = sb + (long)nr * a.snew_ld + 4 * hf;
-                v = *reinterpret_cast<const floatx4*>(src);
-                for (int x = 1; x < splitk; ++x) v += *reinterpret_cast<const floatx4*>(src + x * split_stride);
+                const int off = (nr * a.snew_ld + 4 * hf) * 4;
+                v = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16 /* sc1 */));
+                for (int x = 1; x < splitk; ++x)
+                    v += as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, (int)(x * split_stride * 4), 16 /* sc1 */));
             }
             r.sn[k] = v;
         }
@@ -691,6 +715,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 
     int slot_run = (int)(a.step0 % a.ring);
     const int ring_n = (int)a.ring;
+    int cb_next = call_long ? a.call_sub : 0;                              // first step of the next sub-batch (call-long launch)
+    bool sig_pending = false;                                              // (wave 6) an L2 write-back of a finished sub-batch is in flight
     const bool ovr0 = ((a.override_mask >> l) & 1u) != 0;
     // step 0 takes its totals from elsewhere than the exchange (mailboxes: also when the step before ran in a per-chunk launch)
     const bool special0 = ovr0 || a.first_from_parts || (MBOX && a.first_from_acc);
@@ -737,12 +763,23 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
             }
             __syncthreads();                                                     // barrier 0
         }
+        // call-long launch: step i opens a new sub-batch -> the steps of the one before are all published once step i-1 is
+        const bool batch_open = call_long && i > 0 && i == cb_next;
+        if (batch_open) cb_next += a.call_sub;
         if (i > 0) {
             // in the shadow of wave 0's scan: the previous step goes out, the loader asks for the inputs of step i+2
             if (loader) {
                 if (i + 2 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 2) & 1) ld_request(i + 2, ldB); else ld_request(i + 2, ldA); }
             } else if (wave != 0) {
                 publish_step(i - 1, prev_slot, acc0, acc1);
+                // hand a finished sub-batch to the UC stream.  Every publishing wave drains its stores (they are then in this XCD's
+                // L2); behind barrier 1 wave 6 starts the L2 write-back and, a step later, waits for it and counts this workgroup in.
+                if (wave == 6 && sig_pending) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the write-back issued one step ago has completed
+                    if (lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sig_pending = false;
+                }
+                if (batch_open) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         prev_slot = slot;
@@ -821,6 +858,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         }
         __syncthreads();                                                         // barrier 1
         B3STAMP(2);
+        if (batch_open && wave == 6) { asm volatile("buffer_wbl2 sc1" ::: "memory"); sig_pending = true; }
         if constexpr (!MBOX) {
             // Clear the accumulator slot of step i+1 (it held the totals of step i-2).  Wave 0 has just seen every arrival of
             // step i-1, and a workgroup arrives only after its own poll of step i-2's totals, so nobody reads the slot any more;
@@ -984,6 +1022,16 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         // read by waves 1 and 6 behind barrier 2 of step i+1.
     }
     if (a.n_steps > 0 && wave != 0 && !loader) publish_step(a.n_steps - 1, prev_slot, acc0, acc1);
+    if (call_long) {
+        // the last sub-batch (and a write-back still in flight): drain, write back, count this workgroup in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 6 && sig_pending && lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (wave == 6) {
+            asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // ---- hand the point scores to the next launch (its set-up reads them back through pb) ----
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
@@ -1346,20 +1394,27 @@ bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
            n_blocks <= 384 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
 }
 
-// Variants of the persistent role S.  The shipped library launches ONE: 16-row tiles, atomics exchange.  The experiments build
-// can select 8-row tiles (INFV_CHAIN_RPW=1) and the mailbox exchange inside one XCD's L2 (INFV_CHAIN_XCD=1) for A/B runs.
+// Variants of the persistent role S.  The shipped library launches ONE: 16-row tiles, mailbox exchange inside one XCD's L2, one
+// launch per call (round 5).  The experiments build can select 8-row tiles (INFV_CHAIN_RPW=1), the atomics exchange of rounds
+// 1-4 (INFV_CHAIN_XCD=0) and one launch per sub-batch (INFV_CHAIN_CALL=0) for A/B runs.
 constexpr int kDefRpw = 2;
 typedef void (*Chain3Fn)(ChainBatchArgs);
 bool chain_batch3_mailboxes() {
-    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_XCD"); return e && atoi(e) != 0; }();
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_XCD"); return !e || atoi(e) != 0; }();
+    return want;
+}
+bool chain_call_long() {
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_CALL"); return !e || atoi(e) != 0; }();
     return want;
 }
 static Chain3Fn chain3_fn(int rpw) {
 #ifdef INFV_EXPERIMENTS
     if (chain_batch3_mailboxes()) return rpw == 1 ? chain_batch3_kernel<1, true> : chain_batch3_kernel<2, true>;
-    if (rpw == 1) return chain_batch3_kernel<1, false>;
+    return rpw == 1 ? chain_batch3_kernel<1, false> : chain_batch3_kernel<2, false>;
+#else
+    (void)rpw;
+    return chain_batch3_kernel<2, true>;
 #endif
-    return chain_batch3_kernel<2, false>;
 }
 
 static hipError_t chain_batch_attr() {
@@ -1435,6 +1490,31 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
     if (e != hipSuccess) return false;
     const int safe = per_cu > 1 ? per_cu - 1 : per_cu;
     return (long)safe * cus >= n_blocks;
+}
+
+// ---- hand-offs of a call-long role-S launch.  GEMM stream -> role S: flag_set_kernel runs behind a sub-batch's projection GEMM (whose
+// end-of-kernel release has written its output back) and raises the count role S's loaders poll.  Role S -> UC stream:
+// flag_wait_kernel holds the UC stream until every role-S workgroup has counted the sub-batch in (ChainBatchArgs.done); the
+// kernels behind it start with the usual launch-time acquire.  One wave each; the wait is bounded and latches the error word.
+__global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error) {
+    if (threadIdx.x != 0) return;
+    for (int spins = 0;; ++spins) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        __builtin_amdgcn_s_sleep(32);
+        if ((spins & 1023) == 1023 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;   // the chain has already failed
+        if (spins > spin_limit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    }
+}
+hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream) {
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, stream, flag, value);
+    return hipGetLastError();
+}
+hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream) {
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
+    return hipGetLastError();
 }
 
 hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {

@@ -17,9 +17,12 @@ __host__ __device__ inline int acc_word(int j) { return j < 64 ? 2 * j : 2 * (j 
 // A ring slot holds, per layer, kAccShards replicas of those 128 words ([L][kAccShards][128]); the total of a bin is the
 // (integer) sum over the replicas, whoever clears a slot clears all of them.  Round 4 measured 2-8 replicas for the
 // persistent role S (adds to one word serialise at the memory side): 1.77-1.95 us per exchange against 1.90 with one --
-// every cross-XCD exchange costs that much -- so role S now exchanges through mailboxes inside one XCD's L2
-// (chain_batch3_kernel) and the accumulators, used by the per-chunk kernels only, are back to one replica.
+// every cross-XCD exchange costs that much, replicas buy nothing -- so the ring is back to one replica.  Who uses it: the
+// per-chunk kernels, and chain_batch3_kernel<., false> (one launch per sub-batch, atomics exchange).  The call-long launch
+// (chain_batch3_kernel<., true>, round 5) exchanges through mailboxes inside one XCD's L2 instead and only reads the
+// accumulators when the step before it ran in a per-chunk launch.
 constexpr int kAccShards = 1;
+constexpr int kCallSets = 8;               // most rotating projection workspace sets a call-long role-S launch can address (kPSets <= this)
 
 // Device-side view of one ridge operator (first-chunk or infinite-memory) of a plan.
 struct OperatorView {
@@ -181,12 +184,26 @@ struct ChainBatchArgs {
     const float* cq; const float* w; float w_out;
     long long* dbg;                 // timing experiments: phase stamps of workgroup 0 at step 5, or nullptr
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
+    // ---- call-long launch of chain_batch3_kernel: ONE launch per infv_ltm_consolidate, resident from the call's first sub-batch to its
+    // last (ready == nullptr: one launch per sub-batch, Snew / snew_splitk / snew_split_stride describe that sub-batch) ----
+    const unsigned int* ready;      // sub-batches of this call whose projection GEMM is complete (flag_set_kernel on the GEMM's stream)
+    unsigned int* done;             // every workgroup adds 1 per sub-batch once the steps it published are written back (flag_wait_kernel on the UC stream polls it)
+    int call_sub;                   // steps per sub-batch (the last one may be shorter)
+    int call_batches;               // sub-batches of the launch
+    const float* snew_set[kCallSets];   // S'new origin of workspace set s; sub-batch b reads set b % call_sets
+    int call_sets;
+    int sk_last; long ss_last;      // split-K form of the LAST sub-batch's projection (all others: snew_splitk / snew_split_stride)
+    long long* call_stats;          // [0]: 100 MHz ticks workgroup 0 spent waiting for `ready`; [1]: sub-batches it had to wait for; or nullptr
 };
+// role S -> UC stream / GEMM stream -> role S hand-offs of a call-long launch (ltm_chain_batch.hip)
+hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream);
+hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream);
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
 bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch3_kernel (scores rebuilt by alpha_rows2)
 bool chain_batch3_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);   // the shape runs chain_batch3_kernel (needs ChainBatchArgs.uf)
 hipError_t launch_round_up_uniforms(const double* u, float* uf, long n, hipStream_t stream);   // uf[i] = smallest float >= u[i]
-bool chain_batch3_mailboxes();                               // experiments build, INFV_CHAIN_XCD=1: role S exchanges through mailboxes in one XCD's L2
+bool chain_batch3_mailboxes();                               // role S exchanges through mailboxes in one XCD's L2 (experiments build, INFV_CHAIN_XCD=0: memory-side atomics)
+bool chain_call_long();                                      // role S is ONE launch per consolidate call (experiments build, INFV_CHAIN_CALL=0: one per sub-batch)
 size_t chain_mailbox_bytes(int L, int G);                    // G = workgroups of a layer (chain_batch_blocks / L)
 // part[l][0][j] = total of bin j held by the mailboxes of parity `parity` (the last step of a chain_batch3 launch), same sum order as the kernel
 hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, int G, int parity, int parts_pitch, float* part, hipStream_t stream);

@@ -161,9 +161,10 @@ def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
     print(f"[timed path] {n_chunks} chunks: {flips} of {(n_chunks - 1) * L * S} draws differ between consolidate and the per-chunk chain")
     # the CPU oracle itself, both layers, teacher-forced to the call's traced bins, over the WHOLE call (then also final B
     # and last scores) -- including the 2048-chunk bench call (ring wrap of the workspace / R sets, the short 49th
-    # sub-batch with its split-K projection: all past chunk 128; about a minute of CPU); the bf16x6 variant of the
-    # 2048-chunk call keeps the first 128 chunks (three 42-chunk sub-batches)
-    n_or = n_chunks if (n_chunks <= 256 or not x6) else 128
+    # sub-batch with its own projection dispatch: all past chunk 128; about a minute of CPU) on the path bench.py times,
+    # the DEFAULT (bf16x6) projection GEMM; the legacy fp32-MFMA variant (INFV_PROJ_X6=0) of the 2048-chunk call keeps
+    # the first 128 chunks (three 42-chunk sub-batches)
+    n_or = n_chunks if (n_chunks <= 256 or x6) else 128
     worst, oflips = _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast if n_or == n_chunks else None)
     print(f"[timed path] {n_chunks} chunks vs the CPU oracle over {n_or}: max |ctx diff| {worst:.2e}, {oflips} draws differ")
 
@@ -284,9 +285,11 @@ _VARIANTS = [
     {},                                                        # the experiments build with no knob set
     {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
     {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
-    {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
+    {"INFV_CHAIN_CALL": "0"},                                  # one role-S launch per sub-batch (rounds 1-4) instead of one per call, same mailbox exchange
+    {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_CALL": "0"},           # ... with the atomics exchange: exactly round 4's role S (against the atomics baseline)
+    {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_RPW": "1"},            # 8-row chain tiles (96 workgroups) as in round 2 (atomics exchange: the totals do not depend on the tiling)
     {"INFV_PROJ_X6": "0", "INFV_VPROJ_ON_UC": "1"},            # (fp32-MFMA GEMM) V' half of the projection as its own GEMM on the UC stream
-    {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
+    {"INFV_CHAIN_XCD": "0", "INFV_PERSISTENT": "0"},           # one role-S launch per chunk (always the atomics exchange)
     {"INFV_PROJ_X6": "0", "INFV_GEMM_LW": "0"},                # (fp32-MFMA GEMM) without loader waves
     {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
     {"INFV_POOL_TID": "1"},                                    # pooling kernel with lane-id addressed loads (no vector address operand)
@@ -304,10 +307,12 @@ def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
         path = str(tmp_path / name)
         _run_child(_VARIANT_CHILD, env_add, path)
         return {k_: v for k_, v in np.load(path).items()}
-    base = {"": run({}, "base.npz"), "0": run({"INFV_PROJ_X6": "0"}, "base_f32mfma.npz")}   # shipped library: default, and the fp32-MFMA GEMM
+    base = {"": run({}, "base.npz"), "0": run({"INFV_PROJ_X6": "0"}, "base_f32mfma.npz"),   # shipped library: default, and the fp32-MFMA GEMM
+            # the atomics exchange of rounds 1-4 (exact fixed-point totals; experiments build): the baseline of the variants that use it
+            "atomics": run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "0"}, "base_atomics.npz")}
     for i, v in enumerate(_VARIANTS):
         got = run(dict(v, INFV_LTM_LIBRARY="exp"), f"v{i}.npz")
-        want = base[v.get("INFV_PROJ_X6", "")]
+        want = base["atomics" if v.get("INFV_CHAIN_XCD") == "0" else v.get("INFV_PROJ_X6", "")]
         for key in want:
             if "INFV_PERSISTENT" in v and key in ("a", "b"):
                 # one role-S launch per chunk computes the read-out weights in the chain kernel itself (a lane per box n, n + 64, ..);
@@ -317,19 +322,19 @@ def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
                 np.testing.assert_array_equal(want[key], got[key], err_msg=f"{v}: {key}")
 
 
-def test_xcd_local_mailbox_exchange_variant(dev, tmp_path):
-    """INFV_CHAIN_XCD=1 (experiments build): role S exchanges its bin masses through mailboxes inside one XCD's L2 (XCD-aware
-    grid + placement handshake, csrc/ltm_chain_batch.hip).  The totals are fp32 sums of per-workgroup row sums in a fixed order
-    instead of the exact fixed-point totals of the atomics exchange: same draws (but for a flip within rounding of a cdf
-    edge), contexts and memory equal to fp32 rounding; and the result must not depend on the placement (sc1 mailboxes when the
-    handshake finds the layer on several XCDs: forced with INFV_S_FLAGS=32) -- bit for bit."""
+def test_xcd_local_mailbox_exchange_is_placement_independent(dev, tmp_path):
+    """The shipped role S exchanges its bin masses through mailboxes inside one XCD's L2 (XCD-aware grid + placement handshake,
+    csrc/ltm_chain_batch.hip).  The totals are fp32 sums of per-workgroup row sums in a fixed order; the atomics exchange of
+    rounds 1-4 (experiments build, INFV_CHAIN_XCD=0) has exact fixed-point totals: same draws (but for a flip within rounding of
+    a cdf edge), contexts and memory equal to fp32 rounding; and the result must not depend on the placement (sc1 mailboxes
+    when the handshake finds the layer on several XCDs: forced with INFV_S_FLAGS=32) -- bit for bit."""
     def run(env_add, name):
         path = str(tmp_path / name)
         _run_child(_VARIANT_CHILD, env_add, path)
         return {k_: v for k_, v in np.load(path).items()}
-    base = run({}, "base.npz")
-    xcd = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "1"}, "xcd.npz")
-    far = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "1", "INFV_S_FLAGS": "32"}, "far.npz")
+    xcd = run({}, "xcd.npz")                                                                 # the shipped default
+    base = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "0"}, "base.npz")            # atomics exchange
+    far = run({"INFV_LTM_LIBRARY": "exp", "INFV_S_FLAGS": "32"}, "far.npz")
     for key in base:
         np.testing.assert_array_equal(xcd[key], far[key], err_msg=f"placement changed {key}")
     assert int((base["bins"] != xcd["bins"]).sum()) <= 1
