@@ -187,6 +187,8 @@ struct infv_ltm_s {
     DeviceBuf uf_all;                  // a consolidate call's Gibbs uniforms as fp32 round-ups [n_chunks][L][S] (chain_batch3_kernel's search)
     DeviceBuf step_tab;                // per-call path: resolved gather table of the step [L][N][tabw] (written by the draw plane of step_project)
     DeviceBuf psi_Y, psi_E, psi_Eg, psi_alpha;   // general-psi step: resampled rows, edge scores, grid scores / probabilities, read-out weights
+    DeviceBuf R_all, planes_all[3];    // call-long pooling launch: every new row of the call (fp32, and as three bf16 planes per sub-batch for the projection GEMM)
+    DeviceBuf pool_done;               // ... and its per-sub-batch completion counts
     DeviceBuf call_flags;              // call-long role S: [0] sub-batches projected (GEMM stream -> role S), [64] workgroup x sub-batch completions (role S -> UC stream); words 256 B apart
     DeviceBuf call_stats;              // call-long role S: [0] ticks (100 MHz) workgroup 0 waited for projections, [1] how many sub-batches it waited for
     hipEvent_t ev_chain = nullptr;     // the call-long role-S launch has finished (recorded on its stream)
@@ -904,11 +906,17 @@ struct FastPipe {
         ChainBatchArgs b;
         memset(&b, 0, sizeof(b));
         if (cl != nullptr) {
-            b.ready = h->call_flags.as<unsigned int>(); b.done = h->call_flags.as<unsigned int>() + 64;
-            b.call_sub = cl->sub; b.call_batches = cl->n_batches; b.call_sets = cl->n_sets;
-            for (int i = 0; i < cl->n_sets && i < kCallSets; ++i) b.snew_set[i] = cl->sets[i];
-            b.sk_last = cl->sk_last; b.ss_last = cl->ss_last;
-            b.call_stats = h->call_stats.as<long long>();
+            // the sub-batch description travels through device memory (a small kernel in front of the launch writes it)
+            ChainCallDesc cd;
+            memset(&cd, 0, sizeof(cd));
+            cd.ready = h->call_flags.as<unsigned int>(); cd.done = h->call_flags.as<unsigned int>() + 64;
+            cd.sub = cl->sub; cd.n_batches = cl->n_batches; cd.n_sets = cl->n_sets;
+            for (int i = 0; i < cl->n_sets && i < kCallSets; ++i) cd.snew_set[i] = cl->sets[i];
+            cd.sk_last = cl->sk_last; cd.ss_last = cl->ss_last;
+            cd.stats = h->call_stats.as<long long>();
+            ChainCallDesc* dst = reinterpret_cast<ChainCallDesc*>(h->call_flags.as<char>() + 512);
+            HIP_TRY(launch_chain_call_desc(dst, cd, stream));
+            b.call = dst; b.call_sub = cl->sub;
         }
         const int QS = chain_s_tiles(Q);
         b.N = h->N; b.H = h->H; b.Q = Q; b.QS = QS; b.L = h->L; b.S = h->S;
@@ -1059,18 +1067,21 @@ struct FastPipe {
 // [ V' projection of the row (L*dm) | its scores under the call's pre-multiplied queries (L*H*Q) ]
 int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T, int Q,
                         const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad,
-                        bool defer_values = false, int rset = -1, bool rows_done = false) {
+                        bool defer_values = false, int rset = -1, bool rows_done = false, const float* r_ext = nullptr,
+                        void* const* planes_ext = nullptr) {
     if (rset < 0) rset = set;                                 // R buffer of the sub-batch (the pooling kernel may have filled it)
+    // r_ext / planes_ext: the call-long pooling launch has written the sub-batch's rows (and their bf16 planes) elsewhere
     const Operator& op = inf ? plan.inf : plan.first;
     const long M = (long)n_chunks * op.rows;
     const int n_out = h->L * h->H * Q;
     const long ld = (long)h->L * h->dm + n_out;
     const int sk_max = 8;
     const size_t needR = (size_t)(M ? M : 1) * h->d * sizeof(float), needP = (size_t)(M ? M : 1) * ld * sk_max * sizeof(float);
-    if (needR > h->R_ws[rset].bytes || (M < 1024 ? needP : needP / sk_max) > h->P_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(h->R_ws[rset].reserve(needR));
+    if ((r_ext == nullptr && needR > h->R_ws[rset].bytes) || (M < 1024 ? needP : needP / sk_max) > h->P_ws[set].bytes) HIP_TRY(hipDeviceSynchronize());
+    if (r_ext == nullptr) HIP_TRY(h->R_ws[rset].reserve(needR));
     HIP_TRY(h->P_ws[set].reserve(M < 1024 ? needP : needP / sk_max));
-    if (!rows_done) {
+    const float* Rrows = r_ext != nullptr ? r_ext : h->R_ws[rset].as<float>();
+    if (!rows_done && r_ext == nullptr) {
         Timed t_(h->prof, INFV_KERNEL_ROWS, stream);
         HIP_TRY(launch_rows(kbar, n_chunks, T, h->d, op.view(), h->R_ws[rset].as<float>(), stream));
     }
@@ -1079,26 +1090,28 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         *splitk = project_splitk((int)M, h->d);
     } else if (defer_values && M >= 1024) {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
+        HIP_TRY(launch_project_scores((int)M, h->d, n_out, h->qt_buf.as<float>(), Rrows,
                                       h->P_ws[set].as<float>() + v_cols, (int)ld, stream, gemm_pad));
         *splitk = 1;
     } else if (h->proj_x6 && h->w3_valid && inf && M >= 1024 && h->d % 32 == 0 && !defer_values) {
         // [V'new | S'new] = R . [Wv ; q~]^T from three bf16 planes per operand (the weights' planes were made once for the call)
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
         const size_t szR = (size_t)M * h->d * sizeof(__bf16);
-        if (szR > h->r3[0].bytes) {
-            HIP_TRY(hipDeviceSynchronize());
-            for (int i = 0; i < 3; ++i) HIP_TRY(h->r3[i].reserve((size_t)h->maxC * op.rows * h->d * sizeof(__bf16) > szR ? (size_t)h->maxC * op.rows * h->d * sizeof(__bf16) : szR));
+        if (planes_ext == nullptr) {
+            if (szR > h->r3[0].bytes) {
+                HIP_TRY(hipDeviceSynchronize());
+                for (int i = 0; i < 3; ++i) HIP_TRY(h->r3[i].reserve((size_t)h->maxC * op.rows * h->d * sizeof(__bf16) > szR ? (size_t)h->maxC * op.rows * h->d * sizeof(__bf16) : szR));
+            }
+            HIP_TRY(launch_split3_rows(Rrows, h->d, M, h->d, h->r3[0].p, h->r3[1].p, h->r3[2].p, 0, M, stream));
         }
-        HIP_TRY(launch_split3_rows(h->R_ws[rset].as<float>(), h->d, M, h->d, h->r3[0].p, h->r3[1].p, h->r3[2].p, 0, M, stream));
         SplitGemm6 g{};
-        for (int i = 0; i < 3; ++i) { g.A[i] = h->r3[i].as<__bf16>(); g.B[i] = h->w3[i].as<__bf16>(); }
+        for (int i = 0; i < 3; ++i) { g.A[i] = planes_ext != nullptr ? static_cast<const __bf16*>(planes_ext[i]) : h->r3[i].as<__bf16>(); g.B[i] = h->w3[i].as<__bf16>(); }
         g.lda = h->d; g.ldb = h->d; g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.M = (int)M; g.N = (int)ld; g.K = h->d;
         HIP_TRY(launch_gemm_x6(g, stream));
         *splitk = 1;
     } else {
         Timed t_(h->prof, INFV_KERNEL_PROJECT, stream);
-        HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), h->R_ws[rset].as<float>(),
+        HIP_TRY(launch_project_fast((int)M, h->d, h->dm, h->L, n_out, pp, h->qt_buf.as<float>(), Rrows,
                                     h->P_ws[set].as<float>(), splitk, stream, gemm_pad));
     }
     *split_stride = M * ld;
@@ -1158,7 +1171,8 @@ int shared_streams(int dev, SharedStreams** out) {
         // Role S's stream: the call-long launch spin-waits on work of the three worker streams, so it must not sit in front of them
         // in a hardware queue.  The runtime keeps separate queues per priority level: highest priority for role S alone, normal
         // for the UC stream, lowest for pooling and GEMM.
-        HIP_TRY(hipStreamCreateWithPriority(&p.chain, hipStreamNonBlocking, hi));
+        static const bool own_chain_stream = [] { const char* e = exp_env("INFV_CHAIN_STREAM"); return e && atoi(e) != 0; }();
+        if (own_chain_stream) HIP_TRY(hipStreamCreateWithPriority(&p.chain, hipStreamNonBlocking, hi));
         HIP_TRY(hipStreamCreateWithPriority(&p.ucs, hipStreamNonBlocking, prio_ucs));
         HIP_TRY(hipStreamCreateWithPriority(&p.pools, hipStreamNonBlocking, prio_pool));
         HIP_TRY(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, prio_side));   // last: marks the set complete
@@ -1201,7 +1215,7 @@ int ensure_side_stream(infv_ltm_handle h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
-    HIP_TRY(h->call_flags.reserve(512));
+    HIP_TRY(h->call_flags.reserve(1024));                      // [0, 512): the two counters, [512, 1024): ChainCallDesc of the current call
     HIP_TRY(h->call_stats.reserve(64));
     HIP_TRY(hipMemset(h->call_stats.p, 0, 64));
     h->issue_mu = &sh->issue;
@@ -1259,9 +1273,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
+    {   // hand-off counters of the call-long launches restart with the call (before ev_start: the pooling stream starts behind it)
+        const size_t need_pd = ((size_t)n_chunks + 1) * sizeof(unsigned int);
+        if (need_pd > h->pool_done.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->pool_done.reserve(need_pd < 32768 ? 32768 : need_pd)); }
+        HIP_TRY(hipMemsetAsync(h->pool_done.p, 0, need_pd, stream));
+        HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));
+    }
     HIP_TRY(hipEventRecord(h->ev_start, stream));
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
-    HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));                      // call-long role S: projected / completed counts restart with the call
     {   // rings of role S's per-chunk outputs (sized for this call's Q)
         const size_t need_a = (size_t)h->ring * pipe.alpha_slot() * sizeof(float);
         if (need_a > h->alpha_ring.bytes) {
@@ -1429,8 +1448,15 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // their own: the GEMM of sub-batch b is itself ordered behind the UC kernel of sub-batch b - kPSets.
     const long call_slot0 = pipe.counter;                     // ring slot of the call-long launch's first step
     const int call_wgs = chain_batch_blocks(h->H, Q, h->L, 1, plan->sticky().points_ok, plan->inf.rows, h->S);   // role-S workgroups that count a sub-batch in
-    const bool use_call = persistent && uf != nullptr && chain_call_long() && n_batches > 0 && h->chain_s != nullptr && cu_mask_k() == 0 &&
+    hipStream_t call_stream = h->chain_s != nullptr ? h->chain_s : stream;      // where the call-long launch lives
+    const bool use_call = persistent && uf != nullptr && chain_call_long() && n_batches > 0 && cu_mask_k() == 0 &&
                           !(sub_env <= 0 && n_chunks < 768 && ramp_env > 0) && kPSets <= kCallSets && !host_serial() && !(skip_mask() & 8);
+    // ... and ONE pooling launch for the whole call: no launch boundaries on the HBM stream (with role S resident nothing but the
+    // projection GEMM still needs an empty CU), rows and their bf16 planes for the whole call in HBM (402 + 604 MB at 2048 chunks),
+    // the GEMM stream follows it through per-sub-batch completion counts
+    static const bool pool_call_env = [] { const char* e = exp_env("INFV_POOL_CALL"); return !e || atoi(e) != 0; }();
+    const bool use_pool_call = use_call && use_pr2 && pool_call_env && pr_wgs == 0 && !(skip_mask() & 1);
+    const bool planes_call = use_pool_call && h->proj_x6 && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks);
     const int v_cols_all = h->L * h->dm;
     auto predict_split = [&](int nb, int* sk, long* ss) {       // the split-K form project_chunks_fast will choose for a sub-batch of nb chunks
         const long M = (long)nb * plan->inf.rows;
@@ -1455,11 +1481,16 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const size_t need3 = (size_t)(h->maxC > sub ? h->maxC : sub) * rows * h->d * sizeof(__bf16);
         const size_t szW = (size_t)v_cols_all * h->d * 2, szR = (size_t)(h->maxC > sub ? h->maxC : sub) * rows * h->d * 2;
         bool grow = false;
+        const size_t needRall = use_pool_call ? (size_t)(n_chunks - first_c) * rows * h->d * sizeof(float) : 0;
+        const size_t needPl = planes_call ? needRall / 2 : 0;
+        grow = grow || needRall > h->R_all.bytes || needPl > h->planes_all[0].bytes;
         for (int i = 0; i < kPSets; ++i) grow = grow || needP > h->P_ws[i].bytes;
         if (h->proj_x6) for (int i = 0; i < 3; ++i) grow = grow || need3 > h->r3[i].bytes;
         if (h->v_split) grow = grow || szW > h->wv_hi.bytes || szR > h->R_hi.bytes;
         if (grow) {
             HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(h->R_all.reserve(needRall));
+            for (int i = 0; i < 3; ++i) HIP_TRY(h->planes_all[i].reserve(needPl));
             for (int i = 0; i < kPSets; ++i) HIP_TRY(h->P_ws[i].reserve(needP));
             if (h->proj_x6) for (int i = 0; i < 3; ++i) HIP_TRY(h->r3[i].reserve(need3));
             if (h->v_split) {
@@ -1470,7 +1501,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         }
     }
     auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
-        if (kbar_pre) return INFV_OK;
+        if (kbar_pre || use_pool_call) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % kPSets, rset = b % kRSets;
         if (use_pr) {
@@ -1498,10 +1529,19 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const int set = b % kPSets, rset = b % kRSets;
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (r_pending[rset] && !use_pr) HIP_TRY(hipStreamWaitEvent(side, h->ev_r[rset], 0));   // (the rows kernel writes R here)
-        if (split_pool) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
+        if (split_pool && !use_pool_call) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
         const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
+        const float* r_ext = nullptr;
+        void* pl_ext[3] = {nullptr, nullptr, nullptr};
+        if (use_pool_call) {
+            // the rows of sub-batch b are complete once every (chunk, row) workgroup of the pooling launch has counted itself in
+            HIP_TRY(launch_flag_wait(h->pool_done.as<unsigned int>() + b, (unsigned int)((size_t)nb * rows), h->spin_limit, h->err_dev, side));
+            const size_t off = (size_t)(c0 - first_c) * rows * h->d;
+            r_ext = h->R_all.as<float>() + off;
+            if (planes_call) for (int i = 0; i < 3; ++i) pl_ext[i] = h->planes_all[i].as<__bf16>() + off;
+        }
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
-                                         h->vproj_on_uc(n_chunks), rset, use_pr)) return rc;
+                                         h->vproj_on_uc(n_chunks), rset, use_pr, r_ext, planes_call ? pl_ext : nullptr)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         if (use_call) {
@@ -1520,17 +1560,27 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             predict_split(sub, &sk_main, &ss_main);
             predict_split(nbl, &sk_last, &ss_last);
             if (n_batches == 1) { sk_main = sk_last; ss_main = ss_last; }
-            HIP_TRY(hipStreamWaitEvent(h->chain_s, h->ev_in, 0));
-            pipe.stream = h->chain_s;
+            if (call_stream != stream) HIP_TRY(hipStreamWaitEvent(call_stream, h->ev_in, 0));
+            pipe.stream = call_stream;
             const float* sets[kCallSets] = {};
             for (int i = 0; i < kPSets; ++i) sets[i] = h->P_ws[i].as<float>() + (size_t)v_cols_all;
             if (int rc = pipe.launch_s_call(n_chunks - first_c, sub, n_batches, sets, kPSets, sk_main, ss_main, sk_last, ss_last,
                                             u + (size_t)first_c * chunk_u, uf + (size_t)first_c * chunk_u)) return rc;
-            HIP_TRY(hipEventRecord(h->ev_chain, h->chain_s));
+            if (call_stream != stream) HIP_TRY(hipEventRecord(h->ev_chain, call_stream));
             pipe.stream = stream;
         }
         HIP_TRY(hipStreamWaitEvent(side, h->ev_q, 0));
         if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_start, 0));
+        if (use_pool_call) {
+            PoolCallDesc pc;
+            memset(&pc, 0, sizeof(pc));
+            pc.sub = sub; pc.n_chunks = n_chunks - first_c;
+            pc.R_all = h->R_all.as<float>();
+            if (planes_call) for (int i = 0; i < 3; ++i) pc.plane[i] = h->planes_all[i].p;
+            pc.done = h->pool_done.as<unsigned int>();
+            Timed t_(h->prof, INFV_KERNEL_POOL, pools);
+            HIP_TRY(launch_pool_rows2_call(k + first_c * chunk_k, h->k_bf16, T, h->P, h->d, plan->inf.view(), pc, pools, pr_u, pr_pad));
+        }
         if (int rc = stage_pool(0)) return rc;
         if (n_batches > 1)
             if (int rc = stage_pool(1)) return rc;
@@ -1562,6 +1612,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
         }
         const long slot0 = use_call ? call_slot0 + (long)(c0 - first_c) : pipe.counter;
+        const float* r_rows = use_pool_call ? h->R_all.as<float>() + (size_t)(c0 - first_c) * rows * h->d : h->R_ws[rset].as<float>();   // the sub-batch's new rows
         const bool serial = host_serial();                              // timing experiments: no overlap between the streams
         if (serial) { HIP_TRY(hipStreamSynchronize(pools)); HIP_TRY(hipStreamSynchronize(side)); HIP_TRY(hipStreamSynchronize(ucs)); }
         if (use_call) {
@@ -1612,7 +1663,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                                   h->wv_lo.as<__bf16>() + (size_t)l * h->dm * h->d, h->d, vs));
                     h->wv_split_valid = true;
                 }
-                HIP_TRY(launch_split_rows(h->R_ws[rset].as<float>(), h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, vs));
+                HIP_TRY(launch_split_rows(r_rows, h->d, Mv, h->d, h->R_hi.p, h->R_lo.p, h->d, vs));
                 SplitGemm g{};
                 g.A_hi = h->R_hi.as<__bf16>(); g.A_lo = h->R_lo.as<__bf16>(); g.lda = h->d; g.strideA = 0;
                 g.B_hi = h->wv_hi.as<__bf16>(); g.B_lo = h->wv_lo.as<__bf16>(); g.ldb = h->d; g.strideB = 0;
@@ -1620,12 +1671,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                 g.M = (int)Mv; g.N = v_cols; g.K = h->d; g.k_per_split = h->d; g.splitk = 1; g.nbatch = 1;
                 HIP_TRY(launch_split_gemm(g, vs, kGemmPad));
             } else {
-                HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, h->R_ws[rset].as<float>(),
+                HIP_TRY(launch_project_values((int)Mv, h->d, h->dm, h->L, pp, r_rows,
                                               h->P_ws[set].as<float>(), p_ld, vs, kGemmPad));
             }
         }
         if (use_call) {
-            // the UC stream holds until every role-S workgroup has written sub-batch b's steps back
+            // the UC stream holds until every role-S workgroup has written sub-batch b's steps back (the counter was zeroed on the
+            // caller's stream: the first wait of a call is ordered behind that)
+            if (b == 0) HIP_TRY(hipStreamWaitEvent(ucs, h->ev_in, 0));
             HIP_TRY(launch_flag_wait(h->call_flags.as<unsigned int>() + 64, (unsigned int)(b + 1) * (unsigned int)call_wgs, h->spin_limit, h->err_dev, ucs));
             pipe.last_snew = h->P_ws[set].as<float>() + (size_t)v_cols_all; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
         } else {
@@ -1634,7 +1687,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         }
         if (persistent)
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
-        if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, h->R_ws[rset].as<float>(), h->P_ws[set].as<float>(),
+        if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, r_rows, h->P_ws[set].as<float>(),
                                     sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
@@ -1653,7 +1706,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         HIP_TRY(hipStreamWaitEvent(stream, h->ev_in, 0));
         pipe.stream = stream;
     }
-    if (use_call) HIP_TRY(hipStreamWaitEvent(stream, h->ev_chain, 0));
+    if (use_call && call_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, h->ev_chain, 0));
     for (int i = 0; i < kPSets; ++i)
         if (uc_pending[i]) HIP_TRY(hipStreamWaitEvent(stream, h->ev_uc[i], 0));
     if (pipe.counter > 0) {

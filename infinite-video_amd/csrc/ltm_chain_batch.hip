@@ -532,28 +532,31 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     // the GEMM stream has raised `ready` past it.  The rows were written by ANOTHER kernel while this one was running, possibly
     // over lines this XCD's L2 still holds from the set's previous use: every load of them is an sc1 load (served by the
     // memory side; the producer's end-of-kernel release has written them back before its flag kernel ran).
-    const bool call_long = a.ready != nullptr;
+    const bool call_long = a.call != nullptr;
     unsigned int ready_seen = 0;                                              // (loader wave) sub-batches known to be projected
     auto ld_request = [&](int i, LdSet& r) {
         const float* sb;
         int splitk = a.snew_splitk;
         long split_stride = a.snew_split_stride;
         if (call_long) {
+            const ChainCallDesc* cd = a.call;                                 // (uniform address: scalar loads)
             const int cb = i / a.call_sub, li = i - cb * a.call_sub;
             if ((unsigned int)cb >= ready_seen) {
+                const unsigned int* ready = cd->ready;
+                long long* stats = (b == 0) ? cd->stats : nullptr;
                 long long t0 = 0;
                 int spins = 0;
                 for (;;) {
-                    const unsigned int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const unsigned int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (v > (unsigned int)cb) { ready_seen = v; break; }
-                    if (spins == 0 && a.call_stats != nullptr && b == 0) t0 = wall_clock64();
+                    if (spins == 0 && stats != nullptr) t0 = wall_clock64();
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ready_seen = 0xffffffffu; break; }   // (failed: no further waits)
                 }
-                if (spins > 0 && a.call_stats != nullptr && b == 0 && lane == 0) { a.call_stats[0] += wall_clock64() - t0; a.call_stats[1] += 1; }
+                if (spins > 0 && stats != nullptr && lane == 0) { stats[0] += wall_clock64() - t0; stats[1] += 1; }
             }
-            sb = a.snew_set[cb % a.call_sets] + (long)li * tile_snew + tile;
-            if (cb == a.call_batches - 1) { splitk = a.sk_last; split_stride = a.ss_last; }
+            sb = cd->snew_set[cb % cd->n_sets] + (long)li * tile_snew + tile;
+            if (cb == cd->n_batches - 1) { splitk = cd->sk_last; split_stride = cd->ss_last; }
         } else {
             sb = a.Snew + (long)i * tile_snew + tile;
         }
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
                 // L2); behind barrier 1 wave 6 starts the L2 write-back and, a step later, waits for it and counts this workgroup in.
                 if (wave == 6 && sig_pending) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the write-back issued one step ago has completed
-                    if (lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_fetch_add(a.call->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sig_pending = false;
                 }
                 if (batch_open) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1025,11 +1028,11 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     if (call_long) {
         // the last sub-batch (and a write-back still in flight): drain, write back, count this workgroup in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wave == 6 && sig_pending && lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 6 && sig_pending && lane == 0) __hip_atomic_fetch_add(a.call->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (wave == 6) {
             asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_add(a.call->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- hand the point scores to the next launch (its set-up reads them back through pb) ----
@@ -1055,16 +1058,20 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 // count-weighted softmax alpha[n] = w_n e^{S_n} / (sum_m w_m e^{S_m} + w_out)  (LTM.py:247-248,269-282 in closed
 // form) and asum = sum_n alpha[n].  One workgroup per (step, layer, head), a wave per query row in turn.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kA2NT = 256;
+constexpr int kA2NT = 256;                // threads of a team (four waves)
+constexpr int kA2Halves = 1;              // teams per workgroup (2 = eight-wave workgroups: measured in round 5, they never shared a CU with a pooling workgroup and the call got slower: 14.0 -> 14.8 ms)
 constexpr int kA2Q = 32;                  // query rows staged per pass
 
 // (TW4 = int4 entries per box of the gather table as a compile-time constant, 0 = read it from the arguments: with a run-time trip
 //  count hipcc unrolls the gather loop four ways with remainder loops for every one of the 32 (row, box) positions -- 12 000
 //  instructions, 16 us of arithmetic per unit; with the constant, 1.)
+// Workgroup = kA2Halves independent teams of four waves (kA2NT threads), each walking its own units with its own LDS tiles.
 template <int TW4>
-__global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(kA2NT * kA2Halves) void alpha_rows2_kernel(AlphaRows2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int half = threadIdx.x / kA2NT;
+    float* lds = lds_all + half * a.lds_half;
+    const int tid = threadIdx.x - half * kA2NT, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
     const int snp = kA2Q + 1;
     wg_stamp_begin(a.wg_stamps);
@@ -1168,10 +1175,14 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     };
     const bool regs_ok = a.regs_ok != 0;                                    // (launcher: the register stage fits and the rows are 16-byte aligned)
     if (tid < snp) snew[rows * snp + tid] = 0.f;                          // the zero row (read by boxes without a new row)
-    long u = blockIdx.x;
-    if (u >= n_units) { wg_stamp_end(a.wg_stamps); return; }
-    Unit cur = unit_of(u);
-    if (regs_ok) load_unit(cur);
+    // team t of workgroup g walks units kA2Halves g + t, + kA2Halves gridDim.x, ...; both teams run the same number of rounds (the
+    // barriers are the workgroup's), a team past its last unit idles through them
+    const long stride = (long)kA2Halves * gridDim.x;
+    long u = (long)kA2Halves * blockIdx.x + half;
+    const long n_rounds = (n_units - (long)kA2Halves * blockIdx.x + stride - 1) / stride;     // rounds of team 0 (>= team 1's)
+    if (n_rounds <= 0) { wg_stamp_end(a.wg_stamps); return; }
+    Unit cur = unit_of(u < n_units ? u : 0);
+    if (regs_ok && u < n_units) load_unit(cur);
     // static operator entries of this lane's four boxes
     float val[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
     int brow[4] = {-1, -1, -1, -1};
@@ -1187,19 +1198,21 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     const bool dbg_on = TW4 != 0 && a.dbg != nullptr;   // (the generic instantiation keeps the shipped register count: test_host_cpu)
     long long t_wg0 = dbg_on ? wall_clock64() : 0, t_stage = 0, t_comp = 0, t_issue = 0; int n_done = 0;
 #endif
-    for (; u < n_units; u += gridDim.x) {
-        cur = unit_of(u);
+    for (long round = 0; round < n_rounds; ++round, u += stride) {
+        const bool active = u < n_units;
+        cur = unit_of(active ? u : 0);
 #ifdef INFV_EXPERIMENTS
         const long long t0 = dbg_on ? wall_clock64() : 0;
 #endif
         __syncthreads();                                                    // the previous unit's rows are done with the LDS tiles
-        if (regs_ok) store_unit(cur); else stage_unit_direct(cur);
+        if (active) { if (regs_ok) store_unit(cur); else stage_unit_direct(cur); }
         const float cq_lane = r_cq;
         __syncthreads();
+        if (!active) continue;
 #ifdef INFV_EXPERIMENTS
         const long long t1 = dbg_on ? wall_clock64() : 0;
 #endif
-        if (regs_ok && u + gridDim.x < n_units) load_unit(unit_of(u + gridDim.x));     // in flight behind this unit's arithmetic
+        if (regs_ok && u + stride < n_units) load_unit(unit_of(u + stride));     // in flight behind this unit's arithmetic
 #ifdef INFV_EXPERIMENTS
         if (dbg_on) { const long long t1b = wall_clock64(); t_issue += t1b - t1; }
 #endif
@@ -1306,11 +1319,12 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
     static const bool force_direct = [] { const char* e = exp_env("INFV_ALPHA_DIRECT"); return e && atoi(e) != 0; }();   // (tests: the fallback staging)
     a.regs_ok = !force_direct && a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
                 a.snew_split_stride % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0;
-    const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1)) * sizeof(float);   // (+ a zero row behind the S'new tile)
+    a.lds_half = (((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1) + 3) & ~3;                       // (+ a zero row behind the S'new tile)
+    const size_t lds = (size_t)a.lds_half * kA2Halves * sizeof(float);
     // two work units per workgroup (experiments build: INFV_ALPHA_UPW; 1 / 2 / 4 on one box: 14.1 / 13.8 / 15.1 ms per video): the next unit's loads fly behind the present one's arithmetic
     static const int upw = [] { const char* e = exp_env("INFV_ALPHA_UPW"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 1; }();
     const long n_units = (long)a.n_steps * a.L * a.H * ((a.Q + kA2Q - 1) / kA2Q);
-    const unsigned grid = (unsigned)((n_units + upw - 1) / upw);
+    const unsigned grid = (unsigned)((n_units + (long)upw * kA2Halves - 1) / ((long)upw * kA2Halves));
     a.wg_stamps = exp_stamps_reserve(WG_ALPHA, (long)grid);
     a.dbg = nullptr;
 #ifdef INFV_EXPERIMENTS
@@ -1329,9 +1343,9 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
         }
     }
 #endif
-    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds, stream, a);
-    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds, stream, a);
-    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
+    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
+    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1496,6 +1510,11 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
 // end-of-kernel release has written its output back) and raises the count role S's loaders poll.  Role S -> UC stream:
 // flag_wait_kernel holds the UC stream until every role-S workgroup has counted the sub-batch in (ChainBatchArgs.done); the
 // kernels behind it start with the usual launch-time acquire.  One wave each; the wait is bounded and latches the error word.
+__global__ void chain_call_desc_kernel(ChainCallDesc* dst, ChainCallDesc v) { if (threadIdx.x == 0) *dst = v; }
+hipError_t launch_chain_call_desc(ChainCallDesc* dst, const ChainCallDesc& v, hipStream_t stream) {
+    hipLaunchKernelGGL(chain_call_desc_kernel, dim3(1), dim3(64), 0, stream, dst, v);
+    return hipGetLastError();
+}
 __global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1529,7 +1548,8 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
         // XCD-aware launch: a layer's workgroups get block ids that are equal mod 8 (one XCD under round-robin placement, where
         // the exchange then stays in that XCD's L2); needs a layer to fit one XCD's CUs and a placement class per layer.  The
         // kernel verifies the placement itself (handshake) and is correct without it.
-        a.xcd_grid = (chain_batch3_mailboxes() && G <= 32 && a.L <= 8) ? 1 : 0;
+        static const bool linear = [] { const char* e = exp_env("INFV_CHAIN_LINEAR"); return e && atoi(e) != 0; }();   // experiments: linear grid (the layer spread over all XCDs)
+        a.xcd_grid = (chain_batch3_mailboxes() && !linear && G <= 32 && a.L <= 8) ? 1 : 0;
         const int blocks = a.xcd_grid ? 8 * G : G * a.L;
         const size_t lds = chain_batch3_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
         a.wg_stamps = exp_stamps_reserve(WG_CHAIN, blocks);

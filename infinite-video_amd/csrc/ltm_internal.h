@@ -69,6 +69,18 @@ hipError_t launch_pool(const void* k, int k_bf16, float* kbar, int64_t n_frames,
 // one short-lived workgroup per (chunk, row), a wave per (frame of the row, 256-float slice); u: 1-KiB loads per burst,
 // lds_pad: occupancy cap
 bool pool_rows2_supported(int d);
+// ONE pooling launch per consolidate call (round 5): workgroup (chunk, row) of the WHOLE call, in order; besides the fp32 row it can
+// write the row's three bf16 planes for the projection GEMM (k-tile-major per sub-batch: split3_rows_kernel's layout), and it counts
+// itself into its sub-batch's completion word -- the GEMM stream waits on that (flag_wait_kernel) instead of a launch boundary.
+struct PoolCallDesc {
+    int sub;                        // chunks per sub-batch (the last one may be shorter)
+    int n_chunks;                   // chunks of the launch
+    float* R_all;                   // [n_chunks][rows][d] fp32
+    void* plane[3];                 // bf16 planes, sub-batch b at element offset b * sub * rows * d, or nullptr
+    unsigned int* done;             // [sub-batches] rows written (write-through) so far
+};
+hipError_t launch_pool_rows2_call(const void* k, int k_bf16, int T, int P, int d, const OperatorView& op, const PoolCallDesc& pc,
+                                  hipStream_t stream, int u, int lds_pad);
 hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
                              hipStream_t stream, int u, int lds_pad, int max_wgs = 0);
 int project_splitk(int M, int K);
@@ -148,6 +160,18 @@ bool chain_supported(int N, int S, int rows_max, int tabw);
 int chain_s_tiles(int Q);            // 8-row query tiles of role S (= sticky partial rows per head)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
 // ---- role S of a whole sub-batch in one persistent launch (ltm_chain_batch.hip) ----
+// description of a call-long launch's sub-batches
+struct ChainCallDesc {
+    const unsigned int* ready;      // sub-batches of this call whose projection GEMM is complete (flag_set_kernel on the GEMM's stream)
+    unsigned int* done;             // every workgroup adds 1 per sub-batch once the steps it published are written back (flag_wait_kernel on the UC stream polls it)
+    int sub;                        // steps per sub-batch (the last one may be shorter)
+    int n_batches;                  // sub-batches of the launch
+    const float* snew_set[kCallSets];   // S'new origin of workspace set s; sub-batch b reads set b % n_sets
+    int n_sets;
+    int sk_last; long ss_last;      // split-K form of the LAST sub-batch's projection (all others: snew_splitk / snew_split_stride)
+    long long* stats;               // [0]: 100 MHz ticks workgroup 0 spent waiting for `ready`; [1]: sub-batches it had to wait for; or nullptr
+};
+hipError_t launch_chain_call_desc(ChainCallDesc* dst, const ChainCallDesc& v, hipStream_t stream);
 struct ChainBatchArgs {
     int N, H, Q, QS, L, S;
     StickyView st;
@@ -186,14 +210,8 @@ struct ChainBatchArgs {
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
     // ---- call-long launch of chain_batch3_kernel: ONE launch per infv_ltm_consolidate, resident from the call's first sub-batch to its
     // last (ready == nullptr: one launch per sub-batch, Snew / snew_splitk / snew_split_stride describe that sub-batch) ----
-    const unsigned int* ready;      // sub-batches of this call whose projection GEMM is complete (flag_set_kernel on the GEMM's stream)
-    unsigned int* done;             // every workgroup adds 1 per sub-batch once the steps it published are written back (flag_wait_kernel on the UC stream polls it)
-    int call_sub;                   // steps per sub-batch (the last one may be shorter)
-    int call_batches;               // sub-batches of the launch
-    const float* snew_set[kCallSets];   // S'new origin of workspace set s; sub-batch b reads set b % call_sets
-    int call_sets;
-    int sk_last; long ss_last;      // split-K form of the LAST sub-batch's projection (all others: snew_splitk / snew_split_stride)
-    long long* call_stats;          // [0]: 100 MHz ticks workgroup 0 spent waiting for `ready`; [1]: sub-batches it had to wait for; or nullptr
+    const ChainCallDesc* call;      // device memory (written by chain_call_desc_kernel ahead of the launch: the kernel's argument registers are full), or nullptr
+    int call_sub;                   // = call->sub (the one field every wave needs every step)
 };
 // role S -> UC stream / GEMM stream -> role S hand-offs of a call-long launch (ltm_chain_batch.hip)
 hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream);
@@ -222,6 +240,7 @@ struct AlphaRows2Args {
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
     int prio;                       // experiments build: s_setprio level of the kernel's waves (0 = leave)
     int regs_ok;                    // set by the launcher: the next unit's inputs fit the kernel's register stage
+    int lds_half;                   // set by the launcher: floats of LDS per four-wave team
     long long* dbg;                 // experiments build, INFV_ALPHA_STAMPS: phase time sums (100 MHz ticks), or nullptr
 };
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);

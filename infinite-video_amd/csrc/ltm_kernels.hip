@@ -17,6 +17,7 @@
 #include "ltm_device.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace infv {
 
@@ -151,10 +152,21 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const float* __restrict
 //     trip through HBM, no rows kernel, and a workgroup lives as long as one of pool_frames_kernel's (a frame's worth of loads per
 //     wave), which is what lets role S find empty CUs at its launches (pool_rows_kernel's workgroups live four times longer).
 // ------------------------------------------------------------------------------------------------------
-template <int U, class Tok>
+// (bf16 three-piece split of an fp32 value, as split_gemm.hip's split3_rows_kernel makes them: x = p0 + p1 + p2 exactly)
+__device__ inline void pool_split3(float x, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)x;
+    const float r1 = x - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+__device__ inline unsigned pool_pack2(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <int U, class Tok, bool CALL>
 __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict__ k_, long chunk_stride, int P, int d4, int slices,
                                                           OperatorView op, long n_rows_total, float* __restrict__ R,
-                                                          long long* __restrict__ stamps, int prio, int tid_addr) {
+                                                          long long* __restrict__ stamps, int prio, int tid_addr, PoolCallDesc pc) {
     typedef typename Tok::vec tvec;
     extern __shared__ __attribute__((aligned(16))) float pr2_lds[];          // [4 frames][d4] float4
     floatx4* park = reinterpret_cast<floatx4*>(pr2_lds);
@@ -223,7 +235,43 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
             }
             __syncthreads();
         }
-        if (fi == 0 && col_ok) __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + rr * (long)d4 + c4);
+        if constexpr (!CALL) {
+            if (fi == 0 && col_ok) __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + rr * (long)d4 + c4);
+        } else {
+            // call-long launch: consumers are kernels launched behind a flag wait while this launch is still running -- every store is
+            // write-through (sc1), drained, then the workgroup counts itself into its sub-batch's word
+            const long cb = c / pc.sub;
+            if (fi == 0 && col_ok) {
+                __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(pc.R_all + rr * (long)d4 * 4, 0, d4 * 16, 0x00020000);
+                uintx4_t w;
+                w.x = __float_as_uint(racc.x); w.y = __float_as_uint(racc.y); w.z = __float_as_uint(racc.z); w.w = __float_as_uint(racc.w);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rr_, c4 * 16, 0, 16 /* sc1 */);
+                if (pc.plane[0] != nullptr) {
+                    const long nb = (pc.n_chunks - cb * pc.sub) < pc.sub ? (pc.n_chunks - cb * pc.sub) : pc.sub;   // chunks of this sub-batch
+                    const long Mb = nb * op.rows, m = (c - cb * pc.sub) * op.rows + r;
+                    const int col = 4 * c4;
+                    const long base = cb * pc.sub * op.rows * (long)(4 * d4);                      // (uniform) first element of the sub-batch's planes
+                    const int voff = (int)((((long)(col >> 4) * Mb + m) * 16 + (col & 15)) * 2);   // (per lane) byte offset inside them
+                    __bf16 a[4], bb[4], dd[4];
+                    pool_split3(racc.x, a[0], bb[0], dd[0]); pool_split3(racc.y, a[1], bb[1], dd[1]);
+                    pool_split3(racc.z, a[2], bb[2], dd[2]); pool_split3(racc.w, a[3], bb[3], dd[3]);
+                    uintx2 v0, v1, v2;
+                    v0.x = pool_pack2(a[0], a[1]); v0.y = pool_pack2(a[2], a[3]);
+                    v1.x = pool_pack2(bb[0], bb[1]); v1.y = pool_pack2(bb[2], bb[3]);
+                    v2.x = pool_pack2(dd[0], dd[1]); v2.y = pool_pack2(dd[2], dd[3]);
+                    const int span = (int)(Mb * (long)(4 * d4) * 2);
+                    __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[0]) + base, 0, span, 0x00020000);
+                    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[1]) + base, 0, span, 0x00020000);
+                    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[2]) + base, 0, span, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b64(v0, r0, voff, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b64(v1, r1, voff, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b64(v2, r2, voff, 0, 16 /* sc1 */);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(pc.done + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef INFV_EXPERIMENTS
     if (stamps != nullptr) { __syncthreads(); wg_stamp_end(stamps); }
@@ -350,7 +398,10 @@ constexpr int kPoolTidAddr = 0;           // pool_rows2_kernel: lane-id addresse
 
 template <class Tok>
 static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                      hipStream_t stream, int u, int lds_pad, int max_wgs) {
+                                      hipStream_t stream, int u, int lds_pad, int max_wgs, const PoolCallDesc* call = nullptr) {
+    PoolCallDesc pc;
+    memset(&pc, 0, sizeof(pc));
+    if (call != nullptr) { pc = *call; max_wgs = 0; }
     const int d4 = d / 4, slices = (d4 + 63) / 64;
     if (4 * slices * 64 > 1024) return hipErrorInvalidValue;
     const long n_rows_total = (long)n_chunks * op.rows;
@@ -358,11 +409,13 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     if ((size_t)lds_pad > lds) lds = lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<4, Tok, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<8, Tok, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef INFV_EXPERIMENTS
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<16, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<32, Tok>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<16, Tok, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_kernel<32, Tok, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -373,7 +426,7 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     static const int prio = [] { const char* e = exp_env("INFV_POOL_PRIO"); return e ? atoi(e) : 0; }();
 #ifdef INFV_EXPERIMENTS
     static const int want_dma = [] { const char* e = exp_env("INFV_POOL_DMA"); return e ? atoi(e) : 0; }();
-    if (want_dma && sizeof(typename Tok::vec) == 16 && P >= 6 && slices == 3) {
+    if (want_dma && call == nullptr && sizeof(typename Tok::vec) == 16 && P >= 6 && slices == 3) {
         // (12 waves x 6 KiB + 12 KiB of parked frame means = 84 KB: the padding size of the register-load kernel)
         constexpr int NB = 6;
         const size_t need = (size_t)16 * d4 * sizeof(float) + (size_t)4 * slices * NB * 1024;
@@ -393,11 +446,16 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     static const int want_tid = [] { const char* e = exp_env("INFV_POOL_TID"); return e ? atoi(e) : kPoolTidAddr; }();
     const int tid_addr = (want_tid && d4 % 64 == 0) ? 1 : 0;               // every lane of every slice holds a column
 #ifdef INFV_EXPERIMENTS
-    if (u >= 32 && P % 32 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<32, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr); return hipGetLastError(); }
-    if (u >= 16 && P % 16 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<16, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr); return hipGetLastError(); }
+    if (call == nullptr && u >= 32 && P % 32 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<32, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
+    if (call == nullptr && u >= 16 && P % 16 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<16, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
 #endif
-    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
-    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr);
+    if (call != nullptr) {
+        if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+        else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+        return hipGetLastError();
+    }
+    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
     return hipGetLastError();
 }
 
@@ -406,6 +464,14 @@ hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
     return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs)
                   : launch_pool_rows2_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs);
+}
+
+hipError_t launch_pool_rows2_call(const void* k, int k_bf16, int T, int P, int d, const OperatorView& op, const PoolCallDesc& pc,
+                                  hipStream_t stream, int u, int lds_pad) {
+    if (op.rows == 0 || pc.n_chunks == 0) return hipSuccess;
+    if (pc.R_all == nullptr || pc.done == nullptr || pc.sub <= 0) return hipErrorInvalidValue;
+    return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, pc.n_chunks, T, P, d, op, nullptr, stream, u, lds_pad, 0, &pc)
+                  : launch_pool_rows2_t<TokF32>(k, pc.n_chunks, T, P, d, op, nullptr, stream, u, lds_pad, 0, &pc);
 }
 
 bool pool_rows2_supported(int d) { return d % 4 == 0 && ((d / 4 + 63) / 64) * 4 * 64 <= 1024; }

@@ -15,14 +15,16 @@ with tempfile.TemporaryDirectory() as d:
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", f], cwd=d, capture_output=True, text=True, check=True).stdout
         cur = {}
         rows = []
+        # the metadata keys of a kernel come in alphabetical order (.agpr_count ... .wavefront_size): a record ends at .wavefront_size
         for line in notes.split("\n"):
-            m = re.search(r"\.(name|vgpr_count|sgpr_count|agpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count):\s+(\S+)", line)
+            m = re.search(r"\.(name|vgpr_count|sgpr_count|agpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count|wavefront_size):\s+(\S+)", line)
             if m:
-                if m.group(1) == "name" and "name" in cur and "vgpr_count" in cur:
-                    rows.append(cur); cur = {}
-                cur[m.group(1)] = m.group(2)
-        if cur:
-            rows.append(cur)
+                if m.group(1) == "wavefront_size":
+                    if "name" in cur:
+                        rows.append(cur)
+                    cur = {}
+                else:
+                    cur[m.group(1)] = m.group(2)
         for r in rows:
             n = subprocess.run(["c++filt", r.get("name", "?")], capture_output=True, text=True).stdout.strip()
             if frags and not any(x in n for x in frags):
