@@ -1058,20 +1058,16 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 // count-weighted softmax alpha[n] = w_n e^{S_n} / (sum_m w_m e^{S_m} + w_out)  (LTM.py:247-248,269-282 in closed
 // form) and asum = sum_n alpha[n].  One workgroup per (step, layer, head), a wave per query row in turn.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kA2NT = 256;                // threads of a team (four waves)
-constexpr int kA2Halves = 1;              // teams per workgroup (2 = eight-wave workgroups: measured in round 5, they never shared a CU with a pooling workgroup and the call got slower: 14.0 -> 14.8 ms)
+constexpr int kA2NT = 256;
 constexpr int kA2Q = 32;                  // query rows staged per pass
 
 // (TW4 = int4 entries per box of the gather table as a compile-time constant, 0 = read it from the arguments: with a run-time trip
 //  count hipcc unrolls the gather loop four ways with remainder loops for every one of the 32 (row, box) positions -- 12 000
 //  instructions, 16 us of arithmetic per unit; with the constant, 1.)
-// Workgroup = kA2Halves independent teams of four waves (kA2NT threads), each walking its own units with its own LDS tiles.
 template <int TW4>
-__global__ __launch_bounds__(kA2NT * kA2Halves) void alpha_rows2_kernel(AlphaRows2Args a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_all[];
-    const int half = threadIdx.x / kA2NT;
-    float* lds = lds_all + half * a.lds_half;
-    const int tid = threadIdx.x - half * kA2NT, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
     const int snp = kA2Q + 1;
     wg_stamp_begin(a.wg_stamps);
@@ -1175,14 +1171,10 @@ __global__ __launch_bounds__(kA2NT * kA2Halves) void alpha_rows2_kernel(AlphaRow
     };
     const bool regs_ok = a.regs_ok != 0;                                    // (launcher: the register stage fits and the rows are 16-byte aligned)
     if (tid < snp) snew[rows * snp + tid] = 0.f;                          // the zero row (read by boxes without a new row)
-    // team t of workgroup g walks units kA2Halves g + t, + kA2Halves gridDim.x, ...; both teams run the same number of rounds (the
-    // barriers are the workgroup's), a team past its last unit idles through them
-    const long stride = (long)kA2Halves * gridDim.x;
-    long u = (long)kA2Halves * blockIdx.x + half;
-    const long n_rounds = (n_units - (long)kA2Halves * blockIdx.x + stride - 1) / stride;     // rounds of team 0 (>= team 1's)
-    if (n_rounds <= 0) { wg_stamp_end(a.wg_stamps); return; }
-    Unit cur = unit_of(u < n_units ? u : 0);
-    if (regs_ok && u < n_units) load_unit(cur);
+    long u = blockIdx.x;
+    if (u >= n_units) { wg_stamp_end(a.wg_stamps); return; }
+    Unit cur = unit_of(u);
+    if (regs_ok) load_unit(cur);
     // static operator entries of this lane's four boxes
     float val[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};
     int brow[4] = {-1, -1, -1, -1};
@@ -1198,21 +1190,19 @@ __global__ __launch_bounds__(kA2NT * kA2Halves) void alpha_rows2_kernel(AlphaRow
     const bool dbg_on = TW4 != 0 && a.dbg != nullptr;   // (the generic instantiation keeps the shipped register count: test_host_cpu)
     long long t_wg0 = dbg_on ? wall_clock64() : 0, t_stage = 0, t_comp = 0, t_issue = 0; int n_done = 0;
 #endif
-    for (long round = 0; round < n_rounds; ++round, u += stride) {
-        const bool active = u < n_units;
-        cur = unit_of(active ? u : 0);
+    for (; u < n_units; u += gridDim.x) {
+        cur = unit_of(u);
 #ifdef INFV_EXPERIMENTS
         const long long t0 = dbg_on ? wall_clock64() : 0;
 #endif
         __syncthreads();                                                    // the previous unit's rows are done with the LDS tiles
-        if (active) { if (regs_ok) store_unit(cur); else stage_unit_direct(cur); }
+        if (regs_ok) store_unit(cur); else stage_unit_direct(cur);
         const float cq_lane = r_cq;
         __syncthreads();
-        if (!active) continue;
 #ifdef INFV_EXPERIMENTS
         const long long t1 = dbg_on ? wall_clock64() : 0;
 #endif
-        if (regs_ok && u + stride < n_units) load_unit(unit_of(u + stride));     // in flight behind this unit's arithmetic
+        if (regs_ok && u + gridDim.x < n_units) load_unit(unit_of(u + gridDim.x));     // in flight behind this unit's arithmetic
 #ifdef INFV_EXPERIMENTS
         if (dbg_on) { const long long t1b = wall_clock64(); t_issue += t1b - t1; }
 #endif
@@ -1319,12 +1309,11 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
     static const bool force_direct = [] { const char* e = exp_env("INFV_ALPHA_DIRECT"); return e && atoi(e) != 0; }();   // (tests: the fallback staging)
     a.regs_ok = !force_direct && a.N * (a.tabw / 4) <= 2 * kA2NT && a.rows * (kA2Q / 4) <= 2 * kA2NT && a.Q % 4 == 0 && a.snew_ld % 4 == 0 &&
                 a.snew_split_stride % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0;
-    a.lds_half = (((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1) + 3) & ~3;                       // (+ a zero row behind the S'new tile)
-    const size_t lds = (size_t)a.lds_half * kA2Halves * sizeof(float);
+    const size_t lds = (size_t)(((a.N * a.tabw + 3) & ~3) + kA2Q * kScPitch + (a.rows + 1) * (kA2Q + 1)) * sizeof(float);   // (+ a zero row behind the S'new tile)
     // two work units per workgroup (experiments build: INFV_ALPHA_UPW; 1 / 2 / 4 on one box: 14.1 / 13.8 / 15.1 ms per video): the next unit's loads fly behind the present one's arithmetic
     static const int upw = [] { const char* e = exp_env("INFV_ALPHA_UPW"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 1; }();
     const long n_units = (long)a.n_steps * a.L * a.H * ((a.Q + kA2Q - 1) / kA2Q);
-    const unsigned grid = (unsigned)((n_units + (long)upw * kA2Halves - 1) / ((long)upw * kA2Halves));
+    const unsigned grid = (unsigned)((n_units + upw - 1) / upw);
     a.wg_stamps = exp_stamps_reserve(WG_ALPHA, (long)grid);
     a.dbg = nullptr;
 #ifdef INFV_EXPERIMENTS
@@ -1343,9 +1332,9 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
         }
     }
 #endif
-    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
-    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
-    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT * kA2Halves), lds, stream, a);
+    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -240,7 +240,6 @@ struct AlphaRows2Args {
     long long* wg_stamps;           // residency experiment (wg_stamps.h), or nullptr
     int prio;                       // experiments build: s_setprio level of the kernel's waves (0 = leave)
     int regs_ok;                    // set by the launcher: the next unit's inputs fit the kernel's register stage
-    int lds_half;                   // set by the launcher: floats of LDS per four-wave team
     long long* dbg;                 // experiments build, INFV_ALPHA_STAMPS: phase time sums (100 MHz ticks), or nullptr
 };
 hipError_t launch_alpha_rows2(const AlphaRows2Args& a, hipStream_t stream);
