@@ -189,6 +189,8 @@ struct infv_ltm_s {
     DeviceBuf psi_Y, psi_E, psi_Eg, psi_alpha;   // general-psi step: resampled rows, edge scores, grid scores / probabilities, read-out weights
     DeviceBuf R_all, planes_all[3];    // call-long pooling launch: every new row of the call (fp32, and as three bf16 planes per sub-batch for the projection GEMM)
     DeviceBuf pool_done;               // ... and its per-sub-batch completion counts
+    DeviceBuf gemm_flags;              // call-long projection GEMM: [0] tile queue head, [64] sub-batches whose UC kernel is done, [128 + b] S' tiles, [128 + cap + b] V' tiles of sub-batch b; the descriptor behind them
+    long gemm_flags_cap = 0;
     DeviceBuf call_flags;              // call-long role S: [0] sub-batches projected (GEMM stream -> role S), [64] workgroup x sub-batch completions (role S -> UC stream); words 256 B apart
     DeviceBuf call_stats;              // call-long role S: [0] ticks (100 MHz) workgroup 0 waited for projections, [1] how many sub-batches it waited for
     hipEvent_t ev_chain = nullptr;     // the call-long role-S launch has finished (recorded on its stream)
@@ -893,10 +895,11 @@ struct FastPipe {
 
     // role S of the WHOLE call in one launch: `n` steps in `n_batches` sub-batches of `sub` (the last may be shorter) whose S'new
     // rows arrive in workspace set (sub-batch % n_sets)
-    struct CallLong { int sub, n_batches; const float* const* sets; int n_sets; int sk_last; long ss_last; };
+    struct CallLong { int sub, n_batches; const float* const* sets; int n_sets; int sk_last; long ss_last;
+                      const unsigned int* tiles_s; int n_tiled, tiles_full, tiles_last; };
     int launch_s_call(int n, int sub, int n_batches, const float* const* sets, int n_sets, int sk_main, long ss_main, int sk_last, long ss_last,
-                      const double* u, const float* uf) {
-        const CallLong cl{sub, n_batches, sets, n_sets, sk_last, ss_last};
+                      const double* u, const float* uf, const unsigned int* tiles_s = nullptr, int n_tiled = 0, int tiles_full = 0, int tiles_last = 0) {
+        const CallLong cl{sub, n_batches, sets, n_sets, sk_last, ss_last, tiles_s, n_tiled, tiles_full, tiles_last};
         return launch_s_batch(n, sets[0], sk_main, ss_main, u, uf, &cl);
     }
 
@@ -910,6 +913,7 @@ struct FastPipe {
             ChainCallDesc cd;
             memset(&cd, 0, sizeof(cd));
             cd.ready = h->call_flags.as<unsigned int>(); cd.done = h->call_flags.as<unsigned int>() + 64;
+            cd.tiles_s = cl->tiles_s; cd.n_tiled = cl->n_tiled; cd.tiles_full = cl->tiles_full; cd.tiles_last = cl->tiles_last;
             cd.sub = cl->sub; cd.n_batches = cl->n_batches; cd.n_sets = cl->n_sets;
             for (int i = 0; i < cl->n_sets && i < kCallSets; ++i) cd.snew_set[i] = cl->sets[i];
             cd.sk_last = cl->sk_last; cd.ss_last = cl->ss_last;
@@ -1277,6 +1281,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const size_t need_pd = ((size_t)n_chunks + 1) * sizeof(unsigned int);
         if (need_pd > h->pool_done.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->pool_done.reserve(need_pd < 32768 ? 32768 : need_pd)); }
         HIP_TRY(hipMemsetAsync(h->pool_done.p, 0, need_pd, stream));
+        const long cap = ((long)n_chunks + 64) & ~63l;
+        if (cap > h->gemm_flags_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            const long ncap = cap < 8192 ? 8192 : cap;
+            HIP_TRY(h->gemm_flags.reserve((size_t)(128 + 2 * ncap) * sizeof(unsigned int) + 1024));
+            h->gemm_flags_cap = ncap;
+        }
+        HIP_TRY(hipMemsetAsync(h->gemm_flags.p, 0, (size_t)(128 + 2 * h->gemm_flags_cap) * sizeof(unsigned int), stream));
         HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));
     }
     HIP_TRY(hipEventRecord(h->ev_start, stream));
@@ -1457,6 +1469,17 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     static const bool pool_call_env = [] { const char* e = exp_env("INFV_POOL_CALL"); return !e || atoi(e) != 0; }();
     const bool use_pool_call = use_call && use_pr2 && pool_call_env && pr_wgs == 0 && !(skip_mask() & 1);
     const bool planes_call = use_pool_call && h->proj_x6 && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks);
+    // ... and ONE projection-GEMM launch: a few resident workgroups per XCD on a tile queue (gemm_x6_call_kernel).  Sub-batches it
+    // covers: every one of >= 1024 rows (all but, possibly, a short last one: that one keeps its own launch behind the resident kernel)
+    static const bool gemm_call_env = [] { const char* e = exp_env("INFV_GEMM_CALL"); return !e || atoi(e) != 0; }();
+    static const int gemm_wgs = [] { const char* e = exp_env("INFV_GEMM_WGS"); const int v = e ? atoi(e) : 32; return v > 0 ? v : 32; }();
+    int n_tiled = 0;
+    if (planes_call && gemm_call_env && h->w3_valid && !(skip_mask() & 2) && (sub * rows) % 32 == 0 && (long)sub * rows >= 1024 &&
+        ((long)h->L * h->dm + (long)h->L * h->H * Q) % 256 == 0 && ((long)h->L * h->dm) % 256 == 0) {
+        int c0l, nbl; batch_range(n_batches - 1, &c0l, &nbl);
+        n_tiled = ((long)nbl * rows >= 1024 && ((long)nbl * rows) % 32 == 0) ? n_batches : n_batches - 1;
+    }
+    const bool use_gemm_call = n_tiled > 0;
     const int v_cols_all = h->L * h->dm;
     auto predict_split = [&](int nb, int* sk, long* ss) {       // the split-K form project_chunks_fast will choose for a sub-batch of nb chunks
         const long M = (long)nb * plan->inf.rows;
@@ -1527,6 +1550,10 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     auto stage_project = [&](int b) -> int {                   // rows -> [V'new | S'new] GEMM of batch b, on `side`
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % kPSets, rset = b % kRSets;
+        if (b < n_tiled) {                                     // the resident GEMM kernel has this sub-batch on its tile queue
+            sks[b] = 1; sss[b] = (long)nb * (long)rows * ((long)h->L * h->dm + (long)h->L * h->H * Q);
+            return INFV_OK;
+        }
         if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(side, h->ev_uc[set], 0));   // the UC kernel that read this set is done
         if (r_pending[rset] && !use_pr) HIP_TRY(hipStreamWaitEvent(side, h->ev_r[rset], 0));   // (the rows kernel writes R here)
         if (split_pool && !use_pool_call) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool[set], 0));
@@ -1564,12 +1591,35 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             pipe.stream = call_stream;
             const float* sets[kCallSets] = {};
             for (int i = 0; i < kPSets; ++i) sets[i] = h->P_ws[i].as<float>() + (size_t)v_cols_all;
+            const int s_ct = (h->L * h->H * Q) / 256;                                   // S' column tiles of the projection
+            const int rt_full = (int)(((long)sub * (long)rows + 383) / 384), rt_last = (int)(((long)nbl * (long)rows + 383) / 384);
             if (int rc = pipe.launch_s_call(n_chunks - first_c, sub, n_batches, sets, kPSets, sk_main, ss_main, sk_last, ss_last,
-                                            u + (size_t)first_c * chunk_u, uf + (size_t)first_c * chunk_u)) return rc;
+                                            u + (size_t)first_c * chunk_u, uf + (size_t)first_c * chunk_u,
+                                            use_gemm_call ? h->gemm_flags.as<unsigned int>() + 128 : nullptr, n_tiled, s_ct * rt_full,
+                                            s_ct * (n_tiled == n_batches ? rt_last : rt_full))) return rc;
             if (call_stream != stream) HIP_TRY(hipEventRecord(h->ev_chain, call_stream));
             pipe.stream = stream;
         }
         HIP_TRY(hipStreamWaitEvent(side, h->ev_q, 0));
+        if (use_gemm_call) {
+            GemmCallDesc gd;
+            memset(&gd, 0, sizeof(gd));
+            unsigned int* gf = h->gemm_flags.as<unsigned int>();
+            for (int i = 0; i < 3; ++i) { gd.A_all[i] = h->planes_all[i].as<__bf16>(); gd.B[i] = h->w3[i].as<__bf16>(); }
+            for (int i = 0; i < kPSets; ++i) gd.C_set[i] = h->P_ws[i].as<float>();
+            gd.n_sets = kPSets;
+            gd.ldc = (long)h->L * h->dm + (long)h->L * h->H * Q; gd.N = (int)gd.ldc; gd.K = h->d;
+            gd.sub_rows = (int)(sub * rows);
+            gd.total_rows = (n_tiled == n_batches) ? (long)(n_chunks - first_c) * (long)rows : (long)n_tiled * sub * (long)rows;
+            gd.n_batches = n_tiled;
+            gd.s_col_tile0 = (h->L * h->dm) / 256;
+            gd.pool_done = h->pool_done.as<unsigned int>();
+            gd.tile_ctr = gf; gd.uc_done = gf + 64; gd.done_s = gf + 128; gd.done_v = gf + 128 + h->gemm_flags_cap;
+            gd.error = h->err_dev; gd.spin_limit = h->spin_limit;
+            GemmCallDesc* gd_dev = reinterpret_cast<GemmCallDesc*>(gf + 128 + 2 * h->gemm_flags_cap);
+            Timed t_(h->prof, INFV_KERNEL_PROJECT, side);
+            HIP_TRY(launch_gemm_x6_call(gd, gd_dev, gemm_wgs, side));
+        }
         if (split_pool) HIP_TRY(hipStreamWaitEvent(pools, h->ev_start, 0));
         if (use_pool_call) {
             PoolCallDesc pc;
@@ -1680,6 +1730,11 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             // caller's stream: the first wait of a call is ordered behind that)
             if (b == 0) HIP_TRY(hipStreamWaitEvent(ucs, h->ev_in, 0));
             HIP_TRY(launch_flag_wait(h->call_flags.as<unsigned int>() + 64, (unsigned int)(b + 1) * (unsigned int)call_wgs, h->spin_limit, h->err_dev, ucs));
+            if (b < n_tiled) {
+                const int rt_b = (int)(((long)nb * (long)rows + 383) / 384);
+                HIP_TRY(launch_flag_wait(h->gemm_flags.as<unsigned int>() + 128 + h->gemm_flags_cap + b, (unsigned int)(rt_b * (v_cols_all / 256)),
+                                         h->spin_limit, h->err_dev, ucs));
+            }
             pipe.last_snew = h->P_ws[set].as<float>() + (size_t)v_cols_all; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
         } else {
             HIP_TRY(hipEventRecord(h->ev_s[set], ls));
@@ -1689,6 +1744,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (int rc = pipe.launch_alpha(nb, slot0, vs, b == n_batches - 1)) return rc;
         if (int rc = pipe.launch_uc(plan->inf, true, nb, slot0, r_rows, h->P_ws[set].as<float>(),
                                     sks[b], sss[b], ctx + (size_t)c0 * chunk_ctx, ucs)) return rc;
+        if (use_gemm_call) HIP_TRY(launch_flag_set(h->gemm_flags.as<unsigned int>() + 64, (unsigned int)(b + 1), ucs));   // the output set of sub-batch b is free again
         HIP_TRY(hipEventRecord(h->ev_uc[set], ucs));
         uc_pending[set] = true;
         HIP_TRY(hipEventRecord(h->ev_r[rset], ucs));

@@ -542,13 +542,16 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
             const ChainCallDesc* cd = a.call;                                 // (uniform address: scalar loads)
             const int cb = i / a.call_sub, li = i - cb * a.call_sub;
             if ((unsigned int)cb >= ready_seen) {
-                const unsigned int* ready = cd->ready;
+                // sub-batch cb is projected: its S' tiles are counted in (call-long GEMM), or the per-sub-batch GEMM's flag has passed it
+                const bool tiled = cd->tiles_s != nullptr && cb < cd->n_tiled;
+                const unsigned int* ready = tiled ? cd->tiles_s + cb : cd->ready;
+                const unsigned int need = tiled ? (unsigned int)(cb == cd->n_tiled - 1 ? cd->tiles_last : cd->tiles_full) : (unsigned int)cb + 1u;
                 long long* stats = (b == 0) ? cd->stats : nullptr;
                 long long t0 = 0;
                 int spins = 0;
                 for (;;) {
                     const unsigned int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (v > (unsigned int)cb) { ready_seen = v; break; }
+                    if (v >= need) { ready_seen = tiled ? (unsigned int)cb + 1u : v; break; }
                     if (spins == 0 && stats != nullptr) t0 = wall_clock64();
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > a.spin_limit) { __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ready_seen = 0xffffffffu; break; }   // (failed: no further waits)
@@ -1332,9 +1335,23 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
         }
     }
 #endif
-    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds, stream, a);
-    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds, stream, a);
-    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds, stream, a);
+    // (experiments: INFV_ALPHA_LDS pads the workgroup's LDS -- who may share a CU with whom is decided by LDS and registers)
+    static const size_t lds_pad = [] { const char* e = exp_env("INFV_ALPHA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    size_t lds_launch = lds;
+    if (lds_pad > lds_launch && lds_pad <= 160 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_rows2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_rows2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(alpha_rows2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        lds_launch = lds_pad;
+    }
+    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
+    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
+    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
     return hipGetLastError();
 }
 

@@ -162,7 +162,9 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
 // ---- role S of a whole sub-batch in one persistent launch (ltm_chain_batch.hip) ----
 // description of a call-long launch's sub-batches
 struct ChainCallDesc {
-    const unsigned int* ready;      // sub-batches of this call whose projection GEMM is complete (flag_set_kernel on the GEMM's stream)
+    const unsigned int* tiles_s;    // [b] S' tiles of sub-batch b the call-long projection GEMM has completed, for b < n_tiled; or nullptr
+    int n_tiled, tiles_full, tiles_last;   // sub-batches covered by it; S' tiles of a full sub-batch / of sub-batch n_tiled - 1
+    const unsigned int* ready;      // (the other sub-batches) sub-batches whose projection GEMM is complete (flag_set_kernel on the GEMM's stream)
     unsigned int* done;             // every workgroup adds 1 per sub-batch once the steps it published are written back (flag_wait_kernel on the UC stream polls it)
     int sub;                        // steps per sub-batch (the last one may be shorter)
     int n_batches;                  // sub-batches of the launch

@@ -560,22 +560,13 @@ constexpr int kYLds = 2 * kYStage;
 constexpr int kYPiecesA = 3 * (kYRowsA / 32), kYPieces = kYPiecesA + 3 * (kYRowsB / 32);   // 36 + 24 pieces of 1 KiB per k-tile
 }  // namespace
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6_wide_kernel(SplitGemm6 g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// one 384 x 256 output tile at (m0, n0); WRITE_THROUGH: the stores leave this XCD's L2 before the function returns (the call-long
+// kernel's consumers are other kernels that run while it is still resident)
+template <bool WRITE_THROUGH>
+__device__ __forceinline__ void x6_wide_tile(const SplitGemm6& g, unsigned char* smem, int m0, int n0) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    wg_stamp_begin(g.wg_stamps);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    int bx = blockIdx.x, by = blockIdx.y;
-    {   // XCD-aware tile order (see split_gemm_kernel): the tiles that share B rows run on one XCD at the same time
-        const unsigned nwg = gridDim.x * gridDim.y;
-        const unsigned orig = blockIdx.x + gridDim.x * blockIdx.y;
-        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
-        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = (int)(v % gridDim.x);
-        by = (int)(v / gridDim.x);
-    }
-    const int m0 = bx * kYRowsA, n0 = by * kYRowsB;
     const int ntiles = g.K / 16;
     typedef int v4i __attribute__((ext_vector_type(4)));
     auto make_rsrc = [](const __bf16* p, int bytes) {
@@ -586,7 +577,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int a_bytes = ntiles * g.M * 32, b_bytes = ntiles * g.N * 32;         // (below 2^31: checked by the launcher)
     const v4i ra0 = make_rsrc(g.A[0], a_bytes), ra1 = make_rsrc(g.A[1], a_bytes), ra2 = make_rsrc(g.A[2], a_bytes);
     const v4i rb0 = make_rsrc(g.B[0], b_bytes), rb1 = make_rsrc(g.B[1], b_bytes), rb2 = make_rsrc(g.B[2], b_bytes);
-    auto dma16 = [](const v4i& rsrc, unsigned lds_addr, int voff, int soff) {   // (assembly: see split_gemm_wide_kernel)
+    auto dma16 = [](const v4i& rsrc_, unsigned lds_addr, int voff, int soff) {   // (assembly: see split_gemm_wide_kernel)
+        v4i rsrc = rsrc_;
+        if (WRITE_THROUGH) {
+            // (in the call-long kernel's loop the allocator parks these uniform values in vector registers and hands them to the "s"
+            //  operand as they are: pull them back component by component)
+            rsrc.x = __builtin_amdgcn_readfirstlane(rsrc_.x); rsrc.y = __builtin_amdgcn_readfirstlane(rsrc_.y);
+            rsrc.z = __builtin_amdgcn_readfirstlane(rsrc_.z); rsrc.w = __builtin_amdgcn_readfirstlane(rsrc_.w);
+        }
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
     };
@@ -661,7 +659,114 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int o = n0 + wn * 128 + j * 32 + li;
                 if (m < g.M) __builtin_nontemporal_store(acc[i][j][r], &g.C[(long)m * g.ldc + o]);
             }
+    if (WRITE_THROUGH) {
+        // every store of the tile has reached this XCD's L2 (vmcnt), then one wave pushes the L2's dirty lines out (release)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 0) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6_wide_kernel(SplitGemm6 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    wg_stamp_begin(g.wg_stamps);
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware tile order (see split_gemm_kernel): the tiles that share B rows run on one XCD at the same time
+        const unsigned nwg = gridDim.x * gridDim.y;
+        const unsigned orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = (int)(v % gridDim.x);
+        by = (int)(v / gridDim.x);
+    }
+    x6_wide_tile<false>(g, smem, bx * kYRowsA, by * kYRowsB);
     wg_stamp_end(g.wg_stamps);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The projection GEMM of a WHOLE consolidate call as ONE resident launch (round 5): a few workgroups per XCD (the same number on
+// every XCD: the static block -> XCD deal of every other launch then sees eight equal XCDs) claim 384 x 256 tiles from a
+// queue -- sub-batch by sub-batch, a sub-batch's S' column tiles (what role S waits for) before its V' tiles -- wait for the
+// pooling launch to have written the sub-batch's rows (its completion count) and for the UC kernel that last read the output
+// set, run the tile, push it out of the L2 and count it into the sub-batch's S' / V' word.  Per-sub-batch launches of
+// gemm_x6_wide_kernel each needed an EMPTY CU 63 times per sub-batch (~100 us of empty CU-time per workgroup, residency stamps).
+// ------------------------------------------------------------------------------------------------------
+__global__ void gemm_call_desc_kernel(GemmCallDesc* dst, GemmCallDesc v) { if (threadIdx.x == 0) *dst = v; }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x6_call_kernel(const GemmCallDesc* __restrict__ dp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned int s_tile;
+    const int tid = threadIdx.x;
+    const GemmCallDesc& d = *dp;                                               // (device memory: the tile body needs the scalar registers)
+    const int n_batches = __builtin_amdgcn_readfirstlane(d.n_batches), sub_rows = __builtin_amdgcn_readfirstlane(d.sub_rows);
+    const int n_sets = __builtin_amdgcn_readfirstlane(d.n_sets), s_col_tile0 = __builtin_amdgcn_readfirstlane(d.s_col_tile0);
+    const int ct_n = __builtin_amdgcn_readfirstlane(d.N) / kYRowsB;            // column tiles of the output
+    const int rt_full = (sub_rows + kYRowsA - 1) / kYRowsA;
+    const int tiles_full = rt_full * ct_n;
+    const int rows_last = __builtin_amdgcn_readfirstlane((int)(d.total_rows - (long)(n_batches - 1) * sub_rows));
+    const int rt_last = (rows_last + kYRowsA - 1) / kYRowsA;
+    const unsigned int total = (unsigned int)((n_batches - 1) * tiles_full + rt_last * ct_n);
+    bool failed = false;
+    for (;;) {
+        __syncthreads();                                                       // (s_tile of the previous round has been read)
+        if (tid == 0) s_tile = atomicAdd(d.tile_ctr, 1u);
+        __syncthreads();
+        const unsigned int t = __builtin_amdgcn_readfirstlane(s_tile);     // (uniform: the operand resources below live in scalar registers)
+        if (t >= total) break;
+        int b = (int)(t / (unsigned)tiles_full);
+        if (b > n_batches - 1) b = n_batches - 1;
+        const int lt = (int)(t - (unsigned)b * tiles_full);
+        const int Mb = (b == n_batches - 1) ? rows_last : sub_rows;
+        const int rt_b = (b == n_batches - 1) ? rt_last : rt_full;
+        const int n_s = (ct_n - s_col_tile0) * rt_b;                          // S' tiles of the sub-batch come first
+        int ct, rt; bool is_s;
+        if (lt < n_s) { is_s = true; ct = s_col_tile0 + lt / rt_b; rt = lt % rt_b; }
+        else { is_s = false; const int lv = lt - n_s; ct = lv / rt_b; rt = lv % rt_b; }
+        if (tid == 0 && !failed) {
+            // the sub-batch's rows are written (pooling launch) and the output set is free (the UC kernel of sub-batch b - n_sets is done)
+            int spins = 0;
+            while (__hip_atomic_load(d.pool_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)Mb ||
+                   (b >= n_sets && __hip_atomic_load(d.uc_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)(b - n_sets + 1))) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > d.spin_limit) { __hip_atomic_store(d.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); failed = true; break; }
+            }
+        }
+        __syncthreads();
+        // (the descriptor is read through vector loads -- the kernel stores to memory, so the compiler will not use scalar loads --
+        //  and the tile body needs its operand resources in scalar registers: make every field uniform by hand)
+        auto uni_ptr = [](const void* p) {
+            const unsigned long a = reinterpret_cast<unsigned long>(p);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            return reinterpret_cast<void*>(((unsigned long)hi << 32) | lo);
+        };
+        SplitGemm6 g;
+        const int Kd = __builtin_amdgcn_readfirstlane(d.K), Nd = __builtin_amdgcn_readfirstlane(d.N);
+        const long a_off = (long)b * __builtin_amdgcn_readfirstlane(d.sub_rows) * Kd;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            g.A[i] = static_cast<const __bf16*>(uni_ptr(d.A_all[i])) + a_off;
+            g.B[i] = static_cast<const __bf16*>(uni_ptr(d.B[i]));
+        }
+        g.lda = Kd; g.ldb = Kd; g.C = static_cast<float*>(uni_ptr(d.C_set[b % n_sets]));
+        g.ldc = (long)__builtin_amdgcn_readfirstlane((int)d.ldc); g.M = (int)Mb; g.N = Nd; g.K = Kd; g.wg_stamps = nullptr; g.narrow = 0;
+        x6_wide_tile<true>(g, smem, rt * kYRowsA, ct * kYRowsB);
+        if (tid == 0) __hip_atomic_fetch_add((is_s ? d.done_s : d.done_v) + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+hipError_t launch_gemm_x6_call(const GemmCallDesc& d, GemmCallDesc* d_dev, int n_wgs, hipStream_t stream) {
+    if (d.n_batches <= 0 || n_wgs <= 0) return hipSuccess;
+    if (d.sub_rows % 32 || d.total_rows % 32 || d.N % kYRowsB || d.K % 16 || (long)(d.K / 16) * d.sub_rows * 32 >= (1l << 31) ||
+        (long)(d.K / 16) * d.N * 32 >= (1l << 31) || d.n_sets <= 0 || d.n_sets > 8) return hipErrorInvalidValue;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_call_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kYLds);   // (+ the static tile word: below the CU's 160 KB)
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_call_desc_kernel, dim3(1), dim3(64), 0, stream, d_dev, d);
+    hipLaunchKernelGGL(gemm_x6_call_kernel, dim3(n_wgs), dim3(512), kYLds, stream, d_dev);
+    return hipGetLastError();
 }
 
 bool gemm_x6_wide_applies(const SplitGemm6& g) {

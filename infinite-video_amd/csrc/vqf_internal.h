@@ -71,6 +71,26 @@ struct SplitGemm6 {
     int narrow;                      // 1: the 128 x 128 kernel even where the 384 x 256 one applies (tests: the two agree bit for bit)
 };
 hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream);
+// the projection GEMM of a whole consolidate call as one resident launch (gemm_x6_call_kernel): sub-batch b multiplies rows
+// [b * sub_rows, ...) of the k-tile-major planes A_all (per sub-batch: split3's layout with rows_total = the sub-batch's rows) by the
+// [N][K] planes B into output set b % n_sets
+struct GemmCallDesc {
+    const __bf16* A_all[3];
+    const __bf16* B[3];
+    float* C_set[8]; int n_sets;
+    long ldc; int N, K;
+    int sub_rows;                    // rows of a full sub-batch
+    long total_rows;                 // rows of all sub-batches of the launch
+    int n_batches;
+    int s_col_tile0;                 // first 256-column tile of the S' block (the tiles from there on are a sub-batch's first)
+    const unsigned int* pool_done;   // [b] rows of sub-batch b the pooling launch has written
+    const unsigned int* uc_done;     // sub-batches whose UC kernel has finished
+    unsigned int* tile_ctr;          // next tile of the queue
+    unsigned int* done_s;            // [b] S' tiles of sub-batch b complete (role S's loaders poll it)
+    unsigned int* done_v;            // [b] V' tiles complete (the UC stream's wait kernel)
+    unsigned int* error; int spin_limit;
+};
+hipError_t launch_gemm_x6_call(const GemmCallDesc& d, GemmCallDesc* d_dev, int n_wgs, hipStream_t stream);   // d_dev: device memory for the descriptor
 // x [rows][cols] fp32 = rows row0.. of an operand with rows_total rows -> p0 + p1 + p2 = x, bf16 planes in k-tile-major order
 // (element (r, c) at ((c / 16) * rows_total + r) * 16 + c % 16); cols % 16 == 0
 hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, void* p0, void* p1, void* p2, long row0, long rows_total,

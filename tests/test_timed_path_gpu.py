@@ -287,6 +287,8 @@ _VARIANTS = [
     {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
     {"INFV_CHAIN_CALL": "0"},                                  # one role-S launch per sub-batch (rounds 1-4) instead of one per call, same mailbox exchange
     {"INFV_POOL_CALL": "0"},                                   # one pooling launch per sub-batch + split3_rows_kernel instead of the call-long pooling launch
+    {"INFV_GEMM_CALL": "0"},                                   # one projection-GEMM launch per sub-batch instead of the resident tile-queue kernel
+    {"INFV_GEMM_WGS": "7"},                                    # the resident GEMM kernel with 7 workgroups (tiles of one sub-batch spread over several rounds)
     {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_CALL": "0"},           # ... with the atomics exchange: exactly round 4's role S (against the atomics baseline)
     {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_RPW": "1"},            # 8-row chain tiles (96 workgroups) as in round 2 (atomics exchange: the totals do not depend on the tiling)
     {"INFV_PROJ_X6": "0", "INFV_VPROJ_ON_UC": "1"},            # (fp32-MFMA GEMM) V' half of the projection as its own GEMM on the UC stream
