@@ -150,6 +150,7 @@ struct infv_ltm_s {
     // six products, fp32 accumulation: split_gemm.hip, gemm_x6_wide_kernel); INFV_PROJ_X6=0 at create selects gemm_nt_lw_kernel's
     // fp32 MFMAs instead (rounds 1-3's default).  Planes of [Wv ; q~] are made once per call, of a sub-batch's new rows per launch.
     DeviceBuf w3[3], r3[3];
+    DeviceBuf r3_ring[kRSets][3];      // bf16 planes of the new rows written by the pooling kernel itself, one set per R set
     bool proj_x6 = true, w3_valid = false;
     hipStream_t side = nullptr;
     hipStream_t pools = nullptr;        // stream of the pooling kernels (HBM-bound; runs ahead of the GEMM stream)
@@ -1007,7 +1008,7 @@ struct FastPipe {
 
     // the persistent role S leaves SCORES in the alpha ring: turn the `n` slots from slot0 into softmax weights + row sums
     int launch_alpha(int n, long slot0, hipStream_t s, bool last_batch) {
-        if (skip_mask() & 4) return INFV_OK;
+        if (skip_mask() & (4 | 16)) return INFV_OK;                 // (timing experiments: 4 = no UC and no alpha launches, 16 = no alpha, 32 = no UC)
         if (last_v2) {
             // chain_batch3_kernel published point scores + drawn bins: rebuild the full score rows, then the weights
             AlphaRows2Args r;
@@ -1059,7 +1060,7 @@ struct FastPipe {
                         hb[1] - hb[0], hb[2] - hb[1], hb[3] - hb[2], hb[4] - hb[3], hb[5] - hb[4], hb[6] - hb[5], hb[7] - hb[6], hb[7] - hb[0]);
             }
             Timed t_(h->prof, INFV_KERNEL_UC, ucs);
-            if (!(skip_mask() & 4)) HIP_TRY(::infv::launch_uc(u, ucs));
+            if (!(skip_mask() & (4 | 32))) HIP_TRY(::infv::launch_uc(u, ucs));
         }
         h->cur ^= 1;
         h->has_memory = true;
@@ -1466,12 +1467,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // ... and ONE pooling launch for the whole call: no launch boundaries on the HBM stream (with role S resident nothing but the
     // projection GEMM still needs an empty CU), rows and their bf16 planes for the whole call in HBM (402 + 604 MB at 2048 chunks),
     // the GEMM stream follows it through per-sub-batch completion counts
-    static const bool pool_call_env = [] { const char* e = exp_env("INFV_POOL_CALL"); return !e || atoi(e) != 0; }();
+    static const bool pool_call_env = [] { const char* e = exp_env("INFV_POOL_CALL"); return e && atoi(e) != 0; }();
     const bool use_pool_call = use_call && use_pr2 && pool_call_env && pr_wgs == 0 && !(skip_mask() & 1);
     const bool planes_call = use_pool_call && h->proj_x6 && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks);
     // ... and ONE projection-GEMM launch: a few resident workgroups per XCD on a tile queue (gemm_x6_call_kernel).  Sub-batches it
     // covers: every one of >= 1024 rows (all but, possibly, a short last one: that one keeps its own launch behind the resident kernel)
-    static const bool gemm_call_env = [] { const char* e = exp_env("INFV_GEMM_CALL"); return !e || atoi(e) != 0; }();
+    static const bool gemm_call_env = [] { const char* e = exp_env("INFV_GEMM_CALL"); return e && atoi(e) != 0; }();
     static const int gemm_wgs = [] { const char* e = exp_env("INFV_GEMM_WGS"); const int v = e ? atoi(e) : 32; return v > 0 ? v : 32; }();
     int n_tiled = 0;
     if (planes_call && gemm_call_env && h->w3_valid && !(skip_mask() & 2) && (sub * rows) % 32 == 0 && (long)sub * rows >= 1024 &&
@@ -1523,6 +1524,19 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             }
         }
     }
+    // per-sub-batch pooling launches: the kernel writes the bf16 planes of its rows too (no split3_rows_kernel, no re-read of R)
+    static const bool planes_env = [] { const char* e = exp_env("INFV_POOL_PLANES"); return !e || atoi(e) != 0; }();
+    const bool planes_in_pool = planes_env && use_pr2 && !use_pool_call && h->proj_x6 && h->w3_valid && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks) && n_batches > 0;
+    std::vector<char> planes_by_pool(n_batches > 0 ? n_batches : 1, 0);
+    if (planes_in_pool) {
+        const size_t need3r = (size_t)sub * rows * h->d * sizeof(__bf16);
+        bool grow3 = false;
+        for (int i = 0; i < kRSets; ++i) grow3 = grow3 || need3r > h->r3_ring[i][0].bytes;
+        if (grow3) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < kRSets; ++i) for (int j = 0; j < 3; ++j) HIP_TRY(h->r3_ring[i][j].reserve(need3r));
+        }
+    }
     auto stage_pool = [&](int b) -> int {                      // frame means (or directly the new rows) of batch b, on `pools`
         if (kbar_pre || use_pool_call) return INFV_OK;
         int c0, nb; batch_range(b, &c0, &nb);
@@ -1530,10 +1544,16 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         if (use_pr) {
             // R set rset was last read by the UC kernel (and the projections) of batch b - kRSets
             if (r_pending[rset]) HIP_TRY(hipStreamWaitEvent(pools, h->ev_r[rset], 0));
+            planes_by_pool[b] = false;
             if (!(skip_mask() & 1)) {
+                // the pooling kernel also writes the rows' bf16 planes when the six-product GEMM will read them (>= 1024 rows)
+                void* pl[3] = {h->r3_ring[rset][0].p, h->r3_ring[rset][1].p, h->r3_ring[rset][2].p};
+                const bool want_planes = planes_in_pool && (long)nb * (long)rows >= 1024;
+                bool done = false;
                 Timed t_(h->prof, INFV_KERNEL_POOL, pools);
                 HIP_TRY(launch_pool_rows2(k + c0 * chunk_k, h->k_bf16, nb, T, h->P, h->d, plan->inf.view(), h->R_ws[rset].as<float>(),
-                                          pools, pr_u, pr_pad, pr_wgs));
+                                          pools, pr_u, pr_pad, pr_wgs, want_planes ? pl : nullptr, &done));
+                planes_by_pool[b] = done;
             }
             if (split_pool) HIP_TRY(hipEventRecord(h->ev_pool[set], pools));
             return INFV_OK;
@@ -1560,6 +1580,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         const float* kb = kbar_pre ? kbar_pre + (size_t)c0 * T * h->d : h->kbar_side[set].as<float>();
         const float* r_ext = nullptr;
         void* pl_ext[3] = {nullptr, nullptr, nullptr};
+        if (!use_pool_call && planes_by_pool[b]) for (int i = 0; i < 3; ++i) pl_ext[i] = h->r3_ring[rset][i].p;
         if (use_pool_call) {
             // the rows of sub-batch b are complete once every (chunk, row) workgroup of the pooling launch has counted itself in
             HIP_TRY(launch_flag_wait(h->pool_done.as<unsigned int>() + b, (unsigned int)((size_t)nb * rows), h->spin_limit, h->err_dev, side));
@@ -1568,7 +1589,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             if (planes_call) for (int i = 0; i < 3; ++i) pl_ext[i] = h->planes_all[i].as<__bf16>() + off;
         }
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
-                                         h->vproj_on_uc(n_chunks), rset, use_pr, r_ext, planes_call ? pl_ext : nullptr)) return rc;
+                                         h->vproj_on_uc(n_chunks), rset, use_pr, r_ext, (planes_call || planes_by_pool[b]) ? pl_ext : nullptr)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         if (use_call) {

@@ -399,6 +399,7 @@ __device__ inline float mailbox_total(const unsigned long long* mbox, int L, int
     return t;
 }
 
+#ifdef INFV_EXPERIMENTS
 // part[l][0][j] = total of bin j of the step whose mailboxes have parity `parity` (fast path -> per-call path hand-over)
 __global__ void mailbox_to_part_kernel(const unsigned long long* __restrict__ mbox, int L, int G, int parity, int parts_pitch, float* __restrict__ part) {
     const int l = blockIdx.x, j = threadIdx.x;
@@ -409,6 +410,9 @@ hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, 
     hipLaunchKernelGGL(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
     return hipGetLastError();
 }
+#else
+hipError_t launch_mailbox_to_part(const unsigned long long*, int, int, int, int, float*, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 __device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15; }
 
@@ -1414,17 +1418,23 @@ bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks) {
            n_blocks <= 384 && chain_batch_lds_bytes(N, S, rows, tabw) <= 100 * 1024;
 }
 
-// Variants of the persistent role S.  The shipped library launches ONE: 16-row tiles, mailbox exchange inside one XCD's L2, one
-// launch per call (round 5).  The experiments build can select 8-row tiles (INFV_CHAIN_RPW=1), the atomics exchange of rounds
-// 1-4 (INFV_CHAIN_XCD=0) and one launch per sub-batch (INFV_CHAIN_CALL=0) for A/B runs.
+// Variants of the persistent role S.  The shipped library launches ONE: 16-row tiles, atomics exchange, one launch per sub-batch.
+// The experiments build can select 8-row tiles (INFV_CHAIN_RPW=1), the mailbox exchange (INFV_CHAIN_XCD=1: inside one XCD's L2
+// with the XCD-aware grid, sc1 mailboxes with INFV_CHAIN_LINEAR=1) and ONE launch per call (INFV_CHAIN_CALL=1) for A/B runs.
+// Round 5 built the call-long forms of role S, of the pooling and of the projection GEMM and measured them on one box against
+// this form (docs/NOTEBOOK.md, round 5): a resident role S is 12 % faster alone (9.4 against 10.65 ms of chain per video) and
+// 10.2 ms without the pooling stream -- but whatever is resident holds its CUs for the whole call, the pooling stream's speed is
+// the number of CUs that can host one of its workgroups, and every all-resident combination ended 3-5 % SLOWER end to end than
+// launches that give their CUs back (14.0-14.2 against 13.4-13.6 ms); a layer's 24 workgroups on ONE XCD (the mailbox exchange
+// in one L2) made it 33 ms: every other launch deals its workgroups round-robin over the XCDs and is paced by the fullest one.
 constexpr int kDefRpw = 2;
 typedef void (*Chain3Fn)(ChainBatchArgs);
 bool chain_batch3_mailboxes() {
-    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_XCD"); return !e || atoi(e) != 0; }();
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_XCD"); return e && atoi(e) != 0; }();
     return want;
 }
 bool chain_call_long() {
-    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_CALL"); return !e || atoi(e) != 0; }();
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_CALL"); return e && atoi(e) != 0; }();
     return want;
 }
 static Chain3Fn chain3_fn(int rpw) {
@@ -1433,7 +1443,7 @@ static Chain3Fn chain3_fn(int rpw) {
     return rpw == 1 ? chain_batch3_kernel<1, false> : chain_batch3_kernel<2, false>;
 #else
     (void)rpw;
-    return chain_batch3_kernel<2, true>;
+    return chain_batch3_kernel<2, false>;
 #endif
 }
 
@@ -1512,6 +1522,7 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
     return (long)safe * cus >= n_blocks;
 }
 
+#ifdef INFV_EXPERIMENTS
 // ---- hand-offs of a call-long role-S launch.  GEMM stream -> role S: flag_set_kernel runs behind a sub-batch's projection GEMM (whose
 // end-of-kernel release has written its output back) and raises the count role S's loaders poll.  Role S -> UC stream:
 // flag_wait_kernel holds the UC stream until every role-S workgroup has counted the sub-batch in (ChainBatchArgs.done); the
@@ -1541,6 +1552,12 @@ hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, in
     hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
     return hipGetLastError();
 }
+
+#else
+hipError_t launch_chain_call_desc(ChainCallDesc*, const ChainCallDesc&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_flag_set(unsigned int*, unsigned int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_flag_wait(const unsigned int*, unsigned int, int, unsigned int*, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
     if (hipError_t e = chain_batch_attr()) return e;

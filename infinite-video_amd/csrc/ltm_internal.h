@@ -81,8 +81,10 @@ struct PoolCallDesc {
 };
 hipError_t launch_pool_rows2_call(const void* k, int k_bf16, int T, int P, int d, const OperatorView& op, const PoolCallDesc& pc,
                                   hipStream_t stream, int u, int lds_pad);
+// planes (or nullptr): the rows' three bf16 planes for the projection GEMM, k-tile-major over the launch's rows (split3's layout);
+// *planes_done says whether the launched kernel wrote them (the grid-stride and LDS-DMA variants of the experiments build do not)
 hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                             hipStream_t stream, int u, int lds_pad, int max_wgs = 0);
+                             hipStream_t stream, int u, int lds_pad, int max_wgs = 0, void* const* planes = nullptr, bool* planes_done = nullptr);
 int project_splitk(int M, int K);
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream);

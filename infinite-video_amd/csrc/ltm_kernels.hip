@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
     const int c4 = sl * 64 + lane;
     const bool col_ok = c4 < d4;
     const float fp = (float)P;
-    for (long rr = blockIdx.x; rr < n_rows_total; rr += gridDim.x) {
+    for (long rr = blockIdx.x; rr < n_rows_total; rr += CALL ? n_rows_total : (long)gridDim.x) {   // (rows + planes: one row per workgroup)
         const long c = rr / op.rows;
         const int r = (int)(rr - c * op.rows);
         const int fb = op.row_begin[r], fe = op.row_end[r];
@@ -268,9 +268,11 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
                     __builtin_amdgcn_raw_buffer_store_b64(v2, r2, voff, 0, 16 /* sc1 */);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(pc.done + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pc.done != nullptr) {                                   // (nullptr: one launch per sub-batch, the kernel boundary is the hand-off)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(pc.done + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 #ifdef INFV_EXPERIMENTS
@@ -398,9 +400,11 @@ constexpr int kPoolTidAddr = 0;           // pool_rows2_kernel: lane-id addresse
 
 template <class Tok>
 static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                                      hipStream_t stream, int u, int lds_pad, int max_wgs, const PoolCallDesc* call = nullptr) {
+                                      hipStream_t stream, int u, int lds_pad, int max_wgs, const PoolCallDesc* call = nullptr,
+                                      void* const* planes = nullptr, bool* planes_done = nullptr) {
     PoolCallDesc pc;
     memset(&pc, 0, sizeof(pc));
+    if (planes_done != nullptr) *planes_done = false;
     if (call != nullptr) { pc = *call; max_wgs = 0; }
     const int d4 = d / 4, slices = (d4 + 63) / 64;
     if (4 * slices * 64 > 1024) return hipErrorInvalidValue;
@@ -442,6 +446,14 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
         return hipGetLastError();
     }
 #endif
+    PoolCallDesc one;                                                         // rows + planes of ONE sub-batch: the call-long kernel without a completion count
+    if (call == nullptr && planes != nullptr && (long)grid == n_rows_total && n_rows_total * (long)d * 2 < (1l << 31)) {   // (a grid-stride grid writes rows only)
+        memset(&one, 0, sizeof(one));
+        one.sub = n_chunks; one.n_chunks = n_chunks; one.R_all = R;
+        for (int i = 0; i < 3; ++i) one.plane[i] = planes[i];
+        call = &one; pc = one;
+        if (planes_done != nullptr) *planes_done = true;
+    }
     long long* stamps = exp_stamps_reserve(WG_POOL, grid);
     static const int want_tid = [] { const char* e = exp_env("INFV_POOL_TID"); return e ? atoi(e) : kPoolTidAddr; }();
     const int tid_addr = (want_tid && d4 % 64 == 0) ? 1 : 0;               // every lane of every slice holds a column
@@ -460,16 +472,18 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
 }
 
 hipError_t launch_pool_rows2(const void* k, int k_bf16, int n_chunks, int T, int P, int d, const OperatorView& op, float* R,
-                             hipStream_t stream, int u, int lds_pad, int max_wgs) {
+                             hipStream_t stream, int u, int lds_pad, int max_wgs, void* const* planes, bool* planes_done) {
+    if (planes_done != nullptr) *planes_done = false;
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
-    return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs)
-                  : launch_pool_rows2_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs);
+    if (planes != nullptr && d % 16 != 0) return hipErrorInvalidValue;
+    return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs, nullptr, planes, planes_done)
+                  : launch_pool_rows2_t<TokF32>(k, n_chunks, T, P, d, op, R, stream, u, lds_pad, max_wgs, nullptr, planes, planes_done);
 }
 
 hipError_t launch_pool_rows2_call(const void* k, int k_bf16, int T, int P, int d, const OperatorView& op, const PoolCallDesc& pc,
                                   hipStream_t stream, int u, int lds_pad) {
     if (op.rows == 0 || pc.n_chunks == 0) return hipSuccess;
-    if (pc.R_all == nullptr || pc.done == nullptr || pc.sub <= 0) return hipErrorInvalidValue;
+    if (pc.R_all == nullptr || pc.sub <= 0) return hipErrorInvalidValue;
     return k_bf16 ? launch_pool_rows2_t<TokBF16>(k, pc.n_chunks, T, P, d, op, nullptr, stream, u, lds_pad, 0, &pc)
                   : launch_pool_rows2_t<TokF32>(k, pc.n_chunks, T, P, d, op, nullptr, stream, u, lds_pad, 0, &pc);
 }

@@ -683,6 +683,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wg_stamp_end(g.wg_stamps);
 }
 
+#ifdef INFV_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------------
 // The projection GEMM of a WHOLE consolidate call as ONE resident launch (round 5): a few workgroups per XCD (the same number on
 // every XCD: the static block -> XCD deal of every other launch then sees eight equal XCDs) claim 384 x 256 tiles from a
@@ -768,6 +769,10 @@ hipError_t launch_gemm_x6_call(const GemmCallDesc& d, GemmCallDesc* d_dev, int n
     hipLaunchKernelGGL(gemm_x6_call_kernel, dim3(n_wgs), dim3(512), kYLds, stream, d_dev);
     return hipGetLastError();
 }
+
+#else
+hipError_t launch_gemm_x6_call(const GemmCallDesc&, GemmCallDesc*, int, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 bool gemm_x6_wide_applies(const SplitGemm6& g) {
     return g.M > 0 && g.M % 32 == 0 && g.N % kYRowsB == 0 && g.K % 16 == 0 && (long)(g.K / 16) * g.M * 32 < (1l << 31) &&

@@ -166,25 +166,24 @@ def _kernel_names(lib, tmp_path):
 
 def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     """A/B variants live in the experiments build only: the shipped code object has ONE persistent role-S kernel (16-row tiles,
-    mailbox exchange inside one XCD's L2: the call-long launch of round 5), ONE instantiation per pooling form and token type it
-    can select, no LDS-DMA / atomics-exchange / 8-row-tile variants, none of the kernels deleted in round 4 (grid-stride fused
-    pooling, rolling double-buffered pooling, round 2-3's chain_batch2)."""
+    atomics exchange), ONE instantiation per pooling form and token type it can select, no LDS-DMA / mailbox / 8-row-tile
+    variants, none of round 5's call-long machinery (resident GEMM tile queue, flag hand-off kernels), none of the kernels deleted
+    in round 4 (grid-stride fused pooling, rolling double-buffered pooling, round 2-3's chain_batch2)."""
     shipped, exp = _kernel_names("libinfv_ltm.so", tmp_path), _kernel_names("libinfv_ltm_exp.so", tmp_path)
     def having(names, frag):
         return sorted(n for n in names if frag in n)
-    assert len(having(shipped, "chain_batch3_kernel")) == 1 and "Lb1" in having(shipped, "chain_batch3_kernel")[0]
-    for hand_off in ("flag_set_kernel", "flag_wait_kernel", "mailbox_to_part_kernel"):      # what the call-long launch needs around it
-        assert having(shipped, hand_off), hand_off
+    assert len(having(shipped, "chain_batch3_kernel")) == 1 and "Lb0" in having(shipped, "chain_batch3_kernel")[0]
     assert len(having(exp, "chain_batch3_kernel")) == 4
     for gone in ("chain_batch2_kernel", "pool_rows_kernel", "pool_frames_db_kernel"):
         assert not having(shipped, gone) and not having(exp, gone), gone
-    for exp_only in ("pool_rows2_dma_kernel",):
+    for exp_only in ("pool_rows2_dma_kernel", "mailbox_to_part_kernel", "gemm_x6_call_kernel", "flag_wait_kernel", "flag_set_kernel",
+                     "chain_call_desc_kernel", "gemm_call_desc_kernel"):
         assert not having(shipped, exp_only) and having(exp, exp_only), exp_only
     assert len(having(shipped, "pool_frames_kernel")) == 4          # {padded 512-thread, plain 256-thread} x {fp32, bf16 tokens}
-    assert len(having(shipped, "pool_rows2_kernel")) == 4           # {8, 4 loads per burst} x {fp32, bf16 tokens}
+    assert len(having(shipped, "pool_rows2_kernel")) == 8           # {8, 4 loads per burst} x {fp32, bf16 tokens} x {rows only, rows + bf16 planes}
     # the general-psi step (Gaussian family) and the dense step are product paths
     for needed in ("psi_gemm_kernel", "psi_update_kernel", "psi_masses_kernel", "psi_grid_kernel", "psi_ctx_kernel",
-                   "dense_update_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "gemm_nt_lw_kernel"):
+                   "dense_update_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "gemm_nt_lw_kernel", "gemm_x6_wide_kernel"):
         assert having(shipped, needed), needed
 
 

@@ -281,18 +281,20 @@ np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy(), B0=B[0], B1=B[1], bi
 '''
 
 # non-default variants kept in the sources (A/B material, experiments build only): each must reproduce the shipped default
+_CALL = {"INFV_CHAIN_CALL": "1"}                                # role S as ONE launch per call (round 5), atomics exchange
 _VARIANTS = [
     {},                                                        # the experiments build with no knob set
     {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
-    {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride
-    {"INFV_CHAIN_CALL": "0"},                                  # one role-S launch per sub-batch (rounds 1-4) instead of one per call, same mailbox exchange
-    {"INFV_POOL_CALL": "0"},                                   # one pooling launch per sub-batch + split3_rows_kernel instead of the call-long pooling launch
-    {"INFV_GEMM_CALL": "0"},                                   # one projection-GEMM launch per sub-batch instead of the resident tile-queue kernel
-    {"INFV_GEMM_WGS": "7"},                                    # the resident GEMM kernel with 7 workgroups (tiles of one sub-batch spread over several rounds)
-    {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_CALL": "0"},           # ... with the atomics exchange: exactly round 4's role S (against the atomics baseline)
-    {"INFV_CHAIN_XCD": "0", "INFV_CHAIN_RPW": "1"},            # 8-row chain tiles (96 workgroups) as in round 2 (atomics exchange: the totals do not depend on the tiling)
+    {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride (rows only: split3_rows_kernel makes the planes)
+    {"INFV_POOL_PLANES": "0"},                                 # the pooling kernel writes rows only, split3_rows_kernel makes the GEMM's bf16 planes (round 4)
+    _CALL,                                                     # call-long role S; pooling and GEMM launched per sub-batch
+    dict(_CALL, INFV_POOL_CALL="1"),                           # ... + ONE pooling launch per call (completion counts instead of launch boundaries)
+    dict(_CALL, INFV_POOL_CALL="1", INFV_GEMM_CALL="1"),       # ... + the projection GEMM as a resident tile-queue kernel (32 workgroups)
+    dict(_CALL, INFV_POOL_CALL="1", INFV_GEMM_CALL="1", INFV_GEMM_WGS="7"),   # ... with 7 workgroups: a sub-batch's tiles over several rounds
+    {"INFV_CHAIN_RPW": "1"},                                   # 8-row chain tiles (96 workgroups) as in round 2
     {"INFV_PROJ_X6": "0", "INFV_VPROJ_ON_UC": "1"},            # (fp32-MFMA GEMM) V' half of the projection as its own GEMM on the UC stream
-    {"INFV_CHAIN_XCD": "0", "INFV_PERSISTENT": "0"},           # one role-S launch per chunk (always the atomics exchange)
+    dict(_CALL, INFV_PROJ_X6="0", INFV_POOL_CALL="1"),         # (fp32-MFMA GEMM) call-long role S and pooling launch (rows only)
+    {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
     {"INFV_PROJ_X6": "0", "INFV_GEMM_LW": "0"},                # (fp32-MFMA GEMM) without loader waves
     {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
     {"INFV_POOL_TID": "1"},                                    # pooling kernel with lane-id addressed loads (no vector address operand)
@@ -305,17 +307,17 @@ _VARIANTS = [
 def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
     """A 70-chunk call (two 32-chunk sub-batches + a short one: split-K slabs) and a 5-chunk continuation, once with the
     shipped library and once per variant with the experiments build: contexts, memory and draws identical bit for bit (variants of
-    the fp32-MFMA projection GEMM against the shipped library with INFV_PROJ_X6=0)."""
+    the fp32-MFMA projection GEMM against the shipped library with INFV_PROJ_X6=0).  Includes round 5's call-long launches of
+    role S, of the pooling and of the projection GEMM: same arithmetic, other hand-offs (device-side flags instead of launch
+    boundaries)."""
     def run(env_add, name):
         path = str(tmp_path / name)
         _run_child(_VARIANT_CHILD, env_add, path)
         return {k_: v for k_, v in np.load(path).items()}
-    base = {"": run({}, "base.npz"), "0": run({"INFV_PROJ_X6": "0"}, "base_f32mfma.npz"),   # shipped library: default, and the fp32-MFMA GEMM
-            # the atomics exchange of rounds 1-4 (exact fixed-point totals; experiments build): the baseline of the variants that use it
-            "atomics": run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "0"}, "base_atomics.npz")}
+    base = {"": run({}, "base.npz"), "0": run({"INFV_PROJ_X6": "0"}, "base_f32mfma.npz")}   # shipped library: default, and the fp32-MFMA GEMM
     for i, v in enumerate(_VARIANTS):
         got = run(dict(v, INFV_LTM_LIBRARY="exp"), f"v{i}.npz")
-        want = base["atomics" if v.get("INFV_CHAIN_XCD") == "0" else v.get("INFV_PROJ_X6", "")]
+        want = base[v.get("INFV_PROJ_X6", "")]
         for key in want:
             if "INFV_PERSISTENT" in v and key in ("a", "b"):
                 # one role-S launch per chunk computes the read-out weights in the chain kernel itself (a lane per box n, n + 64, ..);
@@ -325,21 +327,24 @@ def test_kept_variants_reproduce_the_default_bit_for_bit(dev, tmp_path):
                 np.testing.assert_array_equal(want[key], got[key], err_msg=f"{v}: {key}")
 
 
-def test_xcd_local_mailbox_exchange_is_placement_independent(dev, tmp_path):
-    """The shipped role S exchanges its bin masses through mailboxes inside one XCD's L2 (XCD-aware grid + placement handshake,
-    csrc/ltm_chain_batch.hip).  The totals are fp32 sums of per-workgroup row sums in a fixed order; the atomics exchange of
-    rounds 1-4 (experiments build, INFV_CHAIN_XCD=0) has exact fixed-point totals: same draws (but for a flip within rounding of
-    a cdf edge), contexts and memory equal to fp32 rounding; and the result must not depend on the placement (sc1 mailboxes
-    when the handshake finds the layer on several XCDs: forced with INFV_S_FLAGS=32) -- bit for bit."""
+def test_mailbox_exchange_variants(dev, tmp_path):
+    """INFV_CHAIN_XCD=1 (experiments build): role S exchanges its bin masses through mailboxes (inside one XCD's L2 with the
+    XCD-aware grid + placement handshake, csrc/ltm_chain_batch.hip).  The totals are fp32 sums of per-workgroup row sums in a fixed
+    order instead of the exact fixed-point totals of the atomics exchange: same draws (but for a flip within rounding of a cdf
+    edge), contexts and memory equal to fp32 rounding; the result must not depend on the placement (sc1 mailboxes when the
+    handshake finds the layer on several XCDs: forced with INFV_S_FLAGS=32, or a linear grid: INFV_CHAIN_LINEAR=1) nor on whether
+    role S is launched per sub-batch or once per call -- bit for bit."""
     def run(env_add, name):
         path = str(tmp_path / name)
         _run_child(_VARIANT_CHILD, env_add, path)
         return {k_: v for k_, v in np.load(path).items()}
-    xcd = run({}, "xcd.npz")                                                                 # the shipped default
-    base = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "0"}, "base.npz")            # atomics exchange
-    far = run({"INFV_LTM_LIBRARY": "exp", "INFV_S_FLAGS": "32"}, "far.npz")
-    for key in base:
-        np.testing.assert_array_equal(xcd[key], far[key], err_msg=f"placement changed {key}")
+    base = run({}, "base.npz")
+    xcd = run({"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_XCD": "1"}, "xcd.npz")
+    for name, env in (("far", {"INFV_S_FLAGS": "32"}), ("linear", {"INFV_CHAIN_LINEAR": "1"}), ("call", {"INFV_CHAIN_CALL": "1"}),
+                      ("call_linear", {"INFV_CHAIN_CALL": "1", "INFV_CHAIN_LINEAR": "1", "INFV_POOL_CALL": "1", "INFV_GEMM_CALL": "1"})):
+        other = run(dict(env, INFV_LTM_LIBRARY="exp", INFV_CHAIN_XCD="1"), name + ".npz")
+        for key in base:
+            np.testing.assert_array_equal(xcd[key], other[key], err_msg=f"{name} changed {key}")
     assert int((base["bins"] != xcd["bins"]).sum()) <= 1
     for key in ("a", "b"):
         assert float(np.abs(base[key] - xcd[key]).max()) <= 1e-5, key
