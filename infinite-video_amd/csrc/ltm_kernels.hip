@@ -314,87 +314,11 @@ extern "C" long infv_exp_wg_stamps(long long* host, long cap) {
 }
 #endif
 
-#ifdef INFV_EXPERIMENTS
-// ------------------------------------------------------------------------------------------------------
-// 2d. pool_rows2_kernel with the token rows streamed global -> LDS directly (`buffer_load_dwordx4 ... lds`, no VGPR destination):
-//     NB 1-KiB pieces in flight per wave, each lane reads back its own 16 bytes and adds them in token order -- the same
-//     arithmetic in the same order.  Experiment (INFV_POOL_DMA=1, fp32 tokens): beside a projection-GEMM workgroup the register
-//     loads of pool_rows2_kernel complete three times slower (the adds are not the cause, tools/sweep_r04x.sh); does a load
-//     that never writes the vector register file fare better?
-// ------------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(1024) void pool_rows2_dma_kernel(const float* __restrict__ k, long chunk_stride, int P, int d4, int slices,
-                                                              OperatorView op, long n_rows_total, float* __restrict__ R,
-                                                              long long* __restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) float prd_lds[];           // [4 frames][d4] float4 park, then NB KiB per wave
-    floatx4* park = reinterpret_cast<floatx4*>(prd_lds);
-    wg_stamp_begin(stamps);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fi = wave / slices, sl = wave - fi * slices;
-    const int c4 = sl * 64 + lane;
-    const bool col_ok = c4 < d4;
-    const float fp = (float)P;
-    float* ring = prd_lds + 16 * d4 + wave * (NB * 256);                      // this wave's NB pieces of 64 lanes x 16 bytes
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    for (long rr = blockIdx.x; rr < n_rows_total; rr += gridDim.x) {
-        const long c = rr / op.rows;
-        const int r = (int)(rr - c * op.rows);
-        const int fb = op.row_begin[r], fe = op.row_end[r];
-        const float val = op.box_val[op.row_box[r]];
-        floatx4 racc = {0.f, 0.f, 0.f, 0.f};
-        for (int f0 = fb; f0 < fe; f0 += 4) {
-            const int f = f0 + fi;
-            if (f < fe) {                                                   // (wave-uniform; lanes past the row's width read out of range: 0)
-                const float* frame = k + (c * chunk_stride + (long)f * P * d4) * 4;
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(frame), 0, P * d4 * 16, 0x00020000);
-                const int voff = col_ok ? c4 * 16 : 0x7ffffff0, row_bytes = d4 * 16;
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ring + b * 256), 16, voff, b * row_bytes, 0, 2 /* nt */);
-                int b = 0;
-                for (int p = 0; p < P - NB; ++p) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB - 1) : "memory");   // piece p has landed (pieces complete in order)
-                    const floatx4 v = *reinterpret_cast<const floatx4*>(ring + b * 256 + lane * 4);
-                    acc += v;
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ring + b * 256), 16, voff, (p + NB) * row_bytes, 0, 2);
-                    b = (b + 1 == NB) ? 0 : b + 1;
-                }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {                               // the last NB pieces: nothing new in flight behind them
-                    if (j == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB - 1) : "memory");
-                    else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 2 ? NB - 2 : 0) : "memory");
-                    else if (j == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 3 ? NB - 3 : 0) : "memory");
-                    else if (j == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 4 ? NB - 4 : 0) : "memory");
-                    else if (j == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB >= 5 ? NB - 5 : 0) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const floatx4 v = *reinterpret_cast<const floatx4*>(ring + b * 256 + lane * 4);
-                    acc += v;
-                    b = (b + 1 == NB) ? 0 : b + 1;
-                }
-                acc.x /= fp; acc.y /= fp; acc.z /= fp; acc.w /= fp;
-                if (col_ok) park[fi * d4 + c4] = acc;
-            }
-            __syncthreads();
-            if (fi == 0 && col_ok) {
-                const int nf = min(4, fe - f0);
-                for (int j = 0; j < nf; ++j) {
-                    const floatx4 v = park[j * d4 + c4];
-                    racc.x = fmaf(val, v.x, racc.x); racc.y = fmaf(val, v.y, racc.y);
-                    racc.z = fmaf(val, v.z, racc.z); racc.w = fmaf(val, v.w, racc.w);
-                }
-            }
-            __syncthreads();
-        }
-        if (fi == 0 && col_ok) __builtin_nontemporal_store(racc, reinterpret_cast<floatx4*>(R) + rr * (long)d4 + c4);
-    }
-#ifdef INFV_EXPERIMENTS
-    if (stamps != nullptr) { __syncthreads(); wg_stamp_end(stamps); }
-#endif
-}
-
-#endif
+// (2d. A variant of pool_rows2_kernel that streamed the token rows global -> LDS directly (`buffer_load ... lds`, round 3's
+//  INFV_POOL_DMA=1) is gone: each wave read a piece right behind its own counted vmcnt wait, with no barrier in between -- LDS-DMA data
+//  is ordered for a ds_read only by that wait FOLLOWED by a barrier (cdna_hip_programming.md, "read a staged buffer one phase after
+//  the wait that retires it").  Round 5's variant test caught it: 1 run in 3 differed by 1.6e-4 in B, with round 4's library too.
+//  It was never faster than the register-load kernel either.)
 
 constexpr int kPoolTidAddr = 0;           // pool_rows2_kernel: lane-id addressed buffer loads (no vector address operand); INFV_POOL_TID in the experiments build
 
@@ -428,24 +352,6 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
     const dim3 block(4 * slices * 64);
     static const int prio = [] { const char* e = exp_env("INFV_POOL_PRIO"); return e ? atoi(e) : 0; }();
-#ifdef INFV_EXPERIMENTS
-    static const int want_dma = [] { const char* e = exp_env("INFV_POOL_DMA"); return e ? atoi(e) : 0; }();
-    if (want_dma && call == nullptr && sizeof(typename Tok::vec) == 16 && P >= 6 && slices == 3) {
-        // (12 waves x 6 KiB + 12 KiB of parked frame means = 84 KB: the padding size of the register-load kernel)
-        constexpr int NB = 6;
-        const size_t need = (size_t)16 * d4 * sizeof(float) + (size_t)4 * slices * NB * 1024;
-        size_t l2 = need > lds ? need : lds;
-        static bool attr_dma = false;
-        if (!attr_dma) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows2_dma_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_dma = true;
-        }
-        hipLaunchKernelGGL((pool_rows2_dma_kernel<NB>), dim3(grid), block, l2, stream, static_cast<const float*>(k), (long)T * P * d4, P, d4, slices, op,
-                           n_rows_total, R, exp_stamps_reserve(WG_POOL, grid));
-        return hipGetLastError();
-    }
-#endif
     PoolCallDesc one;                                                         // rows + planes of ONE sub-batch: the call-long kernel without a completion count
     if (call == nullptr && planes != nullptr && (long)grid == n_rows_total && n_rows_total * (long)d * 2 < (1l << 31)) {   // (a grid-stride grid writes rows only)
         memset(&one, 0, sizeof(one));

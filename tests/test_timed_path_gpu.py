@@ -296,7 +296,6 @@ _VARIANTS = [
     dict(_CALL, INFV_PROJ_X6="0", INFV_POOL_CALL="1"),         # (fp32-MFMA GEMM) call-long role S and pooling launch (rows only)
     {"INFV_PERSISTENT": "0"},                                  # one role-S launch per chunk
     {"INFV_PROJ_X6": "0", "INFV_GEMM_LW": "0"},                # (fp32-MFMA GEMM) without loader waves
-    {"INFV_POOL_DMA": "1"},                                    # pooling kernel with global -> LDS loads (no VGPR destination)
     {"INFV_POOL_TID": "1"},                                    # pooling kernel with lane-id addressed loads (no vector address operand)
     {"INFV_PROJ_X6": "0", "INFV_GEMM_SLICES": "2"},            # (fp32-MFMA GEMM) launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
