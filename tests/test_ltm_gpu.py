@@ -315,6 +315,54 @@ def test_gaussian_family_chain_matches_the_reference(dev, case):
         assert torch.equal(whole, torch.stack(outs))
 
 
+@pytest.mark.parametrize("case", GAUSS_CASES, ids=lambda c: c.name)
+def test_gaussian_family_with_the_products_own_plan(dev, case):
+    """The same chains with NOTHING injected: ``basis_maps.build_gaussian_plan`` supplies the ridge operators G on this box
+    (the inverse of the ill-conditioned Gaussian Gram matrix, long_term_attention_gibbs.py:68-84,167-174 and
+    basis_functions.py:135-164, through this host's LAPACK), so the product path -- host builder + device kernels -- is what
+    runs.  Held to the north-star tolerances: contexts 1e-3, B 1e-4 (relative to the golden's scale), probabilities 1e-3;
+    drawn bins are COUNTED against the reference's own draw, not required equal (an operator that differs in the 5th digit
+    moves the scores by ~1e-5 and may flip a draw within rounding of a cdf edge)."""
+    from infinite_video_amd.engine import LTMEngine
+    g = load_golden(case)
+    ks, qs, ws = case_inputs(case)
+    eng = LTMEngine(case.N, case.H, case.dh, case.d, case.P, tau=case.tau, sticky=case.sticky, n_layers=case.n_layers,
+                    max_q=case.Q, device=dev, gaussian_sigmas=GAUSS_SIGMAS)
+    for T in sorted(set(case.chunk_T)):
+        p = eng.ensure_plan(T)                                           # the product's own operators stay in place
+        assert p.dense and p.psi
+        # how far this host's operator is from the reference's (informational; the GPU box has other LAPACK threads / kernels)
+        gdiff = float(np.abs(p.inf_GT - g[f"T{T}_inf_G"].T).max() / np.abs(g[f"T{T}_inf_G"]).max())
+        print(f"[gaussian, own plan] T={T}: max |G - G_ref| / max |G_ref| = {gdiff:.2e}")
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    q = torch.from_numpy(np.stack(qs)).to(dev)
+    draws, flips, worst_ctx, worst_b = 0, 0, 0.0, 0.0
+    for c in range(len(case.chunk_T)):
+        new_doc = c in case.new_doc_at
+        u = np.stack([call_uniforms(case, c, l) for l in range(case.n_layers)])
+        if case.sticky and not new_doc:
+            # teacher-force the reference's own bins so that one flipped draw cannot send the rest of the chain elsewhere;
+            # the product's OWN draw (from its own probabilities) is read back and counted
+            for l in range(case.n_layers):
+                eng.set_bins(l, g[f"c{c}_l{l}_bins"])
+        ctx = eng.forward(torch.from_numpy(ks[c]).to(dev), q, projs, torch.from_numpy(u).to(dev), new_doc=new_doc).cpu().numpy()
+        for l in range(case.n_layers):
+            tag = f"c{c}_l{l}"
+            if case.sticky and not new_doc:
+                bins, _, probs = eng.last_draw(l)
+                np.testing.assert_allclose(probs, g[tag + "_probs"], rtol=1e-3, atol=1e-7)
+                d = bins != g[tag + "_bins"]
+                flips += int(d.sum()); draws += int(bins.size)
+                assert np.abs(bins[d] - g[tag + "_bins"][d]).max(initial=0) <= 1, "a differing draw is not an adjacent bin"
+            B, _ = eng.export_state(l)
+            scale = float(np.abs(g[tag + "_B"]).max())
+            worst_b = max(worst_b, float(np.abs(B.cpu().numpy() - g[tag + "_B"]).max()) / scale)
+            worst_ctx = max(worst_ctx, float(np.abs(ctx[l] - g[tag + "_ctx"]).max()))
+    print(f"[gaussian, own plan] {case.name}: ctx {worst_ctx:.2e}, B (relative) {worst_b:.2e}, {flips} of {draws} draws differ")
+    assert worst_ctx <= 1e-3 and worst_b <= 1e-4
+    assert flips <= max(2, draws // 500)
+
+
 def test_dense_update_with_the_gaussian_family_operator(dev):
     """Operator level, second basis family: the dense ``x . G`` kernel (fp32 MFMA) with the reference's GAUSSIAN ridge operator
     (every entry non-zero) reproduces the coefficients the REAL reference computes for a first chunk
