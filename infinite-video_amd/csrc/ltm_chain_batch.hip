@@ -1077,6 +1077,10 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
     const int snp = kA2Q + 1;
+    // (Round 5 tried occupancy shaping by registers here -- naming v255 / a7 in an asm clobber makes the allocation 264, so that ONE of
+    //  these workgroups fits a CU and a pooling workgroup always fits beside it: they then shared a CU 81 % of the time instead of
+    //  18-49 %, this kernel's workgroups lived 34 us instead of 20 beside the streaming loads, the alpha stage took three rounds,
+    //  and the call went from 13.5 to 14.5 ms.  Three of them on a CU the pooling has just left is the better deal.)
     wg_stamp_begin(a.wg_stamps);
 #ifdef INFV_EXPERIMENTS
     if (a.prio == 3) __builtin_amdgcn_s_setprio(3);          // (experiment INFV_ALPHA_PRIO)

@@ -320,9 +320,13 @@ def test_gaussian_family_with_the_products_own_plan(dev, case):
     """The same chains with NOTHING injected: ``basis_maps.build_gaussian_plan`` supplies the ridge operators G on this box
     (the inverse of the ill-conditioned Gaussian Gram matrix, long_term_attention_gibbs.py:68-84,167-174 and
     basis_functions.py:135-164, through this host's LAPACK), so the product path -- host builder + device kernels -- is what
-    runs.  Held to the north-star tolerances: contexts 1e-3, B 1e-4 (relative to the golden's scale), probabilities 1e-3;
-    drawn bins are COUNTED against the reference's own draw, not required equal (an operator that differs in the 5th digit
-    moves the scores by ~1e-5 and may flip a draw within rounding of a cdf edge)."""
+    runs.  Held to the north-star tolerance on what the op returns (contexts 1e-3; measured 1.1e-4) and on the probabilities
+    (1e-3); drawn bins are COUNTED against the reference's own draw, not required equal (an operator that differs in the 4th digit
+    moves the scores by ~1e-5 and may flip a draw within rounding of a cdf edge).  The coefficient matrix B itself is NOT
+    well-determined across hosts for this family: the Gram matrix of 256 overlapping Gaussians is ill-conditioned, this box's
+    inverse differs from the build container's by up to 9e-4 of max |G| (printed below) and B follows it (2.4e-3 of max |B|
+    measured) while B . psi -- everything the op computes from B -- does not move: B is held to 2e-2 of its scale here, and to
+    1e-4 with the golden's operators in test_gaussian_family_chain_matches_the_reference."""
     from infinite_video_amd.engine import LTMEngine
     g = load_golden(case)
     ks, qs, ws = case_inputs(case)
@@ -359,7 +363,7 @@ def test_gaussian_family_with_the_products_own_plan(dev, case):
             worst_b = max(worst_b, float(np.abs(B.cpu().numpy() - g[tag + "_B"]).max()) / scale)
             worst_ctx = max(worst_ctx, float(np.abs(ctx[l] - g[tag + "_ctx"]).max()))
     print(f"[gaussian, own plan] {case.name}: ctx {worst_ctx:.2e}, B (relative) {worst_b:.2e}, {flips} of {draws} draws differ")
-    assert worst_ctx <= 1e-3 and worst_b <= 1e-4
+    assert worst_ctx <= 1e-3 and worst_b <= 2e-2
     assert flips <= max(2, draws // 500)
 
 
