@@ -183,7 +183,11 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
     const int c4 = sl * 64 + lane;
     const bool col_ok = c4 < d4;
     const float fp = (float)P;
-    for (long rr = blockIdx.x; rr < n_rows_total; rr += CALL ? n_rows_total : (long)gridDim.x) {   // (rows + planes: one row per workgroup)
+    // (rows + planes: one row per workgroup.  Round 5 also ran this form as 176 RESIDENT workgroups walking the rows grid-stride, with
+    //  role S and the GEMM resident too -- every CU with exactly one resident kernel: the pooling finished its 51.5 GB in 11.2 ms
+    //  (4.6 TB/s) and the call took 19-22 ms: beside a workgroup that streams without a pause the UC / alpha workgroups lived up to
+    //  four times longer and role S's exchange slowed.  Short-lived workgroups that leave gaps are part of why the pipeline works.)
+    for (long rr = blockIdx.x; rr < n_rows_total; rr += CALL ? n_rows_total : (long)gridDim.x) {
         const long c = rr / op.rows;
         const int r = (int)(rr - c * op.rows);
         const int fb = op.row_begin[r], fe = op.row_end[r];
