@@ -540,6 +540,35 @@ def test_long_video_many_subbatches_matches_oracle(dev):
         np.testing.assert_allclose(out[l], ref, rtol=0, atol=CTX_TOL)
 
 
+@pytest.mark.parametrize("Q,L", [(16, 2), (8, 4), (8, 2), (24, 2)])
+def test_small_query_counts_take_their_documented_paths(dev, Q, L):
+    """INTEGRATION.md, "query counts": the persistent role-S kernel of the whole-video path works on 16-row query tiles and needs
+    more than 8 queries.  Q = 16 / 24: the fast path (one full tile / one full + one half tile per head).  Q = 8 with L * H * Q a
+    multiple of 128 (L = 4): the fast path with round 1's chain_batch_kernel (8-row tiles, scores kept whole; the shipped library
+    has no 8-row instantiation of chain_batch3_kernel).  Q = 8, L = 2 (L * H * Q = 192): per-chunk stage kernels.  Every one against
+    the CPU oracle, through the shipped library."""
+    from infinite_video_amd import synth
+    from infinite_video_amd.engine import LTMEngine
+    N, H, dh, d, P, T, Cn = 64, 12, 64, 768, 32, 8, 11
+    eng = LTMEngine(N, H, dh, d, P, tau=0.75, sticky=True, n_layers=L, max_q=Q, device=dev, max_batch_chunks=4)
+    ws = [synth.layer_projections(l, d, H * dh, seed=901) for l in range(L)]
+    projs = [tuple(_to(dev, *w)) for w in ws]
+    qs = np.stack([synth.layer_query(l, Q, H * dh, seed=902) for l in range(L)])
+    u = synth.gibbs_uniforms(Cn, L, seed=903)
+    ks = np.stack([synth.frame_tokens(c, T, P, d, seed=904) for c in range(Cn)])
+    ctx = eng.consolidate(torch.from_numpy(ks).to(dev), torch.from_numpy(qs).to(dev), projs,
+                          torch.from_numpy(u).to(dev), new_doc=True).cpu().numpy()
+    eng.sync()
+    orc = [O.ClosedFormOracle(N, H, dh, 0.75, True, *ws[l], tokens_per_frame=P) for l in range(L)]
+    for c in range(Cn):
+        for l in range(L):
+            ref = orc[l].step(ks[c], qs[l], new_doc=(c == 0), u=u[c, l])
+            np.testing.assert_allclose(ctx[c, l], ref, rtol=0, atol=CTX_TOL, err_msg=f"Q={Q} L={L} chunk {c} layer {l}")
+    for l in range(L):
+        np.testing.assert_array_equal(eng.last_draw(l)[0], orc[l].last_bins)
+        np.testing.assert_allclose(eng.export_state(l)[0].cpu().numpy(), orc[l].B_past, rtol=0, atol=B_TOL)
+
+
 def test_headline_shape_consolidate_in_pieces(dev):
     """BASELINE headline shape (T=256, N=256, 2 layers): 13 chunks consolidated in one call, in sub-batches of 5,
     and as two calls (7 + 6 chunks, second one continuing the memory) give the same video as the per-chunk
