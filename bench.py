@@ -37,7 +37,8 @@ T, P, D, N, H, DH, Q, L, TAU, S = 256, 32, 768, 256, 12, 64, 32, 2, 0.75, 512
 DM = H * DH
 BYTES_K = 4 * T * P * D                                            # 25 165 824
 ROWS, FRAMES_IN_ROWS = 64, 255                                     # new rows per chunk / frames they cover at (T, N, tau) above
-BYTES_POOL_PER_CHUNK = 4 * FRAMES_IN_ROWS * P * D + 4 * ROWS * D   # pool_rows2_kernel: read the covered frames of k, write R
+BYTES_POOL_ROWS_ONLY = 4 * FRAMES_IN_ROWS * P * D + 4 * ROWS * D   # pool_rows2_kernel<.., false> (infv_ltm_pool_rows): read the covered frames of k, write R
+BYTES_POOL_PER_CHUNK = BYTES_POOL_ROWS_ONLY + 3 * 2 * ROWS * D     # ... in the pipeline (round 5) it also writes the rows' three bf16 planes for the projection GEMM
 BYTES_LAYER = 4 * 2 * N * D + 4 * 2 * (D * DM + DM) + 4 * 2 * Q * DM + 4 * 2 * H * Q * N
 BYTES_PER_CHUNK = BYTES_K + L * BYTES_LAYER                        # 39 727 104
 
@@ -651,7 +652,7 @@ def main():
         eng.pool_rows(k[:nb])
     ev1.record()
     torch.cuda.synchronize()
-    alone_gbs = 5 * nb * BYTES_POOL_PER_CHUNK / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    alone_gbs = 5 * nb * BYTES_POOL_ROWS_ONLY / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
     # ---- roofline leg: one more pass with HIP events around every kernel launch ----
     eng.profile(True)
@@ -659,7 +660,10 @@ def main():
     prof = eng.profile_read()
     eng.profile(False)
     pool_n, pool_ms = prof["pool"]
-    pool_bytes = c_local * BYTES_POOL_PER_CHUNK
+    # (the planes are written for sub-batches of >= 1024 rows when the default six-product GEMM runs: every sub-batch of this call)
+    planes = os.environ.get("INFV_PROJ_X6", "") != "0" and os.environ.get("INFV_VPROJ_SPLIT", "0") in ("", "0")
+    per_chunk = BYTES_POOL_PER_CHUNK if planes else BYTES_POOL_ROWS_ONLY
+    pool_bytes = c_local * per_chunk
     achieved = pool_bytes / (pool_ms * 1e-3) / 1e9 if pool_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic_per_full_launch()
     roofline = {
@@ -669,7 +673,7 @@ def main():
         "note": "achieved = in situ, while the pool shares the chip with the chain and update/read-out streams; "
                 "achieved_alone = same launch size through infv_ltm_pool_rows, nothing else running",
         "launches": pool_n, "avg_launch_ms": pool_ms / max(pool_n, 1),
-        "bytes_per_full_launch": nb * BYTES_POOL_PER_CHUNK,
+        "bytes_per_full_launch": nb * per_chunk,
         "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
         "kernel_ms_per_pass": {name: round(ms, 3) for name, (n, ms) in prof.items()},
         "mfma_busy_pct": pmc_mfma_busy(args.batch_chunks), "mfma_busy_from_committed_profile": True,
