@@ -116,7 +116,8 @@ def pmc_fabric_bytes_per_chunk(batch_chunks: int):
     if not files:
         return None
     d = json.load(open(files[-1]))
-    frags = ("pool_rows2_kernel<", "split3_rows_kernel", "gemm_x6_wide_kernel", "gemm_nt_lw_kernel", "chain_batch3_kernel<",
+    # (split3_rows_kernel ran once per sub-batch up to round 4; since round 5 only once per call, for the weights' planes: left out)
+    frags = ("pool_rows2_kernel<", "gemm_x6_wide_kernel", "gemm_nt_lw_kernel", "chain_batch3_kernel<",
              "chain_call_kernel", "alpha_rows2_kernel<", "uc_fast_kernel<")
     per = {}
     try:

@@ -349,3 +349,21 @@ def test_short_memory_buffer_keeps_the_reference_frames():
         buf.replace(frames[:3, :2])
     with pytest.raises(RuntimeError):
         ShortMemoryBuffer(P, d, 4).frames()
+
+
+def test_bench_reads_the_honest_ceiling_from_the_committed_pmc_pass():
+    """bench.py's ``roofline.fabric_bytes_per_chunk``: bytes that crossed the fabric per chunk for every kernel of the whole-video
+    pipeline, from the newest committed PMC summary (no GPU involved).  The pooling stream's share must equal its algorithmic bytes
+    (no wasted re-reads), the total must sit between the pooling's bytes and the section-8d formula's 39.7 MB, and the launch
+    census the drop-in / encode_video legs use must be exported."""
+    import bench
+    fab = bench.pmc_fabric_bytes_per_chunk(42)
+    assert fab is not None and fab["source"].endswith("_pmc_summary.json")
+    pool = fab["per_kernel_high"]["pool_rows2_kernel"]
+    assert abs(pool - bench.BYTES_POOL_PER_CHUNK) / bench.BYTES_POOL_PER_CHUNK < 0.01, (pool, bench.BYTES_POOL_PER_CHUNK)
+    assert bench.BYTES_POOL_PER_CHUNK < fab["low"] <= fab["high"] < bench.BYTES_PER_CHUNK
+    for k in ("gemm_x6_wide_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "chain_batch3_kernel"):
+        assert fab["per_kernel_high"][k] > 0, k
+    assert "split3_rows_kernel" not in fab["per_kernel_high"]          # (once per call since round 5: the weights' planes)
+    lib = _lib.load()
+    assert int(lib.infv_ltm_launch_count()) >= 0
