@@ -238,6 +238,10 @@ def test_chain_timeout_is_reported_not_swallowed(dev):
     unaffected.  Runs in a child process: a process loads one build of the library."""
     r = _run_child(_FAULT_CHILD, {"INFV_LTM_LIBRARY": "exp"})
     assert "FAULT_CHILD_OK" in r.stdout, r.stdout + r.stderr
+    # the same with round 5's call-long launches (role S, pooling and projection GEMM resident for the whole call, handed off through
+    # device-side counters): every bounded wait -- exchange, readiness poll, flag_wait_kernel -- must give up, latch and report
+    r = _run_child(_FAULT_CHILD, {"INFV_LTM_LIBRARY": "exp", "INFV_CHAIN_CALL": "1", "INFV_POOL_CALL": "1", "INFV_GEMM_CALL": "1"})
+    assert "FAULT_CHILD_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_consolidate_video_through_rccl_world_of_one(dev):
