@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define INFV_LTM_ABI_VERSION 3
+#define INFV_LTM_ABI_VERSION 4
 #define INFV_LTM_MAX_LAYERS 8
 
 typedef enum {

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _WHICH = os.environ.get("INFV_LTM_LIBRARY", "")
 LIB_PATH = (os.path.join(_HERE, "libinfv_ltm_exp.so") if _WHICH == "exp" else
             (_WHICH if _WHICH else os.path.join(_HERE, "libinfv_ltm.so")))
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 8
 
 i32p = C.POINTER(C.c_int32)
