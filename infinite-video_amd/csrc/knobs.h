@@ -21,14 +21,14 @@ inline const char* exp_env(const char* name) {
 }
 }  // namespace infv
 
-// ---- launch census: every kernel launch of the library goes through hipLaunchKernelGGL; this re-definition counts them on the
-// host (one relaxed atomic add per launch) so that a benchmark can state "launches per chunk" of a path without a profiler
-// (infv_ltm_launch_count, include/infv_ltm.h).
+// ---- launch census: every kernel launch of the library goes through INFV_LAUNCH (same argument order as hipLaunchKernelGGL); it
+// counts them on the host (one relaxed atomic add per launch) so that a benchmark can state "launches per chunk" of a path without
+// a profiler (infv_ltm_launch_count, include/infv_ltm.h).  tests/test_host_cpu.py checks that no source launches a kernel any other
+// way (no raw <<< >>>, no hipLaunchKernelGGL, no hipModuleLaunchKernel).
 #include <hip/hip_runtime.h>
 #include <atomic>
 namespace infv { extern std::atomic<long long> g_kernel_launches; }
-#undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                         \
+#define INFV_LAUNCH(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                \
     do {                                                                                                          \
         ::infv::g_kernel_launches.fetch_add(1, std::memory_order_relaxed);                                        \
         (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                      \

@@ -1220,9 +1220,11 @@ int ensure_side_stream(infv_ltm_handle h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
-    HIP_TRY(h->call_flags.reserve(1024));                      // [0, 512): the two counters, [512, 1024): ChainCallDesc of the current call
-    HIP_TRY(h->call_stats.reserve(64));
-    HIP_TRY(hipMemset(h->call_stats.p, 0, 64));
+    if (chain_call_long()) {                                   // (experiments build: hand-off words of the call-long launches)
+        HIP_TRY(h->call_flags.reserve(1024));                  // [0, 512): the two counters, [512, 1024): ChainCallDesc of the current call
+        HIP_TRY(h->call_stats.reserve(64));
+        HIP_TRY(hipMemset(h->call_stats.p, 0, 64));
+    }
     h->issue_mu = &sh->issue;
     h->side = sh->side;                                       // last: h->side != nullptr means "streams and events exist"
     return INFV_OK;
@@ -1267,7 +1269,9 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     if (int rc = ensure_side_stream(h)) return rc;
     // One call enqueues at a time per device: the worker streams are shared by every handle, and a call-long role-S launch
     // spin-waits on work that must not end up behind another call's hand-off kernels in a shared stream.
-    std::lock_guard<std::mutex> issue_lock(*h->issue_mu);
+    // (The per-sub-batch launches of the shipped pipeline only order themselves through events: no lock, as in rounds 1-4.)
+    std::unique_lock<std::mutex> issue_lock(*h->issue_mu, std::defer_lock);
+    if (chain_call_long()) issue_lock.lock();
     // Padding LDS caps the pooling kernel's occupancy at ONE 512-thread workgroup (84 KB: two do not fit, one leaves room for
     // a 74 KB workgroup of the loader-wave GEMM) per CU, so a role-S workgroup
     // always finds LDS and wave slots and the pool's bytes in flight stay bounded.  The GEMMs carry no padding any more
@@ -1278,7 +1282,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
-    {   // hand-off counters of the call-long launches restart with the call (before ev_start: the pooling stream starts behind it)
+    if (chain_call_long()) {   // hand-off counters of the call-long launches restart with the call (before ev_start: the pooling stream starts behind it)
         const size_t need_pd = ((size_t)n_chunks + 1) * sizeof(unsigned int);
         if (need_pd > h->pool_done.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->pool_done.reserve(need_pd < 32768 ? 32768 : need_pd)); }
         HIP_TRY(hipMemsetAsync(h->pool_done.p, 0, need_pd, stream));
@@ -1855,7 +1859,7 @@ int infv_ltm_export_chain_state(infv_ltm_handle h, int32_t Q, void* blob, void* 
     if (!h->has_memory || !h->last_fast || h->lastQ != Q || h->parts != 1)
         return fail(INFV_ERR_STATE, "export_chain_state: the memory's last step must come from infv_ltm_consolidate with Q=%d", Q);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(blob_header_write_kernel, dim3(1), dim3(64), 0, stream, static_cast<int*>(blob), blob_header(h, Q));
+    INFV_LAUNCH(blob_header_write_kernel, dim3(1), dim3(64), 0, stream, static_cast<int*>(blob), blob_header(h, Q));
     HIP_TRY(hipGetLastError());
     float* out = static_cast<float*>(blob) + kBlobHeaderInts;
     const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,
@@ -1874,7 +1878,7 @@ int infv_ltm_import_chain_state(infv_ltm_handle h, int32_t Q, const void* blob, 
     if (int rc = check_chain_error(h)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     // the header is checked on the device (the call stays asynchronous): a mismatch latches an error that the next entry point reports
-    hipLaunchKernelGGL(blob_header_check_kernel, dim3(1), dim3(1), 0, stream, static_cast<const int*>(blob), blob_header(h, Q), h->err_dev);
+    INFV_LAUNCH(blob_header_check_kernel, dim3(1), dim3(1), 0, stream, static_cast<const int*>(blob), blob_header(h, Q), h->err_dev);
     HIP_TRY(hipGetLastError());
     const float* in = static_cast<const float*>(blob) + kBlobHeaderInts;
     const size_t nB = (size_t)h->L * h->N * h->d, nKV = (size_t)h->L * h->N * 2 * h->dm, nS = (size_t)h->L * h->H * Q * h->N,

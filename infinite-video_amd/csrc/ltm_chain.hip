@@ -91,7 +91,7 @@ hipError_t launch_new_scores(const float* q, int Q, int H, int n_layers, int n_c
                              long chunk_stride, long row_stride, long layer_stride, int splitk, long split_stride,
                              const ProjPtrs& proj, float* Snew, float* cq, hipStream_t stream) {
     if (rows == 0 || n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(new_scores_kernel, dim3(H, n_layers, n_chunks), dim3(256), 0, stream, q, Q, H, rows, Kmat,
+    INFV_LAUNCH(new_scores_kernel, dim3(H, n_layers, n_chunks), dim3(256), 0, stream, q, Q, H, rows, Kmat,
                        chunk_stride, row_stride, layer_stride, splitk, split_stride, proj, Snew, cq);
     return hipGetLastError();
 }
@@ -327,7 +327,7 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream) {
     const int rows = a.s.op.rows, tabw = a.s.op.tabw;
     if (!chain_supported(a.N, a.S, rows, tabw)) return hipErrorInvalidValue;
     const size_t lds = chain_lds_bytes(a.N, a.S, rows, tabw);
-    hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kNT), lds, stream, a);
+    INFV_LAUNCH(chain_kernel, dim3(blocks), dim3(kNT), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -342,7 +342,7 @@ __global__ void acc_to_part_kernel(const unsigned long long* __restrict__ acc, i
     part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? (float)mass_of(tot) : 0.f;
 }
 hipError_t launch_acc_to_part(const unsigned long long* acc, int n_layers, int parts_pitch, float* part, hipStream_t stream) {
-    hipLaunchKernelGGL(acc_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, acc, parts_pitch, part);
+    INFV_LAUNCH(acc_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, acc, parts_pitch, part);
     return hipGetLastError();
 }
 }  // namespace infv

@@ -344,7 +344,10 @@ constexpr int kPollWaves = 6;              // waves 0..5 read the mailboxes (wav
                                            // front of a poll in its vmcnt queue; wave 6 carries the writer's extra stores)
 constexpr int kPollRound = 4;              // slots per wave and round: 24 workgroups per layer = one round
 
-__host__ __device__ inline Batch3Smem batch3_smem(int N, int S, int rows, int tabw, int rpw) {
+constexpr int kDmaPar = 4;                // DMA loader: LDS buffers of the S'new tile / the uniforms (steps i .. i+3)
+constexpr int kDmaSnew = 64 * kB2Ld * 4;  // floats of one S'new buffer: kB2Ld load instructions of 1 KiB
+constexpr int kDmaUf = 64 * 2 * 4;        // floats of one uniforms buffer: two load instructions
+__host__ __device__ inline Batch3Smem batch3_smem(int N, int S, int rows, int tabw, int rpw, bool dma = false) {
     Batch3Smem m;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -357,8 +360,8 @@ __host__ __device__ inline Batch3Smem batch3_smem(int N, int S, int rows, int ta
     m.box_row = take(N);
     m.pb = take(kBins);
     m.sc = take(rpw * kBRows * kScPitch);
-    m.Snew = take(2 * rpw * kBRows * (rows + 1));
-    m.uf = take(2 * S);
+    m.Snew = dma ? take(kDmaPar * kDmaSnew) : take(2 * rpw * kBRows * (rows + 1));
+    m.uf = dma ? take(kDmaPar * kDmaUf) : take(2 * S);
     m.Msm = take(rpw * kBRows * kMPitch);
     m.total = o;
     return m;
@@ -376,7 +379,7 @@ __global__ void round_up_uniforms_kernel(const double* __restrict__ u, float* __
 
 hipError_t launch_round_up_uniforms(const double* u, float* uf, long n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(round_up_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, uf, n);
+    INFV_LAUNCH(round_up_uniforms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, uf, n);
     return hipGetLastError();
 }
 
@@ -407,7 +410,7 @@ __global__ void mailbox_to_part_kernel(const unsigned long long* __restrict__ mb
     part[((long)l * parts_pitch) * kBins + j] = (j < kBins - 1) ? mailbox_total(mbox, L, G, parity, l, j) : 0.f;
 }
 hipError_t launch_mailbox_to_part(const unsigned long long* mbox, int n_layers, int G, int parity, int parts_pitch, float* part, hipStream_t stream) {
-    hipLaunchKernelGGL(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
+    INFV_LAUNCH(mailbox_to_part_kernel, dim3(n_layers), dim3(128), 0, stream, mbox, n_layers, G, parity, parts_pitch, part);
     return hipGetLastError();
 }
 #else
@@ -422,8 +425,12 @@ __device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_
 //                beside the other kernels -- but a layer then needs 24 FREE CUs on one XCD at every launch, which in the shared
 //                pipeline takes longer than the launch saves (21.5 against 14.7 ms per video): experiments build only
 //                (INFV_CHAIN_XCD=1), for a future call-long launch on dedicated CUs.
-template <int RPW, bool MBOX>
-__global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
+// DMA = true (round 6): the loader wave moves the S'new tile and the uniforms global -> LDS with `buffer_load_dwordx4 ... lds`
+//   (no register sets: the two sets of the register loader and their address arithmetic were 86 of the kernel's 214 registers),
+//   four LDS buffers deep (requested three steps ahead).  The kernel then fits 128 registers: two of these workgroups -- or one
+//   and a pooling workgroup -- share a CU.  Needs splitk == 1 (a DMA cannot add slabs), per-sub-batch launches, atomics exchange.
+template <int RPW, bool MBOX, bool DMA>
+__device__ __forceinline__ void chain_batch3_body(const ChainBatchArgs a) {
     constexpr int TR = kBRows * RPW;                                   // rows of the tile
     constexpr int PPR = TR / 4;                                        // float4 pieces per new row of the S'new tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.dbg != nullptr && l == 0 && blk == 0 && tid == 0) a.dbg[18] = wall_clock64();      // (stamps: kernel entry of workgroup 0)
     const int rows = a.op.rows, tabw = a.op.tabw;
-    const Batch3Smem m = batch3_smem(N, a.S, rows, tabw, RPW);
+    const Batch3Smem m = batch3_smem(N, a.S, rows, tabw, RPW, DMA);
     const int h = blk % H, qs = blk / H;
     const int b = l * blocks_per_layer + blk;                          // (stamps: workgroup 0 = layer 0, head 0, tile 0)
     const int G = blocks_per_layer;
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         }
         if (tid < kBins) pb[tid] = a.st.bin_box[tid];
         if (tid < a.S) pos[tid] = -1;
-        for (int e = tid; e < 2 * sn_tile; e += kBNT) (lds + m.Snew)[e] = 0.f;     // incl. the zero column (index rows) of every row
+        for (int e = tid; e < (DMA ? kDmaPar * kDmaSnew : 2 * sn_tile); e += kBNT) (lds + m.Snew)[e] = 0.f;     // incl. the zero column (index rows) of every row
+        if (DMA) for (int e = tid; e < kDmaPar * kDmaUf; e += kBNT) (lds + m.uf)[e] = 2.f;                       // (a uniform nobody draws with)
         for (int e = tid; e < TR * kScPitch; e += kBNT) (lds + m.sc)[e] = 0.f;     // incl. the zero point of every row
         __syncthreads();
         for (int e = tid; e < N * tabw; e += kBNT) {
@@ -506,6 +514,9 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     const int n0 = pb[lane], n1 = pb[lane + 64];
     const float val0 = box_val[n0], val1 = box_val[n1];
     const int br0 = box_row[n0] >= 0 ? box_row[n0] : rows, br1 = box_row[n1] >= 0 ? box_row[n1] : rows;   // `rows` = the zero column
+    // DMA layout of the S'new tile: float4 slot (hf, nr) = hf * rows + nr holds tile rows 4 hf .. 4 hf + 3 of new row nr
+    const bool has_r0 = br0 < rows, has_r1 = br1 < rows;
+    const int sna0 = has_r0 ? 4 * br0 : 0, sna1 = has_r1 ? 4 * br1 : 0;
     const bool e0ok = a.st.edge_box[lane] >= 0, e1ok = a.st.edge_box[lane + 64] >= 0;     // edge 0 lies left of every box
     const float dx0 = a.st.edge_dx[lane], dx1 = a.st.edge_dx[lane + 64];
     const float dxa = a.st.edge_dx[lane + 1], dxb = (lane + 65 < kBins) ? a.st.edge_dx[lane + 65] : 0.f;
@@ -530,8 +541,43 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     // ---- loader (wave 7): the S'new tile and the rounded-up uniforms of a step in registers, two sets (steps i+1, i+2 in
     // flight).  Wide loads only.  S'new tile: new row nr holds this tile's TR scores contiguously -> float4 e4 = lane + 64 k:
     // row e4 / PPR, piece e4 % PPR;   uniforms: S floats -> two float4 per lane
-    struct LdSet { floatx4 sn[kB2Ld]; floatx4 u[2]; };
+    struct LdSet { floatx4 sn[DMA ? 1 : kB2Ld]; floatx4 u[DMA ? 1 : 2]; };
     LdSet ldA, ldB;
+    // ---- DMA loader: per-lane global byte offsets of this lane's float4 of each load instruction (an offset beyond the buffer's
+    // range reads as zero), the same for every step; the step selects the buffer through the scalar offset
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    int dvo[kB2Ld] = {-1, -1, -1, -1}, dvu[2] = {-1, -1};
+    v4i_t drs_sn = {0, 0, 0, 0}, drs_uf = {0, 0, 0, 0};
+    unsigned dl_sn = 0, dl_uf = 0;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int k = 0; k < kB2Ld; ++k) {
+            const int e4 = lane + 64 * k;
+            const int hf = e4 / rows, nr = e4 - hf * rows;
+            dvo[k] = (hf < PPR && 4 * hf < valid) ? (nr * a.snew_ld + 4 * hf) * 4 : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int s4 = lane + 64 * k; dvu[k] = (4 * s4 < a.S) ? 16 * s4 : -1; }
+        const unsigned long ps = reinterpret_cast<unsigned long>(a.Snew + tile), pu = reinterpret_cast<unsigned long>(a.uf + (long)l * a.S);
+        drs_sn = v4i_t{(int)(unsigned)ps, (int)(unsigned)((ps >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+        drs_uf = v4i_t{(int)(unsigned)pu, (int)(unsigned)((pu >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+        dl_sn = (unsigned)(unsigned long)(lds_ptr_t)(lds + m.Snew);
+        dl_uf = (unsigned)(unsigned long)(lds_ptr_t)(lds + m.uf);
+    }
+    auto dma16 = [](const v4i_t& rsrc, unsigned lds_addr, int voff, int soff) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+    };
+    // request step i into buffer i % kDmaPar: six load instructions, no registers
+    auto dma_request = [&](int i) {
+        const int buf = i & (kDmaPar - 1);
+        const int so_sn = (int)((long)i * tile_snew * 4), so_uf = (int)((long)i * a.L * a.S * 4);     // (below 2^31: launcher)
+#pragma unroll
+        for (int k = 0; k < kB2Ld; ++k) dma16(drs_sn, dl_sn + (buf * kDmaSnew + k * 256) * 4, dvo[k], so_sn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) dma16(drs_uf, dl_uf + (buf * kDmaUf + k * 256) * 4, dvu[k], so_uf);
+    };
     // Call-long launch: step i belongs to sub-batch i / call_sub, whose S'new rows sit in workspace set (sub-batch % call_sets) once
     // the GEMM stream has raised `ready` past it.  The rows were written by ANOTHER kernel while this one was running, possibly
     // over lines this XCD's L2 still holds from the set's previous use: every load of them is an sc1 load (served by the
@@ -567,19 +613,37 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         } else {
             sb = a.Snew + (long)i * tile_snew + tile;
         }
-        __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb), 0, 0x7fffffff, 0x00020000);
+        // one buffer resource per split-K slab, its 64-bit base at the slab (a 32-bit slab offset overflowed for short sub-batches of
+        // large models: the hardware then returns zeros, silently); the offset inside a slab, rows * snew_ld * 4 bytes, is bounded by
+        // the launcher.  sc1 only on the call-long launch, whose rows another kernel writes while this one is resident.
+        // (slab 0 on its own: its loads stay in flight behind the request; the further slabs of a short sub-batch are added behind them)
+        {
+            __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < kB2Ld; ++k) {
-            const int e4 = lane + 64 * k;
-            const int nr = e4 / PPR, hf = e4 % PPR;
-            floatx4 v = {0.f, 0.f, 0.f, 0.f};
-            if (nr < rows && 4 * hf < valid) {
-                const int off = (nr * a.snew_ld + 4 * hf) * 4;
-                v = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16 /* sc1 */));
-                for (int x = 1; x < splitk; ++x)
-                    v += as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, (int)(x * split_stride * 4), 16 /* sc1 */));
+            for (int k = 0; k < kB2Ld; ++k) {
+                const int e4 = lane + 64 * k;
+                const int nr = e4 / PPR, hf = e4 % PPR;
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nr < rows && 4 * hf < valid) {
+                    const int off = (nr * a.snew_ld + 4 * hf) * 4;
+                    v = call_long ? as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16 /* sc1 */))
+                                  : as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 0));
+                }
+                r.sn[k] = v;
             }
-            r.sn[k] = v;
+        }
+        for (int x = 1; x < splitk; ++x) {
+            __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb + (long)x * split_stride), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < kB2Ld; ++k) {
+                const int e4 = lane + 64 * k;
+                const int nr = e4 / PPR, hf = e4 % PPR;
+                if (nr < rows && 4 * hf < valid) {
+                    const int off = (nr * a.snew_ld + 4 * hf) * 4;
+                    r.sn[k] += call_long ? as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16 /* sc1 */))
+                                         : as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 0));
+                }
+            }
         }
         const floatx4* ub = reinterpret_cast<const floatx4*>(a.uf + ((long)i * a.L + l) * a.S);
 #pragma unroll
@@ -608,10 +672,20 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         }
     };
     if (loader) {
+        if constexpr (DMA) {
+            // steps 0, 1, 2 in flight; step 0 has landed before the barrier below hands it to the other waves
+            dma_request(0);
+            if (a.n_steps > 1) dma_request(1);
+            if (a.n_steps > 2) dma_request(2);
+            if (a.n_steps > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (a.n_steps > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
         ld_request(0, ldA);
         ld_park(0, ldA);
         if (a.n_steps > 1) ld_request(1, ldB);                         // odd steps live in set B, even steps in set A
         if (a.n_steps > 2) ld_request(2, ldA);
+        }
     }
 
     // ---- placement handshake, second half: one XCD for the whole layer?  (bounded wait; needs every workgroup resident, as
@@ -709,6 +783,10 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             const int row = wave + kBRows * j;
+            if constexpr (DMA) {
+                // (own rows from LDS as well: they hold the step's scores until barrier 2 of the next step; no registers live across the step)
+                if (row_ok[j]) { cr[row * kBins + lane] = scw[j * kBRows * kScPitch + lane]; cr[row * kBins + lane + 64] = scw[j * kBRows * kScPitch + lane + 64]; }
+            } else
             if (row_ok[j] && !(a.exp_flags & 4)) { cr[row * kBins + lane] = pa0[j]; cr[row * kBins + lane + 64] = pa1[j]; }
             const int extra = (wave == 1) ? kBRows * j : ((wave == 6) ? kBRows * j + kBRows - 1 : -1);
             if (extra >= 0 && extra < valid) {
@@ -758,7 +836,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         const long slot = slot_run;
         if (++slot_run == ring_n) slot_run = 0;
         const bool last = (i == a.n_steps - 1);
-        const float* Snew = lds + m.Snew + (i & 1) * sn_tile;
+        const float* Snew = lds + m.Snew + (DMA ? (i & (kDmaPar - 1)) * kDmaSnew : (i & 1) * sn_tile);
         unsigned long long* acc_prev = a.acc[g3 == 0 ? 2 : g3 - 1] + l * layer_words;
         unsigned long long* acc_cur = a.acc[g3] + l * layer_words;
         unsigned long long* acc_clr = a.acc[g3 == 2 ? 0 : g3 + 1] + l * layer_words;
@@ -779,7 +857,8 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         if (i > 0) {
             // in the shadow of wave 0's scan: the previous step goes out, the loader asks for the inputs of step i+2
             if (loader) {
-                if (i + 2 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 2) & 1) ld_request(i + 2, ldB); else ld_request(i + 2, ldA); }
+                if constexpr (DMA) { if (i + 2 < a.n_steps) dma_request(i + 2); }      // (buffer of step i - 2: its last readers ran before barrier 3 of that step)
+                else if (i + 2 < a.n_steps && !(a.exp_flags & 8)) { if ((i + 2) & 1) ld_request(i + 2, ldB); else ld_request(i + 2, ldA); }
             } else if (wave != 0) {
                 publish_step(i - 1, prev_slot, acc0, acc1);
                 // hand a finished sub-batch to the UC stream.  Every publishing wave drains its stores (they are then in this XCD's
@@ -878,7 +957,7 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         }
         if (tid < a.S) {
             // ---- lower bound of this thread's uniform in the cdf == number of entries below it ----
-            const float my_uf = (lds + m.uf + (i & 1) * a.S)[tid];
+            const float my_uf = (lds + m.uf + (DMA ? (i & (kDmaPar - 1)) * kDmaUf : (i & 1) * a.S))[tid];
             const floatx4* c4 = reinterpret_cast<const floatx4*>(coarse);
             int grp = 0;
 #pragma unroll
@@ -930,8 +1009,15 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int row = wave + kBRows * j;
+                if constexpr (DMA) {
+                    const float* sr = Snew + (row >> 2) * rows * 4 + (row & 3);
+                    const float x0 = sr[sna0], x1 = sr[sna1];
+                    acc0[j] += has_r0 ? x0 : 0.f;
+                    acc1[j] += has_r1 ? x1 : 0.f;
+                } else {
                 acc0[j] += Snew[row * sn + br0];
                 acc1[j] += Snew[row * sn + br1];
+                }
                 // in place: every gather of this wave is issued before these stores (the lanes read each other's old values),
                 // and LDS runs a wave's operations in order
                 if (j == 0) wave_lds_handover();
@@ -1020,6 +1106,13 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
         // the publishing stores and the loader's requests wait for the window behind that barrier (wave 0's scan), so neither a
         // poll nor a re-poll queues behind them in this CU's memory pipe
         if (MBOX && poller && !last) poll_issue((int)(gstep & 1), 0);
+        if constexpr (DMA) {
+            // step i+1's tile and uniforms have landed (the barriers of step i+1 hand them to the other waves); step i+2 may still fly
+            if (loader && !last) {
+                if (i + 2 < a.n_steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else
         if (loader && !last) { if ((i + 1) & 1) ld_park(i + 1, ldB); else ld_park(i + 1, ldA); }   // LDS only (requested two steps ago)
         if (wave == 0) B3STAMP(5);
         B3STAMP(6);
@@ -1057,6 +1150,25 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) {
     wg_stamp_end(a.wg_stamps);
 }
 
+template <int RPW, bool MBOX>
+__global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) { chain_batch3_body<RPW, MBOX, false>(a); }
+
+// the DMA-loader form (atomics exchange, 16-row tiles): 128 registers, four of its waves per SIMD -- two workgroups, or one and
+// a pooling workgroup (168 registers x 3 waves per SIMD), fit a CU.  Bit-identical to the register loader and 2 % faster alone
+// (10.45 against 10.7 ms of chain per 2048-chunk video) -- and measured in situ (round 6, docs/NOTEBOOK.md): sharing its CUs with
+// pooling workgroups gives the pooling 48 more seats (12.5 -> 11.6 ms, 0.56 of the HBM peak), the GEMM and UC kernels 8-15 %,
+// and costs role S 3 us per step (chain 12.5 -> 14.9 ms, call 13.4 -> 16.3 ms; shorter pooling bursts do not help); padded to
+// 77 KB (two of these per CU, no pooling workgroup) the chain is 13.0-13.6 ms; padded to 84 KB (a CU each) it is the shipped
+// pipeline to the noise.  Role S stays a CU's only tenant: experiments build only (INFV_CHAIN_DMA=1).
+#ifdef INFV_EXPERIMENTS
+#ifndef INFV_CHAIN_WPE
+#define INFV_CHAIN_WPE 4
+#endif
+__global__ __launch_bounds__(kBNT) __attribute__((amdgpu_waves_per_eu(INFV_CHAIN_WPE, INFV_CHAIN_WPE))) void chain_batch3_dma_kernel(ChainBatchArgs a) {
+    chain_batch3_body<2, false, true>(a);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------------
 // alpha_rows2_kernel: the chunk-parallel other half of chain_batch2_kernel.  For every step of a sub-batch and every
 // (layer, head, query) row it rebuilds the full score row from the point scores of the PREVIOUS step and the step's
@@ -1072,7 +1184,10 @@ constexpr int kA2Q = 32;                  // query rows staged per pass
 //  count hipcc unrolls the gather loop four ways with remainder loops for every one of the 32 (row, box) positions -- 12 000
 //  instructions, 16 us of arithmetic per unit; with the constant, 1.)
 template <int TW4>
-__global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
+#ifndef INFV_ALPHA_WPE
+#define INFV_ALPHA_WPE 2
+#endif
+__global__ __launch_bounds__(kA2NT) __attribute__((amdgpu_waves_per_eu(INFV_ALPHA_WPE))) void alpha_rows2_kernel(AlphaRows2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, Q = a.Q, H = a.H, rows = a.rows, tabw = a.tabw;
@@ -1100,7 +1215,9 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     const long n_units = (long)a.n_steps * LH * n_pass;
     const int tw4 = TW4 > 0 ? TW4 : tabw / 4, n_tb = N * tw4;                  // int4s per box / per table
     constexpr int kRpw = kA2Q / (kA2NT / 64);                                  // query rows per wave and pass
-    int4 r_tb[2]; floatx4 r_prev[4]; floatx4 r_sn[2]; float r_cq;
+    // (r_tb as two named values, each written unconditionally: as a conditionally written array hipcc kept it in scratch -- 48 bytes
+    //  of private memory and an s_waitcnt vmcnt(0) right behind the "prefetch" of the next unit's table, rounds 4-5)
+    int4 r_tb0 = make_int4(-1, -1, -1, -1), r_tb1 = make_int4(-1, -1, -1, -1); floatx4 r_prev[4]; floatx4 r_sn[2]; float r_cq;
     struct Unit { int i, lh, l, q0, qn; long slot, pslot, row0; };
     auto unit_of = [&](long u) {
         Unit t;
@@ -1114,8 +1231,12 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     // (launcher: N % 4 == 0, n_tb <= 512, rows * kA2Q / 4 <= 512, Q % 4 == 0 and 16-byte aligned S'new rows)
     auto load_unit = [&](const Unit& t) {                                   // global -> registers: 9 load instructions per wave
         const int32_t* tb = a.tabb_ring + t.slot * a.tab_slot + (long)t.l * N * tabw;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int e = tid + j * kA2NT; if (e < n_tb) r_tb[j] = reinterpret_cast<const int4*>(tb)[e]; }
+        {
+            // (in range for every thread: an index past the table is clamped to its last entry and never parked)
+            const int4* tb4 = reinterpret_cast<const int4*>(tb);
+            r_tb0 = tb4[min(tid, n_tb - 1)];
+            r_tb1 = tb4[min(tid + kA2NT, n_tb - 1)];
+        }
         const float* cp = a.crit_ring + t.pslot * a.crit_slot + t.row0 * kBins;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1140,7 +1261,7 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int e = tid + j * kA2NT;
-            if (e < n_tb) { const int n = e / tw4, jj = e - n * tw4; tabb[(4 * jj + (n & 3)) * nq + (n >> 2)] = r_tb[j]; }
+            if (e < n_tb) { const int n = e / tw4, jj = e - n * tw4; tabb[(4 * jj + (n & 3)) * nq + (n >> 2)] = j == 0 ? r_tb0 : r_tb1; }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1182,6 +1303,7 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
     };
     const bool regs_ok = a.regs_ok != 0;                                    // (launcher: the register stage fits and the rows are 16-byte aligned)
     if (tid < snp) snew[rows * snp + tid] = 0.f;                          // the zero row (read by boxes without a new row)
+    if (tid < kA2Q * (kScPitch - kBins)) prev[(tid / (kScPitch - kBins)) * kScPitch + kBins + tid % (kScPitch - kBins)] = 0.f;   // zero words behind every row's points (never rewritten)
     long u = blockIdx.x;
     if (u >= n_units) { wg_stamp_end(a.wg_stamps); return; }
     Unit cur = unit_of(u);
@@ -1226,7 +1348,7 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
         // into coefficients that are 0 for an empty slot (fma(0, finite, acc) = acc: the same bits as skipping it); a box without
         // a new row reads the zero row behind the S'new tile.  Per row that leaves the reads, the fma chain and the softmax.
         constexpr int kSl = TW4 > 0 ? 4 * TW4 : 4;                          // resolved slots per box held in registers
-        const float* gp[4][kSl]; float gv[4][kSl]; const float* sp[4];
+        const float* gp[4][kSl]; const float* sp[4];
         if (TW4 > 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1235,11 +1357,9 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
                     int4 src = make_int4(-1, -1, -1, -1);
                     if (lane_ok) src = tabb[(4 * jj + k) * nq + lane];
                     const int sx[4] = {src.x, src.y, src.z, src.w};
+                    // an empty slot reads the zero word behind the row's 128 points (fma(val, 0, acc) == acc: the same bits as skipping it)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        gp[k][4 * jj + c] = prev + wave * kScPitch + max(sx[c], 0);
-                        gv[k][4 * jj + c] = sx[c] >= 0 ? val[k] : 0.f;
-                    }
+                    for (int c = 0; c < 4; ++c) gp[k][4 * jj + c] = prev + wave * kScPitch + (sx[c] >= 0 ? sx[c] : kZeroPoint);
                 }
                 sp[k] = snew + (brow[k] >= 0 ? brow[k] : rows) * snp + wave;
             }
@@ -1259,7 +1379,7 @@ __global__ __launch_bounds__(kA2NT) void alpha_rows2_kernel(AlphaRows2Args a) {
                     float acc = 0.f;
                     if (TW4 > 0) {
 #pragma unroll
-                        for (int c = 0; c < kSl; ++c) acc = fmaf(gv[k][c], gp[k][c][j * (kA2NT / 64) * kScPitch], acc);
+                        for (int c = 0; c < kSl; ++c) acc = fmaf(val[k], gp[k][c][j * (kA2NT / 64) * kScPitch], acc);
                         acc += sp[k][j * (kA2NT / 64)];
                     } else {
 #pragma unroll 1
@@ -1357,9 +1477,9 @@ hipError_t launch_alpha_rows2(const AlphaRows2Args& a_, hipStream_t stream) {
         }
         lds_launch = lds_pad;
     }
-    if (a.tabw == 4) hipLaunchKernelGGL(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
-    else if (a.tabw == 8) hipLaunchKernelGGL(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
-    else hipLaunchKernelGGL(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
+    if (a.tabw == 4) INFV_LAUNCH(alpha_rows2_kernel<1>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
+    else if (a.tabw == 8) INFV_LAUNCH(alpha_rows2_kernel<2>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
+    else INFV_LAUNCH(alpha_rows2_kernel<0>, dim3(grid), dim3(kA2NT), lds_launch, stream, a);
     return hipGetLastError();
 }
 
@@ -1410,7 +1530,7 @@ hipError_t launch_alpha_rows(float* alpha_ring, long alpha_slot, float* asum_rin
     if (n_steps <= 0) return hipSuccess;
     if (N > 256) return hipErrorInvalidValue;
     const long rows = (long)n_steps * rows_per_step;
-    hipLaunchKernelGGL(alpha_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, alpha_ring, alpha_slot,
+    INFV_LAUNCH(alpha_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, alpha_ring, alpha_slot,
                        asum_ring, asum_slot, slot0, ring, n_steps, rows_per_step, N, w, w_out);
     return hipGetLastError();
 }
@@ -1451,6 +1571,20 @@ static Chain3Fn chain3_fn(int rpw) {
 #endif
 }
 
+// Round 6 (experiments build, INFV_CHAIN_DMA=1): the DMA-loader form of the default role S (chain_batch3_dma_kernel, 128 registers).
+// It applies to every launch whose new-row scores are one slab (the sub-batches of 16 chunks and more), on the atomics exchange
+// with per-sub-batch launches.
+static bool chain_dma_wanted() {
+    static const bool want = [] { const char* e = exp_env("INFV_CHAIN_DMA"); return e && atoi(e) != 0; }();
+    return want;
+}
+static bool chain_dma_applies(const ChainBatchArgs& a, int rpw) {
+    return chain_dma_wanted() && rpw == 2 && !chain_batch3_mailboxes() && a.call == nullptr && a.snew_splitk == 1 && a.exp_flags == 0 &&
+           a.snew_ld % 4 == 0 && a.Q % 4 == 0 && (reinterpret_cast<unsigned long>(a.Snew) & 15) == 0 && (reinterpret_cast<unsigned long>(a.uf) & 15) == 0 &&
+           a.S % 4 == 0 && a.S <= 512 && 4 * a.op.rows <= 64 * kB2Ld &&
+           (long)a.n_steps * a.op.rows * a.snew_ld * 4 < (1l << 31) && (long)a.n_steps * a.L * a.S * 4 < (1l << 31);
+}
+
 static hipError_t chain_batch_attr() {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1458,6 +1592,9 @@ static hipError_t chain_batch_attr() {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         for (int rpw = 1; rpw <= 2 && e == hipSuccess; ++rpw)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain3_fn(rpw)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef INFV_EXPERIMENTS
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch3_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1499,10 +1636,10 @@ int chain_batch_blocks(int H, int Q, int L, int draw_mode, int points_ok, int ro
     return H * ((Q + kBRows * rpw - 1) / (kBRows * rpw)) * L;
 }
 
-static size_t chain_batch3_launch_lds(int N, int S, int rows, int tabw, int rpw) {
+static size_t chain_batch3_launch_lds(int N, int S, int rows, int tabw, int rpw, bool dma = false) {
     // padding LDS keeps the workgroup's CU footprint what the stream layout of consolidate() was tuned for
     static const int pad = [] { const char* e = exp_env("INFV_S_LDS"); return e ? atoi(e) : 0; }();
-    size_t lds = (size_t)batch3_smem(N, S, rows, tabw, rpw).total * sizeof(float);
+    size_t lds = (size_t)batch3_smem(N, S, rows, tabw, rpw, dma).total * sizeof(float);
     if ((size_t)pad > lds) lds = pad;
     return lds;
 }
@@ -1533,7 +1670,7 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
 // kernels behind it start with the usual launch-time acquire.  One wave each; the wait is bounded and latches the error word.
 __global__ void chain_call_desc_kernel(ChainCallDesc* dst, ChainCallDesc v) { if (threadIdx.x == 0) *dst = v; }
 hipError_t launch_chain_call_desc(ChainCallDesc* dst, const ChainCallDesc& v, hipStream_t stream) {
-    hipLaunchKernelGGL(chain_call_desc_kernel, dim3(1), dim3(64), 0, stream, dst, v);
+    INFV_LAUNCH(chain_call_desc_kernel, dim3(1), dim3(64), 0, stream, dst, v);
     return hipGetLastError();
 }
 __global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
@@ -1549,11 +1686,11 @@ __global__ void flag_wait_kernel(const unsigned int* counter, unsigned int targe
     }
 }
 hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream) {
-    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, stream, flag, value);
+    INFV_LAUNCH(flag_set_kernel, dim3(1), dim3(64), 0, stream, flag, value);
     return hipGetLastError();
 }
 hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream) {
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
+    INFV_LAUNCH(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
     return hipGetLastError();
 }
 
@@ -1569,6 +1706,7 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
     ChainBatchArgs a = a_in;
     if (!chain_batch_supported(a.N, a.S, a.op.rows, a.op.tabw, a.H * a.QS * a.L)) return hipErrorInvalidValue;
     if (chain_batch2_applies(a)) {
+        if ((long)a.op.rows * a.snew_ld * 4 >= (1l << 31)) return hipErrorInvalidValue;   // (32-bit byte offsets inside one step's rows of S'new)
         const int rpw = chain_batch3_rpw(a.op.rows, a.Q);
         a.QS = (a.Q + kBRows * rpw - 1) / (kBRows * rpw);             // tiles of 8 * rpw query rows
         const int G = a.H * a.QS;                                      // workgroups of a layer
@@ -1578,13 +1716,17 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
         static const bool linear = [] { const char* e = exp_env("INFV_CHAIN_LINEAR"); return e && atoi(e) != 0; }();   // experiments: linear grid (the layer spread over all XCDs)
         a.xcd_grid = (chain_batch3_mailboxes() && !linear && G <= 32 && a.L <= 8) ? 1 : 0;
         const int blocks = a.xcd_grid ? 8 * G : G * a.L;
-        const size_t lds = chain_batch3_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw);
+        const bool dma = chain_dma_applies(a, rpw);
+        const size_t lds = chain_batch3_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw, dma);
         a.wg_stamps = exp_stamps_reserve(WG_CHAIN, blocks);
-        hipLaunchKernelGGL(chain3_fn(rpw), dim3(blocks), dim3(kBNT), lds, stream, a);
+#ifdef INFV_EXPERIMENTS
+        if (dma) { INFV_LAUNCH(chain_batch3_dma_kernel, dim3(blocks), dim3(kBNT), lds, stream, a); return hipGetLastError(); }
+#endif
+        INFV_LAUNCH(chain3_fn(rpw), dim3(blocks), dim3(kBNT), lds, stream, a);
         return hipGetLastError();
     }
     a.wg_stamps = nullptr;
-    hipLaunchKernelGGL(chain_batch_kernel, dim3(a.H * a.QS * a.L), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
+    INFV_LAUNCH(chain_batch_kernel, dim3(a.H * a.QS * a.L), dim3(kBNT), chain_batch_lds_bytes(a.N, a.S, a.op.rows, a.op.tabw),
                        stream, a);
     return hipGetLastError();
 }

@@ -65,7 +65,7 @@ hipError_t launch_dense_update(const float* GT, int K, int ldg, int n_old, const
                                int n_layers, hipStream_t stream) {
     if (N % 16 || d % 16) return hipErrorInvalidValue;
     dim3 grid((d / 16 + 3) / 4, N / 16, n_layers);
-    hipLaunchKernelGGL(dense_update_kernel, grid, dim3(256), 0, stream, GT, K, ldg, n_old, bins, bins_stride, pos_box2, B_prev,
+    INFV_LAUNCH(dense_update_kernel, grid, dim3(256), 0, stream, GT, K, ldg, n_old, bins, bins_stride, pos_box2, B_prev,
                        kbar, B_next, N, d);
     return hipGetLastError();
 }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void dense_masses_kernel(const float* __restri
 
 hipError_t launch_dense_masses(const float* scores, int Q, int N, int H, int n_layers, const int32_t* edge_box2,
                                const float* edge_dx, float* part, hipStream_t stream) {
-    hipLaunchKernelGGL(dense_masses_kernel, dim3(H, n_layers), dim3(256), 0, stream, scores, Q, N, H, edge_box2, edge_dx, part);
+    INFV_LAUNCH(dense_masses_kernel, dim3(H, n_layers), dim3(256), 0, stream, scores, Q, N, H, edge_box2, edge_dx, part);
     return hipGetLastError();
 }
 

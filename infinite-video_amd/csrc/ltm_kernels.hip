@@ -116,9 +116,9 @@ static hipError_t launch_pool_t(const void* k, float* kbar, int64_t n_frames, in
             attr_set = true;
         }
         const unsigned grid = (unsigned)((n_units + 7) / 8);
-        hipLaunchKernelGGL((pool_frames_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
+        INFV_LAUNCH((pool_frames_kernel<4, 512, Tok>), dim3(grid), dim3(512), lds_pad, stream, k, kbar, n_units, P, d4, slices);
     } else {
-        hipLaunchKernelGGL((pool_frames_kernel<16, 256, Tok>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
+        INFV_LAUNCH((pool_frames_kernel<16, 256, Tok>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, stream, k, kbar,
                            n_units, P, d4, slices);
     }
     return hipGetLastError();
@@ -368,16 +368,16 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     static const int want_tid = [] { const char* e = exp_env("INFV_POOL_TID"); return e ? atoi(e) : kPoolTidAddr; }();
     const int tid_addr = (want_tid && d4 % 64 == 0) ? 1 : 0;               // every lane of every slice holds a column
 #ifdef INFV_EXPERIMENTS
-    if (call == nullptr && u >= 32 && P % 32 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<32, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
-    if (call == nullptr && u >= 16 && P % 16 == 0) { hipLaunchKernelGGL((pool_rows2_kernel<16, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
+    if (call == nullptr && u >= 32 && P % 32 == 0) { INFV_LAUNCH((pool_rows2_kernel<32, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
+    if (call == nullptr && u >= 16 && P % 16 == 0) { INFV_LAUNCH((pool_rows2_kernel<16, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc); return hipGetLastError(); }
 #endif
     if (call != nullptr) {
-        if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
-        else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+        if (u >= 8 && P % 8 == 0) INFV_LAUNCH((pool_rows2_kernel<8, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+        else INFV_LAUNCH((pool_rows2_kernel<4, Tok, true>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
         return hipGetLastError();
     }
-    if (u >= 8 && P % 8 == 0) hipLaunchKernelGGL((pool_rows2_kernel<8, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
-    else hipLaunchKernelGGL((pool_rows2_kernel<4, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+    if (u >= 8 && P % 8 == 0) INFV_LAUNCH((pool_rows2_kernel<8, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
+    else INFV_LAUNCH((pool_rows2_kernel<4, Tok, false>), dim3(grid), block, lds, stream, k, (long)T * P * d4, P, d4, slices, op, n_rows_total, R, stamps, prio, tid_addr, pc);
     return hipGetLastError();
 }
 
@@ -778,7 +778,7 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
         }
         if (((M + 127) / 128) * (n_cols / 128) <= 160 && ((M + 63) / 64) * (n_cols / 128) <= 256) {
             dim3 grid((M + 63) / 64, n_cols / 128, splitk);
-            hipLaunchKernelGGL((gemm_nt_lw_kernel<64, 128, 24>), grid, dim3(512), 2 * (64 + 128) * kLdsStride * sizeof(float), stream,
+            INFV_LAUNCH((gemm_nt_lw_kernel<64, 128, 24>), grid, dim3(512), 2 * (64 + 128) * kLdsStride * sizeof(float), stream,
                                A, M, K, segs, C, ldc, split_stride, exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z), 0);
         } else {
             // Column slices launched one after the other on the stream (experiment INFV_GEMM_SLICES): a launch whose workgroups do not
@@ -794,7 +794,7 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
                 const int y0 = gy * sl / slices, y1 = gy * (sl + 1) / slices;
                 if (y1 <= y0) continue;
                 dim3 grid((M + 127) / 128, y1 - y0, splitk);
-                hipLaunchKernelGGL((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), lds_bytes, stream,
+                INFV_LAUNCH((gemm_nt_lw_kernel<128, 128, 24>), grid, dim3(512), lds_bytes, stream,
                                    A, M, K, segs, C, ldc, split_stride, exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y * grid.z), y0);
             }
         }
@@ -812,7 +812,7 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
             attr64 = true;
         }
         dim3 grid(gx, gy, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
+        INFV_LAUNCH((gemm_nt_kernel<64, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
                            C, ldc, split_stride, k_per_split, 0);
     } else if (M >= 1024) {
         const int gx = (M + 127) / 128, gy = n_cols / 128;
@@ -824,17 +824,17 @@ static hipError_t launch_gemm(const float* A, int M, int K, const WSegs& segs,
             if (ny < 1) ny = 1;
             for (int y0 = 0; y0 < gy; y0 += ny) {
                 dim3 grid(gx, (gy - y0 < ny) ? gy - y0 : ny, splitk);
-                hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
+                INFV_LAUNCH((gemm_nt_kernel<128, 128>), grid, dim3(256), lds_pad, stream, A, M, K, segs,
                                    C, ldc, split_stride, k_per_split, y0);
             }
         } else {
             dim3 grid(gx, gy, splitk);
-            hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, segs,
+            INFV_LAUNCH((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, stream, A, M, K, segs,
                                C, ldc, split_stride, k_per_split, 0);
         }
     } else {
         dim3 grid((M + 63) / 64, n_cols / 64, splitk);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, segs,
+        INFV_LAUNCH((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, M, K, segs,
                            C, ldc, split_stride, k_per_split, 0);
     }
     return hipGetLastError();
@@ -851,7 +851,7 @@ int project_splitk(int M, int K) {
 hipError_t launch_rows(const float* kbar, int n_chunks, int T, int d, const OperatorView& op, float* R,
                        hipStream_t stream) {
     if (op.rows == 0 || n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_rows_kernel, dim3(op.rows, n_chunks), dim3(256), 0, stream, kbar, T, d / 4, op, R);
+    INFV_LAUNCH(build_rows_kernel, dim3(op.rows, n_chunks), dim3(256), 0, stream, kbar, T, d / 4, op, R);
     return hipGetLastError();
 }
 
@@ -877,7 +877,7 @@ hipError_t launch_step_project(const float* kbar, int d, int dm, int n_layers, c
     int gy = n_cols / 64;
     if (gy < draw.n_layers) gy = draw.n_layers;
     dim3 grid((M + 63) / 64 > 0 ? (M + 63) / 64 : 1, gy, sk + 1);
-    hipLaunchKernelGGL(step_project_kernel, grid, dim3(256), 0, stream, ra, M, d, kv_segs(proj, 0, n_layers, dm), Pnew, n_cols,
+    INFV_LAUNCH(step_project_kernel, grid, dim3(256), 0, stream, ra, M, d, kv_segs(proj, 0, n_layers, dm), Pnew, n_cols,
                        (long)M * n_cols, d / sk, sk, draw);
     return hipGetLastError();
 }
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void qtilde_kernel(const float* __restrict__ q
 
 hipError_t launch_qtilde(const float* q, int Q, int H, int d, int n_layers, const ProjPtrs& proj, float* qt, float* cq,
                          hipStream_t stream) {
-    hipLaunchKernelGGL(qtilde_kernel, dim3(H, n_layers, (d + 255) / 256), dim3(256), (size_t)Q * kHeadSize * sizeof(float), stream, q, Q, H,
+    INFV_LAUNCH(qtilde_kernel, dim3(H, n_layers, (d + 255) / 256), dim3(256), (size_t)Q * kHeadSize * sizeof(float), stream, q, Q, H,
                        d, proj, qt, cq);
     return hipGetLastError();
 }
@@ -987,7 +987,7 @@ hipError_t launch_draw(const float* bin_part, int parts, const float* probs_over
                        const StickyView& sticky, const double* u, int S, int n_layers, float* probs,
                        int32_t* bins, int32_t* idx, hipStream_t stream, const int32_t* bins_forced, unsigned forced_mask) {
     if (S > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(draw_kernel, dim3(n_layers), dim3(256), 0, stream, bin_part, parts, probs_override,
+    INFV_LAUNCH(draw_kernel, dim3(n_layers), dim3(256), 0, stream, bin_part, parts, probs_override,
                        override_mask, sticky, u, S, probs, bins, idx, bins_forced, forced_mask);
     return hipGetLastError();
 }
@@ -1084,7 +1084,7 @@ hipError_t launch_update(const OperatorView& op, int N, int d, int dm, int n_lay
     // instead of three in sequence; the kernel is nothing but those dependent round trips: 13.3 -> 7 us per step)
     const int total4 = d / 4 + 2 * (dm / 4);
     const int nt = total4 >= 1024 ? 1024 : ((total4 + 63) / 64) * 64;
-    hipLaunchKernelGGL(update_kernel, dim3(N, n_layers), dim3(nt), 0, stream, op, N, d / 4, dm / 4, n_layers, S,
+    INFV_LAUNCH(update_kernel, dim3(N, n_layers), dim3(nt), 0, stream, op, N, d / 4, dm / 4, n_layers, S,
                        idx, idx_layer_stride, R, Pnew, splitk, split_stride / 4, B_prev, KV_prev, B_next,
                        KV_next, kbar, (op.slot_tab != nullptr && op.tabw > 0) ? tab : nullptr);
     return hipGetLastError();
@@ -1404,14 +1404,14 @@ hipError_t launch_attend(const float* q, int Q, int N, int H, int n_layers, cons
             attr2 = true;
         }
         if (rt == 4)
-            hipLaunchKernelGGL(attend_small_kernel<4>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
+            INFV_LAUNCH(attend_small_kernel<4>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
                                KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
         else
-            hipLaunchKernelGGL(attend_small_kernel<16>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
+            INFV_LAUNCH(attend_small_kernel<16>, dim3(H, QT, n_layers), dim3(256), attend_small_lds_bytes(N), stream, q, Q, N, H,
                                KV, proj, readout_w, readout_w_out, sticky, ctx, bin_part, scores);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(attend_kernel, dim3(H, QT, n_layers), dim3(256), lds, stream, q, Q, N, H, KV, proj,
+    INFV_LAUNCH(attend_kernel, dim3(H, QT, n_layers), dim3(256), lds, stream, q, Q, N, H, KV, proj,
                        readout_w, readout_w_out, sticky, ctx, bin_part, scores);
     return hipGetLastError();
 }
@@ -1427,7 +1427,7 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, int parts, int 
     out[j] = (float)acc;
 }
 hipError_t launch_sum_parts(const float* bin_part_layer, int parts, int pitch, float* bin_mass, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(256), 0, stream, bin_part_layer, parts, pitch, bin_mass);
+    INFV_LAUNCH(sum_parts_kernel, dim3(1), dim3(256), 0, stream, bin_part_layer, parts, pitch, bin_mass);
     return hipGetLastError();
 }
 }  // namespace infv

@@ -48,8 +48,8 @@ hipError_t launch_psi_gemm(bool transB, const float* A, int lda, long sA, const 
                            int M, int Nc, int K, int batch, hipStream_t stream) {
     if (M <= 0 || Nc <= 0 || K <= 0 || batch <= 0) return hipSuccess;
     dim3 grid((Nc + 63) / 64, (M + 15) / 16, batch);
-    if (transB) hipLaunchKernelGGL(psi_gemm_kernel<true>, grid, dim3(256), 0, stream, A, lda, sA, B, ldb, sB, C, ldc, sC, M, Nc, K);
-    else hipLaunchKernelGGL(psi_gemm_kernel<false>, grid, dim3(256), 0, stream, A, lda, sA, B, ldb, sB, C, ldc, sC, M, Nc, K);
+    if (transB) INFV_LAUNCH(psi_gemm_kernel<true>, grid, dim3(256), 0, stream, A, lda, sA, B, ldb, sB, C, ldc, sC, M, Nc, K);
+    else INFV_LAUNCH(psi_gemm_kernel<false>, grid, dim3(256), 0, stream, A, lda, sA, B, ldb, sB, C, ldc, sC, M, Nc, K);
     return hipGetLastError();
 }
 
@@ -92,7 +92,7 @@ hipError_t launch_psi_update(const float* GT, int K, int ldg, int n_old, const i
                              const float* kbar, float* B_next, int N, int d, int n_layers, hipStream_t stream) {
     if (N % 16 || d % 16) return hipErrorInvalidValue;
     dim3 grid((d / 16 + 3) / 4, N / 16, n_layers);
-    hipLaunchKernelGGL(psi_update_kernel, grid, dim3(256), 0, stream, GT, K, ldg, n_old, bins, bins_stride, Y, n_pos, kbar, B_next, N, d);
+    INFV_LAUNCH(psi_update_kernel, grid, dim3(256), 0, stream, GT, K, ldg, n_old, bins, bins_stride, Y, n_pos, kbar, B_next, N, d);
     return hipGetLastError();
 }
 
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void psi_masses_kernel(const float* __restrict
 }
 
 hipError_t launch_psi_masses(const float* E, int ldE, int Q, int H, int n_layers, const float* edge_dx, float* part, hipStream_t stream) {
-    hipLaunchKernelGGL(psi_masses_kernel, dim3(H, n_layers), dim3(256), 0, stream, E, ldE, Q, H, edge_dx, part);
+    INFV_LAUNCH(psi_masses_kernel, dim3(H, n_layers), dim3(256), 0, stream, E, ldE, Q, H, edge_dx, part);
     return hipGetLastError();
 }
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void psi_grid_kernel(float* __restrict__ Eg, i
 }
 
 hipError_t launch_psi_grid(float* Eg, int ldg, int n_grid, long n_rows, const float* w, hipStream_t stream) {
-    hipLaunchKernelGGL(psi_grid_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, stream, Eg, ldg, n_grid, n_rows, w);
+    INFV_LAUNCH(psi_grid_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, stream, Eg, ldg, n_grid, n_rows, w);
     return hipGetLastError();
 }
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void psi_ctx_kernel(const float* __restrict__ 
 
 hipError_t launch_psi_ctx(const float* alpha, const float* KV, const ProjPtrs& proj, int Q, int N, int H, int dh, int n_layers, float* ctx,
                           hipStream_t stream) {
-    hipLaunchKernelGGL(psi_ctx_kernel, dim3((H * dh + 255) / 256, Q, n_layers), dim3(256), 0, stream, alpha, KV, proj, Q, N, H, dh, ctx);
+    INFV_LAUNCH(psi_ctx_kernel, dim3((H * dh + 255) / 256, Q, n_layers), dim3(256), 0, stream, alpha, KV, proj, Q, N, H, dh, ctx);
     return hipGetLastError();
 }
 

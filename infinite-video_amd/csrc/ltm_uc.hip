@@ -601,10 +601,10 @@ hipError_t launch_uc(const UcArgs& a, hipStream_t stream) {
         b.prio = prio | (skipm << 4);
         const size_t vfl = (size_t)2 * a.N * 16 + 8 * 64 * 4 + kUcQ * (a.N + 4), bfl = (size_t)2 * a.N * 32;
         const size_t lds_floats = vfl > bfl ? vfl : bfl;
-        hipLaunchKernelGGL(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
+        INFV_LAUNCH(uc_fast_kernel<true>, dim3(nblk), dim3(kUcNT), lds_floats * sizeof(float), stream, b);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
+    INFV_LAUNCH(uc_kernel, dim3(blocks), dim3(kUcNT), uc_lds_bytes(a.N, a.tabw, a.op.rows), stream, a);
     return hipGetLastError();
 }
 

@@ -374,7 +374,7 @@ hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad
                 if (e != hipSuccess) return e;
                 attr_w = true;
             }
-            hipLaunchKernelGGL(kernel, grid, dim3(512), kDLds, stream, gg);
+            INFV_LAUNCH(kernel, grid, dim3(512), kDLds, stream, gg);
             return hipGetLastError();
         };
 #ifdef INFV_EXPERIMENTS
@@ -397,7 +397,7 @@ hipError_t launch_split_gemm(const SplitGemm& g, hipStream_t stream, int lds_pad
     if (g.K % kSBK || g.k_per_split % kSBK || g.k_per_split <= 0 || g.lda % 8 || g.ldb % 8 || g.strideA % 8 || g.strideB % 8)
         return hipErrorInvalidValue;
     dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, g.nbatch * g.splitk);
-    hipLaunchKernelGGL(split_gemm_kernel, grid, dim3(256), kSLds + (lds_pad > 0 ? lds_pad : 0), stream, g);
+    INFV_LAUNCH(split_gemm_kernel, grid, dim3(256), kSLds + (lds_pad > 0 ? lds_pad : 0), stream, g);
     return hipGetLastError();
 }
 
@@ -423,7 +423,7 @@ hipError_t launch_split_rows(const float* x, long ld_in, long rows, int cols, vo
     if (rows <= 0) return hipSuccess;
     if (cols % 4 || ld_in % 4 || ld_out % 4) return hipErrorInvalidValue;
     const long n = rows * (cols / 4);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld_in, rows, cols / 4,
+    INFV_LAUNCH(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld_in, rows, cols / 4,
                        static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), ld_out);
     return hipGetLastError();
 }
@@ -765,8 +765,8 @@ hipError_t launch_gemm_x6_call(const GemmCallDesc& d, GemmCallDesc* d_dev, int n
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(gemm_call_desc_kernel, dim3(1), dim3(64), 0, stream, d_dev, d);
-    hipLaunchKernelGGL(gemm_x6_call_kernel, dim3(n_wgs), dim3(512), kYLds, stream, d_dev);
+    INFV_LAUNCH(gemm_call_desc_kernel, dim3(1), dim3(64), 0, stream, d_dev, d);
+    INFV_LAUNCH(gemm_x6_call_kernel, dim3(n_wgs), dim3(512), kYLds, stream, d_dev);
     return hipGetLastError();
 }
 
@@ -791,7 +791,7 @@ hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream) {
         dim3 grid((g.M + kYRowsA - 1) / kYRowsA, g.N / kYRowsB);
         SplitGemm6 gg = g;
         gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y);
-        hipLaunchKernelGGL(gemm_x6_wide_kernel, grid, dim3(512), kYLds, stream, gg);
+        INFV_LAUNCH(gemm_x6_wide_kernel, grid, dim3(512), kYLds, stream, gg);
         return hipGetLastError();
     }
     if (g.K % kXBK) return hipErrorInvalidValue;
@@ -806,7 +806,7 @@ hipError_t launch_gemm_x6(const SplitGemm6& g, hipStream_t stream) {
     gg.wg_stamps = exp_stamps_reserve(WG_GEMM, (long)grid.x * grid.y);
     // (experiment INFV_X6_LDS: total dynamic LDS; above 80 KB only one of these workgroups fits a CU)
     static const size_t lds_x = [] { const char* e = exp_env("INFV_X6_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
-    hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), lds_x > (size_t)kXLds && lds_x <= 96 * 1024 ? lds_x : (size_t)kXLds, stream, gg);
+    INFV_LAUNCH(gemm_x6_kernel, grid, dim3(256), lds_x > (size_t)kXLds && lds_x <= 96 * 1024 ? lds_x : (size_t)kXLds, stream, gg);
     return hipGetLastError();
 }
 
@@ -836,7 +836,7 @@ hipError_t launch_split3_rows(const float* x, long ld_in, long rows, int cols, v
     if (rows <= 0) return hipSuccess;
     if (cols % 16 || ld_in % 4) return hipErrorInvalidValue;
     const long n = rows * (cols / 4);
-    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld_in, rows, cols / 4,
+    INFV_LAUNCH(split3_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ld_in, rows, cols / 4,
                        static_cast<__bf16*>(p0), static_cast<__bf16*>(p1), static_cast<__bf16*>(p2), row0, rows_total);
     return hipGetLastError();
 }
@@ -952,7 +952,7 @@ hipError_t launch_split_transpose(const float* F, int nb, int n, int d, void* Fh
                                   hipStream_t stream, float* kbar, int P) {
     if (n % 32 || d % 64) return hipErrorInvalidValue;
     if (kbar && (P < 1 || 64 % P || n % P)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(split_transpose_kernel, dim3((n + 63) / 64, d / 64, nb), dim3(256), 0, stream, F, n, d,
+    INFV_LAUNCH(split_transpose_kernel, dim3((n + 63) / 64, d / 64, nb), dim3(256), 0, stream, F, n, d,
                        static_cast<__bf16*>(Fh), static_cast<__bf16*>(Fl), static_cast<__bf16*>(Th), static_cast<__bf16*>(Tl),
                        kbar, P);
     return hipGetLastError();
@@ -1053,16 +1053,16 @@ hipError_t launch_softmax_rows_split(const float* S, long n_rows, int len, long 
                                      hipStream_t stream) {
     if (len % 4 || ld % 4 || ld_out % 4) return hipErrorInvalidValue;
     if (len <= 2048) {
-        hipLaunchKernelGGL(softmax_rows_split_reg_kernel<2>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
+        INFV_LAUNCH(softmax_rows_split_reg_kernel<2>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
                            static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
         return hipGetLastError();
     }
     if (len <= 8192) {
-        hipLaunchKernelGGL(softmax_rows_split_reg_kernel<8>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
+        INFV_LAUNCH(softmax_rows_split_reg_kernel<8>, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
                            static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(softmax_rows_split_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
+    INFV_LAUNCH(softmax_rows_split_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld,
                        static_cast<__bf16*>(Ph), static_cast<__bf16*>(Pl), ld_out);
     return hipGetLastError();
 }

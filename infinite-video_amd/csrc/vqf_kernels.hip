@@ -205,11 +205,11 @@ hipError_t launch_qf_gemm(const QfGemm& g, bool nn, hipStream_t stream) {
     const int bm = big ? 128 : 64;
     dim3 grid((g.M + bm - 1) / bm, (g.N + bm - 1) / bm, g.nbatch * g.splitk);
     if (big) {
-        if (nn) hipLaunchKernelGGL((qf_gemm_kernel<128, 128, true>), grid, dim3(256), 0, stream, g);
-        else    hipLaunchKernelGGL((qf_gemm_kernel<128, 128, false>), grid, dim3(256), 0, stream, g);
+        if (nn) INFV_LAUNCH((qf_gemm_kernel<128, 128, true>), grid, dim3(256), 0, stream, g);
+        else    INFV_LAUNCH((qf_gemm_kernel<128, 128, false>), grid, dim3(256), 0, stream, g);
     } else {
-        if (nn) hipLaunchKernelGGL((qf_gemm_kernel<64, 64, true>), grid, dim3(256), 0, stream, g);
-        else    hipLaunchKernelGGL((qf_gemm_kernel<64, 64, false>), grid, dim3(256), 0, stream, g);
+        if (nn) INFV_LAUNCH((qf_gemm_kernel<64, 64, true>), grid, dim3(256), 0, stream, g);
+        else    INFV_LAUNCH((qf_gemm_kernel<64, 64, false>), grid, dim3(256), 0, stream, g);
     }
     return hipGetLastError();
 }
@@ -372,15 +372,15 @@ hipError_t launch_qf_epilogue(const QfEpilogue& e, hipStream_t stream) {
                    (!e.gamma || (al(e.gamma) && al(e.beta)));
         for (int sg = 0; sg < kQfMaxSeg; ++sg) vec = vec && (!e.bias[sg] || al(e.bias[sg]));
         if (vec && e.width <= 1024) {
-            hipLaunchKernelGGL(qf_epilogue_vec_kernel<1>, dim3(e.M), dim3(256), 0, stream, e);
+            INFV_LAUNCH(qf_epilogue_vec_kernel<1>, dim3(e.M), dim3(256), 0, stream, e);
             return hipGetLastError();
         }
         if (vec && e.width <= 4096) {
-            hipLaunchKernelGGL(qf_epilogue_vec_kernel<4>, dim3(e.M), dim3(256), 0, stream, e);
+            INFV_LAUNCH(qf_epilogue_vec_kernel<4>, dim3(e.M), dim3(256), 0, stream, e);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL(qf_epilogue_kernel, dim3(e.M), dim3(256), 0, stream, e);
+    INFV_LAUNCH(qf_epilogue_kernel, dim3(e.M), dim3(256), 0, stream, e);
     return hipGetLastError();
 }
 
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void qf_self_attention_kernel(const float* __r
 
 hipError_t launch_qf_self_attention(const float* qkv, int nb, int Q, int H, float* ctx, hipStream_t stream) {
     if (Q > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qf_self_attention_kernel, dim3(H, nb), dim3(256), 0, stream, qkv, Q, H, ctx);
+    INFV_LAUNCH(qf_self_attention_kernel, dim3(H, nb), dim3(256), 0, stream, qkv, Q, H, ctx);
     return hipGetLastError();
 }
 
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void qf_qtilde_kernel(const float* __restrict_
 
 hipError_t launch_qf_qtilde(const float* xq, int nb, int Q, int H, int d, const float* wk, float* qt,
                             hipStream_t stream) {
-    hipLaunchKernelGGL(qf_qtilde_kernel, dim3(H, (d + 255) / 256, nb * ((Q + 31) / 32)), dim3(256), 0, stream, xq, Q, H, d, wk, qt);
+    INFV_LAUNCH(qf_qtilde_kernel, dim3(H, (d + 255) / 256, nb * ((Q + 31) / 32)), dim3(256), 0, stream, xq, Q, H, d, wk, qt);
     return hipGetLastError();
 }
 
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void qf_softmax_rows_kernel(float* __restrict_
 
 hipError_t launch_qf_softmax_rows(float* S, long n_rows, int len, long ld, hipStream_t stream) {
     if (len % 4 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qf_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld);
+    INFV_LAUNCH(qf_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, stream, S, len, ld);
     return hipGetLastError();
 }
 
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void qf_sum_slabs_kernel(const float* __restri
 hipError_t launch_qf_sum_slabs(float* parts, int nsplit, long stride, long n, hipStream_t stream) {
     if (nsplit <= 1) return hipSuccess;
     if (n % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qf_sum_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, parts, nsplit,
+    INFV_LAUNCH(qf_sum_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, parts, nsplit,
                        stride, n / 4, parts);
     return hipGetLastError();
 }
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void qf_mean_kernel(const float* __restrict__ 
 }
 
 hipError_t launch_qf_mean(const float* in, int nb, long n, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(qf_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, nb, n, out);
+    INFV_LAUNCH(qf_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, nb, n, out);
     return hipGetLastError();
 }
 

@@ -173,6 +173,7 @@ def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     def having(names, frag):
         return sorted(n for n in names if frag in n)
     assert len(having(shipped, "chain_batch3_kernel")) == 1 and "Lb0" in having(shipped, "chain_batch3_kernel")[0]
+    assert not having(shipped, "chain_batch3_dma_kernel") and having(exp, "chain_batch3_dma_kernel")   # round 6: role S with the LDS-DMA loader (128 registers): measured, not shipped
     assert len(having(exp, "chain_batch3_kernel")) == 4
     for gone in ("chain_batch2_kernel", "pool_rows_kernel", "pool_frames_db_kernel"):
         assert not having(shipped, gone) and not having(exp, gone), gone
@@ -186,6 +187,25 @@ def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     for needed in ("psi_gemm_kernel", "psi_update_kernel", "psi_masses_kernel", "psi_grid_kernel", "psi_ctx_kernel",
                    "dense_update_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "gemm_nt_lw_kernel", "gemm_x6_wide_kernel"):
         assert having(shipped, needed), needed
+
+
+def test_every_kernel_launch_goes_through_the_counting_macro():
+    """``infv_ltm_launch_count`` (launches per chunk in the bench line) counts what INFV_LAUNCH (csrc/knobs.h) issues: no source
+    may launch a kernel any other way."""
+    csrc = os.path.join(ROOT, "infinite-video_amd", "csrc")
+    n_launch = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)                         # (comments may mention the HIP macro)
+        n_launch += code.count("INFV_LAUNCH(")
+        if f == "knobs.h":
+            assert code.count("<<<") == 1                             # the macro's own launch
+            continue
+        assert "<<<" not in code and "hipLaunchKernelGGL" not in code and "hipModuleLaunchKernel" not in code and \
+               "hipExtLaunchKernel" not in code and "hipLaunchCooperativeKernel" not in code, f
+    assert n_launch > 60
 
 
 def test_product_package_never_imports_the_oracle():

@@ -304,6 +304,7 @@ _VARIANTS = [
     {"INFV_PROJ_X6": "0", "INFV_GEMM_SLICES": "2"},            # (fp32-MFMA GEMM) launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
     {"INFV_ALPHA_DIRECT": "1", "INFV_ALPHA_UPW": "5"},          # alpha_rows2_kernel's fallback staging (shapes beyond its register stage), 5 units per workgroup
+    {"INFV_CHAIN_DMA": "1"},                                   # role S with the LDS-DMA loader (128 registers, round 6); the short last sub-batch keeps the register loader
 ]
 
 
