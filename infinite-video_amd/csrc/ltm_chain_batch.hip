@@ -429,8 +429,14 @@ __device__ inline int xcc_id() { int v; asm volatile("s_getreg_b32 %0, hwreg(HW_
 //   (no register sets: the two sets of the register loader and their address arithmetic were 86 of the kernel's 214 registers),
 //   four LDS buffers deep (requested three steps ahead).  The kernel then fits 128 registers: two of these workgroups -- or one
 //   and a pooling workgroup -- share a CU.  Needs splitk == 1 (a DMA cannot add slabs), per-sub-batch launches, atomics exchange.
+#ifndef INFV_CHAIN_WPE
+#define INFV_CHAIN_WPE 4
+#endif
+// (one kernel template, DMA a parameter: the waves-per-SIMD attribute takes a template-dependent argument -- as an inlined body
+//  function behind two kernels the register-loader form carried 20 bytes of unused private segment)
 template <int RPW, bool MBOX, bool DMA>
-__device__ __forceinline__ void chain_batch3_body(const ChainBatchArgs a) {
+__global__ __launch_bounds__(kBNT) __attribute__((amdgpu_waves_per_eu(DMA ? INFV_CHAIN_WPE : 2, DMA ? INFV_CHAIN_WPE : 2)))
+void chain_batch3_kernel(ChainBatchArgs a) {
     constexpr int TR = kBRows * RPW;                                   // rows of the tile
     constexpr int PPR = TR / 4;                                        // float4 pieces per new row of the S'new tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1150,9 +1156,6 @@ __device__ __forceinline__ void chain_batch3_body(const ChainBatchArgs a) {
     wg_stamp_end(a.wg_stamps);
 }
 
-template <int RPW, bool MBOX>
-__global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) { chain_batch3_body<RPW, MBOX, false>(a); }
-
 // the DMA-loader form (atomics exchange, 16-row tiles): 128 registers, four of its waves per SIMD -- two workgroups, or one and
 // a pooling workgroup (168 registers x 3 waves per SIMD), fit a CU.  Bit-identical to the register loader and 2 % faster alone
 // (10.45 against 10.7 ms of chain per 2048-chunk video) -- and measured in situ (round 6, docs/NOTEBOOK.md): sharing its CUs with
@@ -1160,14 +1163,6 @@ __global__ __launch_bounds__(kBNT) void chain_batch3_kernel(ChainBatchArgs a) { 
 // and costs role S 3 us per step (chain 12.5 -> 14.9 ms, call 13.4 -> 16.3 ms; shorter pooling bursts do not help); padded to
 // 77 KB (two of these per CU, no pooling workgroup) the chain is 13.0-13.6 ms; padded to 84 KB (a CU each) it is the shipped
 // pipeline to the noise.  Role S stays a CU's only tenant: experiments build only (INFV_CHAIN_DMA=1).
-#ifdef INFV_EXPERIMENTS
-#ifndef INFV_CHAIN_WPE
-#define INFV_CHAIN_WPE 4
-#endif
-__global__ __launch_bounds__(kBNT) __attribute__((amdgpu_waves_per_eu(INFV_CHAIN_WPE, INFV_CHAIN_WPE))) void chain_batch3_dma_kernel(ChainBatchArgs a) {
-    chain_batch3_body<2, false, true>(a);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------------
 // alpha_rows2_kernel: the chunk-parallel other half of chain_batch2_kernel.  For every step of a sub-batch and every
@@ -1563,15 +1558,15 @@ bool chain_call_long() {
 }
 static Chain3Fn chain3_fn(int rpw) {
 #ifdef INFV_EXPERIMENTS
-    if (chain_batch3_mailboxes()) return rpw == 1 ? chain_batch3_kernel<1, true> : chain_batch3_kernel<2, true>;
-    return rpw == 1 ? chain_batch3_kernel<1, false> : chain_batch3_kernel<2, false>;
+    if (chain_batch3_mailboxes()) return rpw == 1 ? chain_batch3_kernel<1, true, false> : chain_batch3_kernel<2, true, false>;
+    return rpw == 1 ? chain_batch3_kernel<1, false, false> : chain_batch3_kernel<2, false, false>;
 #else
     (void)rpw;
-    return chain_batch3_kernel<2, false>;
+    return chain_batch3_kernel<2, false, false>;
 #endif
 }
 
-// Round 6 (experiments build, INFV_CHAIN_DMA=1): the DMA-loader form of the default role S (chain_batch3_dma_kernel, 128 registers).
+// Round 6 (experiments build, INFV_CHAIN_DMA=1): the DMA-loader form of the default role S (chain_batch3_kernel<2, false, true>, 128 registers).
 // It applies to every launch whose new-row scores are one slab (the sub-batches of 16 chunks and more), on the atomics exchange
 // with per-sub-batch launches.
 static bool chain_dma_wanted() {
@@ -1593,7 +1588,7 @@ static hipError_t chain_batch_attr() {
         for (int rpw = 1; rpw <= 2 && e == hipSuccess; ++rpw)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain3_fn(rpw)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef INFV_EXPERIMENTS
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch3_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_batch3_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -1720,7 +1715,7 @@ hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {
         const size_t lds = chain_batch3_launch_lds(a.N, a.S, a.op.rows, a.op.tabw, rpw, dma);
         a.wg_stamps = exp_stamps_reserve(WG_CHAIN, blocks);
 #ifdef INFV_EXPERIMENTS
-        if (dma) { INFV_LAUNCH(chain_batch3_dma_kernel, dim3(blocks), dim3(kBNT), lds, stream, a); return hipGetLastError(); }
+        if (dma) { INFV_LAUNCH((chain_batch3_kernel<2, false, true>), dim3(blocks), dim3(kBNT), lds, stream, a); return hipGetLastError(); }
 #endif
         INFV_LAUNCH(chain3_fn(rpw), dim3(blocks), dim3(kBNT), lds, stream, a);
         return hipGetLastError();

@@ -173,8 +173,8 @@ def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     def having(names, frag):
         return sorted(n for n in names if frag in n)
     assert len(having(shipped, "chain_batch3_kernel")) == 1 and "Lb0" in having(shipped, "chain_batch3_kernel")[0]
-    assert not having(shipped, "chain_batch3_dma_kernel") and having(exp, "chain_batch3_dma_kernel")   # round 6: role S with the LDS-DMA loader (128 registers): measured, not shipped
-    assert len(having(exp, "chain_batch3_kernel")) == 4
+    assert "Lb0ELb0E" in having(shipped, "chain_batch3_kernel")[0]      # atomics exchange, register loader
+    assert len(having(exp, "chain_batch3_kernel")) == 5              # + 8-row tiles, mailbox exchange, and round 6's LDS-DMA loader (128 registers: measured, not shipped)
     for gone in ("chain_batch2_kernel", "pool_rows_kernel", "pool_frames_db_kernel"):
         assert not having(shipped, gone) and not having(exp, gone), gone
     assert not having(shipped, "pool_rows2_dma_kernel") and not having(exp, "pool_rows2_dma_kernel")     # (racy LDS-DMA variant: deleted in round 5)
