@@ -19,3 +19,17 @@ def _built_library():
     import __graft_entry__ as entry
     entry.build()
     yield
+
+
+def record_parity(line: str) -> None:
+    """Keep the parity evidence a GPU test computes (observed flip counts, worst errors): printed (``pytest -rA -s``) and appended
+    to ``gpurun_out/gpu_parity.txt`` -- which ``gpurun`` brings back from the GPU box; the round's copy is committed as
+    ``profiles/rNN_gpu_parity.txt``."""
+    print(line)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "gpu_parity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

@@ -5,6 +5,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from tests.conftest import record_parity
 import torch
 
 from oracle import ltm_oracle as O
@@ -337,7 +339,7 @@ def test_gaussian_family_with_the_products_own_plan(dev, case):
         assert p.dense and p.psi
         # how far this host's operator is from the reference's (informational; the GPU box has other LAPACK threads / kernels)
         gdiff = float(np.abs(p.inf_GT - g[f"T{T}_inf_G"].T).max() / np.abs(g[f"T{T}_inf_G"]).max())
-        print(f"[gaussian, own plan] T={T}: max |G - G_ref| / max |G_ref| = {gdiff:.2e}")
+        record_parity(f"[gaussian, own plan] T={T}: max |G - G_ref| / max |G_ref| = {gdiff:.2e}")
     projs = [tuple(_to(dev, *w)) for w in ws]
     q = torch.from_numpy(np.stack(qs)).to(dev)
     draws, flips, worst_ctx, worst_b = 0, 0, 0.0, 0.0
@@ -362,7 +364,7 @@ def test_gaussian_family_with_the_products_own_plan(dev, case):
             scale = float(np.abs(g[tag + "_B"]).max())
             worst_b = max(worst_b, float(np.abs(B.cpu().numpy() - g[tag + "_B"]).max()) / scale)
             worst_ctx = max(worst_ctx, float(np.abs(ctx[l] - g[tag + "_ctx"]).max()))
-    print(f"[gaussian, own plan] {case.name}: ctx {worst_ctx:.2e}, B (relative) {worst_b:.2e}, {flips} of {draws} draws differ")
+    record_parity(f"[gaussian, own plan] {case.name}: ctx {worst_ctx:.2e}, B (relative) {worst_b:.2e}, {flips} of {draws} draws differ")
     assert worst_ctx <= 1e-3 and worst_b <= 2e-2
     assert flips <= max(2, draws // 500)
 
