@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define INFV_LTM_ABI_VERSION 4
+#define INFV_LTM_ABI_VERSION 5
 #define INFV_LTM_MAX_LAYERS 8
 
 typedef enum {
@@ -209,6 +209,14 @@ int infv_ltm_consolidate_q(infv_ltm_handle h, const void* k, int32_t n_chunks, i
 int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q, int32_t Q,
                      const infv_ltm_proj* proj, const double* u, int32_t new_doc, float* ctx,
                      void* stream);
+
+/* infv_ltm_forward for a caller that keeps the pooled frames: pool k (element type `token_dtype`, an infv_token_dtype) into the
+ * caller's DEVICE buffer kbar [T,d] (long_term_attention_gibbs.py:304), then step from it (:306-346) -- infv_ltm_set_token_dtype +
+ * infv_ltm_pool + infv_ltm_step behind ONE call (round 6: the drop-in module's steady-state forward was three ctypes calls; its
+ * second cross-attention layer of the same chunk steps from the same kbar without pooling again).  No reset: new_doc is the
+ * caller's infv_ltm_reset. */
+int infv_ltm_forward_into(infv_ltm_handle h, const void* k, int32_t token_dtype, int32_t T, float* kbar, const float* q, int32_t Q,
+                          const infv_ltm_proj* proj, const double* u, float* ctx, void* stream);
 
 /* The per-chunk loop of the eval drivers (run_inference_inf_video_llama_nextqa.py:179-196)
  * with the LLM/Q-former stubbed: n_chunks chunks of T frames, k [C, T*P, d], the same

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _WHICH = os.environ.get("INFV_LTM_LIBRARY", "")
 LIB_PATH = (os.path.join(_HERE, "libinfv_ltm_exp.so") if _WHICH == "exp" else
             (_WHICH if _WHICH else os.path.join(_HERE, "libinfv_ltm.so")))
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 
 i32p = C.POINTER(C.c_int32)
@@ -124,6 +124,8 @@ _SIGNATURES = {
                                          C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "infv_ltm_forward_into": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_void_p]),
     "infv_ltm_consolidate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.POINTER(Proj), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "infv_ltm_consolidate_pooled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

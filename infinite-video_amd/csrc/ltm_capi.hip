@@ -809,6 +809,14 @@ int infv_ltm_forward(infv_ltm_handle h, const void* k, int32_t T, const float* q
     return infv_ltm_step(h, h->kbar_ws.as<float>(), T, q, Q, proj, u, ctx, stream);
 }
 
+int infv_ltm_forward_into(infv_ltm_handle h, const void* k, int32_t token_dtype, int32_t T, float* kbar, const float* q, int32_t Q,
+                          const infv_ltm_proj* proj, const double* u, float* ctx, void* stream) {
+    if (int rc = infv_ltm_set_token_dtype(h, token_dtype)) return rc;
+    if (T <= 0) return fail(INFV_ERR_INVALID, "forward_into: T must be positive");
+    if (int rc = infv_ltm_pool(h, k, T, kbar, stream)) return rc;
+    return infv_ltm_step(h, kbar, T, q, Q, proj, u, ctx, stream);
+}
+
 }  // extern "C"
 
 // ---- whole-video fast path -----------------------------------------------------------------------
@@ -1073,7 +1081,7 @@ struct FastPipe {
 int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const float* kbar, int n_chunks, int T, int Q,
                         const ProjPtrs& pp, int set, int* splitk, long* split_stride, hipStream_t stream, int gemm_pad,
                         bool defer_values = false, int rset = -1, bool rows_done = false, const float* r_ext = nullptr,
-                        void* const* planes_ext = nullptr) {
+                        void* const* planes_ext = nullptr, bool small_tiles = false) {
     if (rset < 0) rset = set;                                 // R buffer of the sub-batch (the pooling kernel may have filled it)
     // r_ext / planes_ext: the call-long pooling launch has written the sub-batch's rows (and their bf16 planes) elsewhere
     const Operator& op = inf ? plan.inf : plan.first;
@@ -1112,6 +1120,7 @@ int project_chunks_fast(infv_ltm_handle h, const Plan& plan, bool inf, const flo
         SplitGemm6 g{};
         for (int i = 0; i < 3; ++i) { g.A[i] = planes_ext != nullptr ? static_cast<const __bf16*>(planes_ext[i]) : h->r3[i].as<__bf16>(); g.B[i] = h->w3[i].as<__bf16>(); }
         g.lda = h->d; g.ldb = h->d; g.C = h->P_ws[set].as<float>(); g.ldc = ld; g.M = (int)M; g.N = (int)ld; g.K = h->d;
+        g.narrow = small_tiles ? 1 : 0;                          // 128 x 128 tiles (many short workgroups: the same bits) instead of 384 x 256
         HIP_TRY(launch_gemm_x6(g, stream));
         *splitk = 1;
     } else {
@@ -1407,9 +1416,34 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     {
         int later = sub;
         if (sub_env <= 0 && n_chunks < 768 && ramp_env > sub) later = ramp_env < h->maxC ? ramp_env : h->maxC;
+        // (experiments) tapered schedule of a short call: INFV_TAPER="first,mid,last" -- a small first sub-batch (role S starts early), a
+        // small last one (the serial tail behind the last pooling launch: GEMM -> role S -> alpha -> UC of the last sub-batch), the rest
+        // in equal pieces of at most `mid` chunks
+        static const char* taper_env = exp_env("INFV_TAPER");
+        int tf = 0, tm = 0, tl = 0;
+        const int n_rest = n_chunks - first_c;
+        if (sub_env <= 0 && n_chunks < 768 && taper_env && sscanf(taper_env, "%d,%d,%d", &tf, &tm, &tl) == 3 && tf > 0 && tm > 0 && tl > 0 &&
+            tf <= h->maxC && tm <= h->maxC && tl <= h->maxC && n_rest > tf + tl) {
+            const int middle = n_rest - tf - tl, pieces = (middle + tm - 1) / tm;
+            bstart.push_back(first_c);
+            int c0 = first_c + tf;
+            for (int i = 0; i < pieces; ++i) { bstart.push_back(c0); c0 += middle / pieces + (i < middle % pieces ? 1 : 0); }
+            bstart.push_back(c0);                                // the last sub-batch
+            bstart.push_back(n_chunks);
+            sub = tf > tm ? tf : tm; if (tl > sub) sub = tl;
+        } else if (const char* sched = (sub_env <= 0 && n_chunks < 768) ? exp_env("INFV_SCHED") : nullptr) {
+            // (experiments) INFV_SCHED="a,b,c,...": explicit sub-batch sizes; used when they add up to the call's chunks
+            std::vector<int> sz; int tot = 0, mx = 0;
+            for (const char* p_ = sched; *p_;) { const int v = atoi(p_); sz.push_back(v); tot += v; if (v > mx) mx = v; while (*p_ && *p_ != ',') ++p_; if (*p_ == ',') ++p_; }
+            bool ok_ = tot == n_rest && mx <= h->maxC;
+            for (int v : sz) ok_ = ok_ && v > 0;
+            if (ok_) { int c0 = first_c; for (int v : sz) { bstart.push_back(c0); c0 += v; } bstart.push_back(n_chunks); sub = mx; }
+            else { for (int c0 = first_c; c0 < n_chunks; c0 += sub) bstart.push_back(c0); bstart.push_back(n_chunks); }
+        } else {
         for (int c0 = first_c, i = 0; c0 < n_chunks; ++i) { bstart.push_back(c0); c0 += (i == 0) ? sub : later; }
         bstart.push_back(n_chunks);
         if (later > sub) sub = later;                           // (workspaces below are sized for the largest sub-batch)
+        }
     }
     const int n_batches = (int)bstart.size() - 1;
     const size_t rows = plan->inf.rows;
@@ -1592,8 +1626,13 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             r_ext = h->R_all.as<float>() + off;
             if (planes_call) for (int i = 0; i < 3; ++i) pl_ext[i] = h->planes_all[i].as<__bf16>() + off;
         }
+        // (experiments) INFV_SMALL_TILES=<mask>: bit 0 / 1 / 2 = the call's first / second / last sub-batch runs the projection as
+        // 128 x 128 tiles (hundreds of short workgroups: faster while the chip is still -- or again -- empty)
+        static const int small_mask = [] { const char* e = exp_env("INFV_SMALL_TILES"); return e ? atoi(e) : 0; }();
+        static const int small_below = [] { const char* e = exp_env("INFV_SMALL_BELOW"); return e ? atoi(e) : 0; }();   // sub-batches of fewer chunks than this
+        const bool small = n_chunks < 768 && (((small_mask & 1) && b == 0) || ((small_mask & 2) && b == 1) || ((small_mask & 4) && b == n_batches - 1) || nb < small_below);
         if (int rc = project_chunks_fast(h, *plan, true, kb, nb, T, Q, pp, set, &sks[b], &sss[b], side, kGemmPad,
-                                         h->vproj_on_uc(n_chunks), rset, use_pr, r_ext, (planes_call || planes_by_pool[b]) ? pl_ext : nullptr)) return rc;
+                                         h->vproj_on_uc(n_chunks), rset, use_pr, r_ext, (planes_call || planes_by_pool[b]) ? pl_ext : nullptr, small)) return rc;
         HIP_TRY(hipEventRecord(h->ev_p[set], side));
         p_pending[set] = true;
         if (use_call) {

@@ -272,6 +272,15 @@ class LTMEngine:
         if rc < 0:
             _lib.check(rc)
 
+    def forward_into_raw(self, k_ptr: int, token_code: int, T: int, kbar_ptr: int, q_ptr: int, Q: int, proj_arr, u_ptr: int,
+                         ctx_ptr: int, stream: C.c_void_p):
+        """infv_ltm_forward_into on raw addresses: set the token dtype, pool k into the caller's kbar, step from it -- ONE C call
+        (the drop-in module's steady-state forward; ``pool_into`` + ``step_raw`` were three)."""
+        rc = self.lib.infv_ltm_forward_into(self._h, C.c_void_p(k_ptr), token_code, T, C.c_void_p(kbar_ptr), C.c_void_p(q_ptr), Q,
+                                            proj_arr, C.c_void_p(u_ptr) if u_ptr else None, C.c_void_p(ctx_ptr), stream)
+        if rc < 0:
+            _lib.check(rc)
+
     def forward(self, k: torch.Tensor, q: torch.Tensor, projs: Sequence[ProjTensors],
                 u: Optional[torch.Tensor] = None, new_doc: bool = False) -> torch.Tensor:
         """LongTermAttention.forward for all layers: k [T*P, d], q [L, Q, dm] -> ctx [L, Q, dm]."""

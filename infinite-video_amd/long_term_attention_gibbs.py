@@ -269,9 +269,23 @@ class LongTermAttention(nn.Module):
         dev_index = k.device.index if k.device.index is not None else torch.cuda.current_device()
         stream = C.c_void_p(_raw_stream(dev_index))
         other_device = _cur_device() != dev_index
+        # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
+        sticky_step = eng.has_memory and self.sticky_memories
+        u_addr = self._draw_uniforms(k.device) if sticky_step else 0
+        qf = q.detach()
+        if qf.dtype != torch.float32 or not qf.is_contiguous():
+            qf = qf.float().contiguous()
+        ctx = torch.empty(1, qlen, self.n_head * self.head_size, device=k.device, dtype=torch.float32)
+        proj_arr = eng._proj_array([self._proj(k.device)])
         ref = _pool_cache["ref"]
         if ref is not None and ref() is k and _pool_cache["version"] == k._version:
+            # the frames of this k are pooled already (the chunk's other cross-attention layer did it): step from them
             kbar = _pool_cache["kbar"]
+            if other_device:
+                with torch.cuda.device(k.device):
+                    eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, proj_arr, u_addr, ctx.data_ptr(), stream)
+            else:
+                eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, proj_arr, u_addr, ctx.data_ptr(), stream)
         else:
             kf = k
             if kf.dtype not in TOKEN_DTYPES:                      # bf16 tokens are pooled as they are
@@ -279,26 +293,15 @@ class LongTermAttention(nn.Module):
             if not kf.is_contiguous():
                 kf = kf.contiguous()
             kbar = torch.empty(klen, self.encoder_width, device=k.device, dtype=torch.float32)
+            # pool (:304) + step (:306-346) behind ONE C call
             if other_device:
                 with torch.cuda.device(k.device):
-                    eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)       # :304
+                    eng.forward_into_raw(kf.data_ptr(), TOKEN_DTYPES[kf.dtype], klen, kbar.data_ptr(), qf.data_ptr(), qlen, proj_arr,
+                                         u_addr, ctx.data_ptr(), stream)
             else:
-                eng.pool_into(kf, kbar, klen, TOKEN_DTYPES[kf.dtype], stream)
+                eng.forward_into_raw(kf.data_ptr(), TOKEN_DTYPES[kf.dtype], klen, kbar.data_ptr(), qf.data_ptr(), qlen, proj_arr,
+                                     u_addr, ctx.data_ptr(), stream)
             _pool_cache["ref"], _pool_cache["version"], _pool_cache["kbar"] = weakref.ref(k), k._version, kbar
-        sticky_step = eng.has_memory and self.sticky_memories
-        # torch.multinomial on the CPU path draws its uniforms from the global CPU generator
-        u_addr = self._draw_uniforms(k.device) if sticky_step else 0
-        qf = q.detach()
-        if qf.dtype != torch.float32 or not qf.is_contiguous():
-            qf = qf.float().contiguous()
-        ctx = torch.empty(1, qlen, self.n_head * self.head_size, device=k.device, dtype=torch.float32)
-        if other_device:
-            with torch.cuda.device(k.device):
-                eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, eng._proj_array([self._proj(k.device)]), u_addr,
-                             ctx.data_ptr(), stream)
-        else:
-            eng.step_raw(kbar.data_ptr(), klen, qf.data_ptr(), qlen, eng._proj_array([self._proj(k.device)]), u_addr,
-                         ctx.data_ptr(), stream)
         if sticky_step:
             self._uniforms_used(k.device)
         self.count += 1
