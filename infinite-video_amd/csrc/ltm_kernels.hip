@@ -249,7 +249,12 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
                 __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(pc.R_all + rr * (long)d4 * 4, 0, d4 * 16, 0x00020000);
                 uintx4_t w;
                 w.x = __float_as_uint(racc.x); w.y = __float_as_uint(racc.y); w.z = __float_as_uint(racc.z); w.w = __float_as_uint(racc.w);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rr_, c4 * 16, 0, 16 /* sc1 */);
+                // (sc1 = write-through: needed when consumers run while this launch is resident (done != nullptr); behind a kernel boundary
+                //  any policy is correct: store_mode, an experiment of round 6)
+                const int smode = pc.done != nullptr ? 0 : pc.store_mode;
+                if (smode == 1) __builtin_amdgcn_raw_buffer_store_b128(w, rr_, c4 * 16, 0, 0);
+                else if (smode == 2) __builtin_amdgcn_raw_buffer_store_b128(w, rr_, c4 * 16, 0, 2 /* nt */);
+                else __builtin_amdgcn_raw_buffer_store_b128(w, rr_, c4 * 16, 0, 16 /* sc1 */);
                 if (pc.plane[0] != nullptr) {
                     const long nb = (pc.n_chunks - cb * pc.sub) < pc.sub ? (pc.n_chunks - cb * pc.sub) : pc.sub;   // chunks of this sub-batch
                     const long Mb = nb * op.rows, m = (c - cb * pc.sub) * op.rows + r;
@@ -267,9 +272,19 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
                     __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[0]) + base, 0, span, 0x00020000);
                     __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[1]) + base, 0, span, 0x00020000);
                     __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(static_cast<__bf16*>(pc.plane[2]) + base, 0, span, 0x00020000);
+                    if (smode == 1) {
+                        __builtin_amdgcn_raw_buffer_store_b64(v0, r0, voff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(v1, r1, voff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(v2, r2, voff, 0, 0);
+                    } else if (smode == 2) {
+                        __builtin_amdgcn_raw_buffer_store_b64(v0, r0, voff, 0, 2 /* nt */);
+                        __builtin_amdgcn_raw_buffer_store_b64(v1, r1, voff, 0, 2 /* nt */);
+                        __builtin_amdgcn_raw_buffer_store_b64(v2, r2, voff, 0, 2 /* nt */);
+                    } else {
                     __builtin_amdgcn_raw_buffer_store_b64(v0, r0, voff, 0, 16 /* sc1 */);
                     __builtin_amdgcn_raw_buffer_store_b64(v1, r1, voff, 0, 16 /* sc1 */);
                     __builtin_amdgcn_raw_buffer_store_b64(v2, r2, voff, 0, 16 /* sc1 */);
+                    }
                 }
             }
             if (pc.done != nullptr) {                                   // (nullptr: one launch per sub-batch, the kernel boundary is the hand-off)
@@ -361,6 +376,7 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
         memset(&one, 0, sizeof(one));
         one.sub = n_chunks; one.n_chunks = n_chunks; one.R_all = R;
         for (int i = 0; i < 3; ++i) one.plane[i] = planes[i];
+        { static const int sm = [] { const char* e = exp_env("INFV_POOL_STORE"); return e ? atoi(e) : 0; }(); one.store_mode = sm; }
         call = &one; pc = one;
         if (planes_done != nullptr) *planes_done = true;
     }

@@ -104,21 +104,32 @@ def _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast=Non
     probs_host = probs_all[:n_or].cpu().numpy()
     u_host = u[:n_or].cpu().numpy()
     orcs = [O.ClosedFormOracle(N, H, DH, 0.75, True, *ws[l], tokens_per_frame=P) for l in range(L)]
-    worst, worst_p, flips = 0.0, 0.0, 0
-    for c in range(n_or):
-        kc = k[c].cpu().numpy()
-        yc = ctx[c].cpu().numpy()
-        for l in range(L):
+
+    def walk(l):
+        """One layer's chain over the call (the layers are independent chains: one thread each, the CPU oracle's numpy / torch
+        kernels release the GIL -- the 2048-chunk walk is most of the GPU suite's wall time)."""
+        worst_l, worst_p_l, flips_l = 0.0, 0.0, 0
+        for c in range(n_or):
+            kc = k[c].cpu().numpy()
+            yc = ctx[c, l].cpu().numpy()
             out = orcs[l].step(kc, qs[l], new_doc=(c == 0), u=u_host[c, l] if c else None,
                                bins_override=bins_host[c, l] if c else None)
-            err = float(np.abs(out - yc[l]).max())
+            err = float(np.abs(out - yc).max())
             assert err <= CTX_TOL, f"chunk {c} layer {l}: |ctx(HIP) - ctx(oracle)| = {err:.3e}"
-            worst = max(worst, err)
+            worst_l = max(worst_l, err)
             if c:
                 d = orcs[l].last_bins != bins_host[c, l]
-                flips += int(d.sum())
+                flips_l += int(d.sum())
                 assert np.abs(orcs[l].last_bins[d] - bins_host[c, l][d]).max(initial=0) <= 1, "a differing draw is not an adjacent bin"
-                worst_p = max(worst_p, float(np.abs(orcs[l].last_probs / probs_host[c, l, :127] - 1).max()))
+                worst_p_l = max(worst_p_l, float(np.abs(orcs[l].last_probs / probs_host[c, l, :127] - 1).max()))
+        return worst_l, worst_p_l, flips_l
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=L) as pool:
+        res = list(pool.map(walk, range(L)))                  # (an assertion inside a walk is re-raised here)
+    worst = max(r[0] for r in res)
+    worst_p = max(r[1] for r in res)
+    flips = sum(r[2] for r in res)
     assert worst_p <= 2e-5, f"sticky probabilities of the HIP path and the oracle differ by {worst_p:.2e} relative"
     budget = max(4, int(4e-5 * n_or * L * S))
     assert flips <= budget, f"{flips} of {(n_or - 1) * L * S} oracle draws differ from the HIP path's"
