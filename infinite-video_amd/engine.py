@@ -401,6 +401,15 @@ class LTMEngine:
     def chain_state_numel(self, Q: int) -> int:
         return int(self.lib.infv_ltm_chain_state_bytes(self._h, Q)) // 4
 
+    def last_scores_device(self, Q: int) -> torch.Tensor:
+        """Bias-free scores of the last step under the last call's query, [L, H, Q, N] on the device: the scores slice of the
+        chain-state blob (layout: include/infv_ltm.h, infv_ltm_export_chain_state).  What SURVEY.md section 8e lists beside
+        ``B_past`` in the all-gather payload: with them a peer can re-derive the sticky density on any grid."""
+        blob = self.export_chain_state(Q)
+        Np = self.Np                                                            # (the handle's basis count: padded to a multiple of 16)
+        off = 16 + self.L * Np * self.d + self.L * Np * 2 * self.dm             # header (16 int32) | B | projected memory | scores | masses
+        return blob[off:off + self.L * self.H * Q * Np].reshape(self.L, self.H, Q, Np)[..., :self.N]
+
     def reproject(self, projs: Sequence[ProjTensors]):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.infv_ltm_reproject(self._h, self._proj_array(projs), _stream(self.device)))

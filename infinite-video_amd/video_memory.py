@@ -47,6 +47,7 @@ class ConsolidatedMemory:
     bin_mass: torch.Tensor   # [R, L, 127]    unnormalised sticky bin masses
     ctx_sum: torch.Tensor    # [R, L, Q, dm]  sum over the rank's chunks of the per-chunk outputs
     count: torch.Tensor      # [R]            chunks consolidated by the rank
+    scores: Optional[torch.Tensor] = None   # [R, L, H, Q, N]  bias-free scores of the rank's last step (``with_scores=True``)
 
     def mean_embedding(self) -> torch.Tensor:
         """Mean over ALL chunks of the video of the per-chunk outputs, [L, Q, dm]
@@ -54,8 +55,9 @@ class ConsolidatedMemory:
         return self.ctx_sum.sum(0) / self.count.sum()
 
 
-def pack_local_memory(engine, ctx_local: torch.Tensor) -> torch.Tensor:
-    """Flatten this rank's consolidated memory into one fp32 payload (one collective, not four)."""
+def pack_local_memory(engine, ctx_local: torch.Tensor, with_scores: bool = False) -> torch.Tensor:
+    """Flatten this rank's consolidated memory into one fp32 payload (one collective, not four).  ``with_scores``: also the last
+    step's scores [L, H, Q, N] (SURVEY.md section 8e's full payload: +0.79 MB per rank at the headline shape)."""
     L = engine.L
     parts = []
     masses = []
@@ -64,19 +66,22 @@ def pack_local_memory(engine, ctx_local: torch.Tensor) -> torch.Tensor:
         parts.append(B.reshape(-1))
         masses.append(mass.reshape(-1))
     count = torch.full((1,), float(ctx_local.shape[0]), device=ctx_local.device, dtype=torch.float32)
-    return torch.cat(parts + masses + [ctx_local.sum(0).reshape(-1), count])
+    extra = [engine.last_scores_device(int(ctx_local.shape[2])).reshape(-1).to(torch.float32)] if with_scores else []
+    return torch.cat(parts + masses + extra + [ctx_local.sum(0).reshape(-1), count])
 
 
-def unpack_memory(payload: torch.Tensor, world: int, L: int, N: int, d: int, Q: int, dm: int) -> ConsolidatedMemory:
+def unpack_memory(payload: torch.Tensor, world: int, L: int, N: int, d: int, Q: int, dm: int, H: int = 0) -> ConsolidatedMemory:
+    """``H`` > 0: the payload carries the last scores [L, H, Q, N] behind the bin masses (``pack_local_memory(with_scores=True)``)."""
     payload = payload.reshape(world, -1)
-    nB, nM, nC = L * N * d, L * 127, L * Q * dm
-    if payload.shape[1] != nB + nM + nC + 1:
+    nB, nM, nC, nS = L * N * d, L * 127, L * Q * dm, L * H * Q * N
+    if payload.shape[1] != nB + nM + nS + nC + 1:
         raise ValueError("payload size does not match the memory layout")
     return ConsolidatedMemory(
         B=payload[:, :nB].reshape(world, L, N, d),
         bin_mass=payload[:, nB:nB + nM].reshape(world, L, 127),
-        ctx_sum=payload[:, nB + nM:nB + nM + nC].reshape(world, L, Q, dm),
-        count=payload[:, -1])
+        ctx_sum=payload[:, nB + nM + nS:nB + nM + nS + nC].reshape(world, L, Q, dm),
+        count=payload[:, -1],
+        scores=payload[:, nB + nM:nB + nM + nS].reshape(world, L, H, Q, N) if H > 0 else None)
 
 
 def _device_collectives(group=None) -> bool:
@@ -116,7 +121,7 @@ def _recv(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
 
 def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Sequence,
                       u_local: Optional[torch.Tensor], group=None, handoff: bool = False,
-                      timings: Optional[dict] = None) -> Tuple[torch.Tensor, ConsolidatedMemory]:
+                      timings: Optional[dict] = None, with_scores: bool = False) -> Tuple[torch.Tensor, ConsolidatedMemory]:
     """Consolidate this rank's block of chunks and all-gather the consolidated memory.
 
     k_local [C_local, T*P, d]; q [L, Q, dm]; u_local [C_local, L, S] (rows keyed by global chunk id).
@@ -141,6 +146,9 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
     This is the hand-over point to the LLM forward, so it waits for the consolidation (``engine.sync()``) and
     raises if the persistent chain kernel reported a failure instead of passing an invalid memory on.
 
+    ``with_scores``: the gathered memory also carries every rank's last scores [L, H, Q, N] (``ConsolidatedMemory.scores``) --
+    SURVEY.md section 8e's full payload; off by default (B and the 127 bin masses are enough to continue a sticky draw).
+
     ``timings`` (a dict, benchmarks only): accumulates ``shard_s`` (this rank's consolidation + packing, up to the sync in
     front of the collective) and ``allgather_s`` (the collective, synchronised) so that a multi-GPU line decomposes."""
     import time
@@ -159,7 +167,7 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
         blob = engine.export_chain_state(Q)
         engine.sync()                                # complete (and free of a latched chain failure) before it leaves
         _send(blob, rank + 1, group)
-    payload = pack_local_memory(engine, ctx)         # stream-ordered behind the consolidation: no host round trip in between
+    payload = pack_local_memory(engine, ctx, with_scores)   # stream-ordered behind the consolidation: no host round trip in between
     engine.sync()                                    # a latched chain failure raises here, before anything is handed on
     t_shard = time.perf_counter() if timings is not None else 0.0
     gathered = _all_gather_payload(payload, world, group) if have_group else payload
@@ -169,5 +177,5 @@ def consolidate_video(engine, k_local: torch.Tensor, q: torch.Tensor, projs: Seq
         timings["shard_s"] = timings.get("shard_s", 0.0) + (t_shard - t_begin)
         timings["allgather_s"] = timings.get("allgather_s", 0.0) + (time.perf_counter() - t_shard)
         timings["calls"] = timings.get("calls", 0) + 1
-    mem = unpack_memory(gathered, world, engine.L, engine.N, engine.d, q.shape[1], engine.dm)
+    mem = unpack_memory(gathered, world, engine.L, engine.N, engine.d, q.shape[1], engine.dm, engine.H if with_scores else 0)
     return ctx, mem

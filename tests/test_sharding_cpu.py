@@ -22,7 +22,7 @@ class OracleEngine:
     """Same surface as infinite_video_amd.engine.LTMEngine (consolidate / export_state), CPU oracle inside."""
 
     def __init__(self):
-        self.L, self.N, self.d, self.dm = L, N, D, DM
+        self.L, self.N, self.d, self.dm, self.H = L, N, D, DM, H
         self.ws = [synth.layer_projections(l, D, DM) for l in range(L)]
         self.layers = [ClosedFormOracle(N, H, DH, .75, True, *self.ws[l], tokens_per_frame=P) for l in range(L)]
 
@@ -49,6 +49,9 @@ class OracleEngine:
             part = blob[l * per:(l + 1) * per].numpy()
             o.B_past = part[:N * D].reshape(N, D).copy()
             o.S_prev = part[N * D:].reshape(H, Q, N).copy()
+
+    def last_scores_device(self, Q):
+        return torch.from_numpy(np.stack([o.S_prev for o in self.layers]).astype(np.float32))
 
     def export_state(self, l):
         o = self.layers[l]
@@ -84,6 +87,15 @@ def test_pack_unpack_roundtrip_single_process():
     torch.testing.assert_close(mem.B[0, 1], eng.export_state(1)[0])
     with pytest.raises(ValueError):
         unpack_memory(pack_local_memory(eng, ctx)[:-1], 1, L, N, D, Q, DM)
+    assert mem.scores is None
+    # the full payload of SURVEY.md section 8e: + the last scores [L, H, Q, N]
+    ctx2, mem2 = consolidate_video(OracleEngine(), k[:3], q, None, u[:3], with_scores=True)
+    assert mem2.scores.shape == (1, L, H, Q, N)
+    torch.testing.assert_close(mem2.scores[0, 1], torch.from_numpy(eng.layers[1].S_prev.astype(np.float32)))
+    torch.testing.assert_close(mem2.B, mem.B)
+    torch.testing.assert_close(mem2.ctx_sum, mem.ctx_sum)
+    with pytest.raises(ValueError):
+        unpack_memory(pack_local_memory(eng, ctx, True), 1, L, N, D, Q, DM)          # scores in the payload, not announced
 
 
 def _worker(rank, world, port, ret):

@@ -112,3 +112,28 @@ def test_chain_state_blob_of_another_shape_is_refused():
         other.consolidate(k[32:], q, projs, u[32:], new_doc=False)
     assert ei.value.code == -4 or "blob" in str(ei.value)                # INFV_ERR_STATE
     assert not other.has_memory
+
+
+def test_gathered_memory_can_carry_the_last_scores():
+    """``consolidate_video(..., with_scores=True)``: SURVEY.md section 8e's full payload -- B_past, the last scores [L, H, Q, N], the sum
+    of the outputs and the count.  The scores are the ones the handle's diagnostics report (``last_scores``) without their bias
+    term, the rest of the gathered memory is unchanged."""
+    from infinite_video_amd.video_memory import consolidate_video
+    from tests.test_timed_path_gpu import H, L, N, Q, _engine, _video
+    dev = torch.device("cuda:0")
+    k, q, projs, u, _, _ = _video(dev, 40)
+    eng = _engine(dev, max_batch_chunks=42)
+    ctx0, mem0 = consolidate_video(eng, k, q, projs, u)
+    ctx1, mem1 = consolidate_video(eng, k, q, projs, u, with_scores=True)
+    torch.cuda.synchronize()
+    assert mem0.scores is None and mem1.scores.shape == (1, L, H, Q, N)
+    assert torch.equal(ctx0, ctx1) and torch.equal(mem0.B, mem1.B) and torch.equal(mem0.bin_mass, mem1.bin_mass)
+    assert torch.equal(mem0.ctx_sum, mem1.ctx_sum)
+    # the blob's scores are bias-free (q . K'^T / sqrt(dh)); the diagnostics add the bias term q_h . bk_h / sqrt(dh), constant along N
+    from tests.test_timed_path_gpu import DH
+    for l in range(L):
+        got = mem1.scores[0, l].cpu().numpy().astype(np.float64)
+        full = np.asarray(eng.last_scores(l, Q), dtype=np.float64)
+        bk = projs[l][1].cpu().numpy().astype(np.float64).reshape(H, DH)
+        cq = (q[l].cpu().numpy().astype(np.float64).reshape(Q, H, DH) * bk[None]).sum(-1).T / np.sqrt(DH)      # [H, Q]
+        np.testing.assert_allclose(got + cq[:, :, None], full, rtol=0, atol=2e-6)
