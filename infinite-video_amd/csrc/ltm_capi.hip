@@ -1562,9 +1562,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             }
         }
     }
-    // per-sub-batch pooling launches: the kernel writes the bf16 planes of its rows too (no split3_rows_kernel, no re-read of R)
-    static const bool planes_env = [] { const char* e = exp_env("INFV_POOL_PLANES"); return !e || atoi(e) != 0; }();
-    const bool planes_in_pool = planes_env && use_pr2 && !use_pool_call && h->proj_x6 && h->w3_valid && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks) && n_batches > 0;
+    // per-sub-batch pooling launches: the kernel writes the bf16 planes of its rows too (no split3_rows_kernel, no re-read of R).
+    // Long calls only (round 6, same-box A/B, `profiles/r06_matrix.txt` block 10): a call of 768 chunks and more is bound by the role-S
+    // stream and the planes cost the pooling nothing (150.4 against 149.0 k chunks/s, four rounds); a short call -- the 256-chunk
+    // shard of the 8-GPU split -- is bound by its pooling launches, which the extra stores lengthen: 2.14-2.17 ms with
+    // split3_rows_kernel on the side stream against 2.20-2.24 with the planes written by the pooling kernel.  Same bits either way.
+    // (INFV_POOL_PLANES, experiments build: 0 = never, 2 = always.)
+    static const int planes_env = [] { const char* e = exp_env("INFV_POOL_PLANES"); return e ? atoi(e) : 1; }();
+    const bool planes_in_pool = (planes_env == 2 || (planes_env == 1 && n_chunks >= 768)) && use_pr2 && !use_pool_call && h->proj_x6 && h->w3_valid && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks) && n_batches > 0;
     std::vector<char> planes_by_pool(n_batches > 0 ? n_batches : 1, 0);
     if (planes_in_pool) {
         const size_t need3r = (size_t)sub * rows * h->d * sizeof(__bf16);

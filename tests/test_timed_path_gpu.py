@@ -303,7 +303,8 @@ _VARIANTS = [
     {},                                                        # the experiments build with no knob set
     {"INFV_POOL_ROWS": "0"},                                   # pool_frames_kernel + build_rows_kernel (the round-2 form)
     {"INFV_POOL_ROWS": "2", "INFV_PR_U": "4", "INFV_PR_WGS": "500"},   # default kernel, 4-load bursts, grid-stride (rows only: split3_rows_kernel makes the planes)
-    {"INFV_POOL_PLANES": "0"},                                 # the pooling kernel writes rows only, split3_rows_kernel makes the GEMM's bf16 planes (round 4)
+    {"INFV_POOL_PLANES": "0"},                                 # the pooling kernel writes rows only, split3_rows_kernel makes the GEMM's bf16 planes (round 4; what calls under 768 chunks ship since round 6)
+    {"INFV_POOL_PLANES": "2"},                                 # the pooling kernel writes the planes too (what calls of 768+ chunks ship), here on a short call
     _CALL,                                                     # call-long role S; pooling and GEMM launched per sub-batch
     dict(_CALL, INFV_POOL_CALL="1"),                           # ... + ONE pooling launch per call (completion counts instead of launch boundaries)
     dict(_CALL, INFV_POOL_CALL="1", INFV_GEMM_CALL="1"),       # ... + the projection GEMM as a resident tile-queue kernel (32 workgroups)
