@@ -77,15 +77,20 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+POOL_THREADS_PER_CHUNK = 768 * 64          # pool_rows2_kernel: one 768-thread workgroup per (chunk, new row), 64 new rows per chunk (headline plan)
+
+
 def pmc_traffic_per_full_launch():
-    """HBM bytes of one full pool launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
-    average FETCH_SIZE / WRITE_SIZE in KiB per dispatch).  gfx950 correction: FETCH_SIZE counts the 128-B requests
-    of a wide coalesced stream as 64 B, so it is doubled; WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM)."""
+    """HBM bytes of the pooling kernel's largest launch in the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json: average
+    FETCH_SIZE / WRITE_SIZE in KiB per dispatch) and the chunks that launch covered (its grid: since round 6 a call of 768+ chunks
+    pools in ONE launch).  gfx950 correction: FETCH_SIZE counts the 128-B requests of a wide coalesced stream as 64 B, so it is
+    doubled; WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM).  Returns (bytes, source file, chunks of that launch)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))
+    grid_of = {}
     try:
         # the in-pipeline instantiation (512- or 1024-thread workgroups; the unroll factor is a tuning knob)
         def pick(t):
@@ -93,13 +98,15 @@ def pmc_traffic_per_full_launch():
             # the smaller grids are bench.py's own alone-leg calls)
             full = sorted((int(k.rsplit("grid=", 1)[1]), v) for k, v in d[t].items() if "pool_rows2_kernel<" in k and "grid=" in k)
             if full:
+                grid_of[t] = full[-1][0]
                 return full[-1][1][1]
             old = [v for k, v in d[t].items() if "pool_frames_kernel<" in k and (", 512" in k or ", 1024" in k)]   # rounds 1-2
             return old[0][1]
         fetch, write = pick("fetch"), pick("write")
     except (KeyError, IndexError):
-        return None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
+        return None, None, None
+    chunks = grid_of["fetch"] / POOL_THREADS_PER_CHUNK if "fetch" in grid_of else None
+    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1]), chunks
 
 
 HBM_ACHIEVABLE_GBS = 6290.0    # what a pure streaming kernel reaches on this part (MI355X_MICROARCH.md, HBM section)
@@ -119,6 +126,7 @@ def pmc_fabric_bytes_per_chunk(batch_chunks: int):
     # (split3_rows_kernel ran once per sub-batch up to round 4; since round 5 only once per call, for the weights' planes: left out)
     frags = ("pool_rows2_kernel<", "gemm_x6_wide_kernel", "gemm_nt_lw_kernel", "chain_batch3_kernel<", "alpha_rows2_kernel<", "uc_fast_kernel<")
     per = {}
+    pool_chunks = None
     try:
         for frag in frags:
             best = None
@@ -132,13 +140,20 @@ def pmc_fabric_bytes_per_chunk(batch_chunks: int):
             key = best[2]
             f, w = d["fetch"][key][1] * 1024.0, d["write"].get(key, [0, 0.0])[1] * 1024.0
             pool = frag.startswith("pool_rows2")
+            if pool:
+                # (its LARGEST launch: since round 6 one launch pools a whole call of 768+ chunks; the per-sub-batch launches of a
+                #  shorter video in the same summary are the alone leg's)
+                big = max((int(k_.rsplit("grid=", 1)[1]), k_) for k_ in d["fetch"] if frag in k_ and "grid=" in k_)
+                key = big[1]
+                f, w = d["fetch"][key][1] * 1024.0, d["write"].get(key, [0, 0.0])[1] * 1024.0
+                pool_chunks = big[0] / POOL_THREADS_PER_CHUNK
             per[frag.rstrip("<")] = ((2.0 * f if pool else f) + w, 2.0 * f + w)
     except (KeyError, IndexError, ValueError):
         return None
     if "pool_rows2_kernel" not in per:
         return None
-    def per_chunk(name, v):                                   # every kernel of the shipped pipeline: one launch per sub-batch
-        return v / float(batch_chunks)
+    def per_chunk(name, v):                                   # the pooling launch covers pool_chunks chunks, every other kernel one sub-batch
+        return v / (pool_chunks if name == "pool_rows2_kernel" and pool_chunks else float(batch_chunks))
     lo = sum(per_chunk(n_, v[0]) for n_, v in per.items())
     hi = sum(per_chunk(n_, v[1]) for n_, v in per.items())
     return {"low": lo, "high": hi, "source": os.path.basename(files[-1]),
@@ -683,7 +698,11 @@ def main():
     per_chunk = BYTES_POOL_PER_CHUNK if planes else BYTES_POOL_ROWS_ONLY
     pool_bytes = c_local * per_chunk
     achieved = pool_bytes / (pool_ms * 1e-3) / 1e9 if pool_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic_per_full_launch()
+    traffic_pmc, traffic_src, traffic_chunks = pmc_traffic_per_full_launch()
+    # chunks of the pooling kernel's main launch in THIS run: one launch for the rank's whole call when it has 768+ chunks (round 6),
+    # a sub-batch otherwise; `achieved` = bytes of ALL pooling launches of the pass / their summed duration (HIP events on the launch stream)
+    launch_chunks = (c_local - 1) if c_local >= 768 else nb
+    traffic = traffic_pmc / traffic_chunks * launch_chunks if traffic_pmc and traffic_chunks else traffic_pmc
     roofline = {
         "kernel": "pool_rows2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_from_committed_profile": True,
@@ -691,7 +710,10 @@ def main():
         "note": "achieved = in situ, while the pool shares the chip with the chain and update/read-out streams; "
                 "achieved_alone = same launch size through infv_ltm_pool_rows, nothing else running",
         "launches": pool_n, "avg_launch_ms": pool_ms / max(pool_n, 1),
-        "bytes_per_full_launch": nb * per_chunk,
+        "launch_chunks": launch_chunks, "bytes_per_full_launch": launch_chunks * per_chunk,
+        "traffic_note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of the pooling kernel's largest launch in the committed summary, per chunk, "
+                        "x launch_chunks of this run's launch",
+        "traffic_pmc_launch_chunks": traffic_chunks,
         "whole_path_frac": (args.chunks * args.steps / elapsed) * BYTES_PER_CHUNK / 1e9 / (HBM_PEAK_GBS * world),
         "kernel_ms_per_pass": {name: round(ms, 3) for name, (n, ms) in prof.items()},
         "mfma_busy_pct": pmc_mfma_busy(args.batch_chunks), "mfma_busy_from_committed_profile": True,

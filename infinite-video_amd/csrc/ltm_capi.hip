@@ -1291,19 +1291,34 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     FastPipe pipe{h, *plan, Q, pp, stream};
     h->wv_split_valid = false;                                // the caller's value weights may have changed since the last call
     // the pooling of the first sub-batches depends on the caller's tokens only: it starts here, beside the first chunk
-    if (chain_call_long()) {   // hand-off counters of the call-long launches restart with the call (before ev_start: the pooling stream starts behind it)
+    // ONE pooling launch per call (round 6, shipped for calls of 768 chunks and more): the pooling stream is what bounds a long call,
+    // and between its per-sub-batch launches sat an event record, a wait for the R set's last reader and the ramp of 2688 fresh
+    // workgroups (13 us per boundary by the residency stamps).  The launch walks every (chunk, row) of the call in order, writes rows
+    // and bf16 planes write-through and counts them into one word per sub-batch; the GEMM stream holds on that word with a one-wave
+    // flag_wait_kernel (bounded, latches the handle's error word) instead of an event.  Role S, the GEMM, alpha and UC keep their
+    // per-sub-batch launches -- round 5 measured this pooling launch only beside a RESIDENT role S, which cost more seats than the
+    // boundaries: alone it is 13.3 against 13.7 ms per video on one box, four rounds (profiles/r06_matrix.txt, block 12), same bits.
+    // Rows + planes of the whole call live in HBM (0.49 MB per chunk: 1 GB at 2048 chunks); above kPoolCallBudget the call keeps its
+    // per-sub-batch pooling launches.  INFV_POOL_CALL (experiments build): 0 never, 1 with the call-long role S, 2 always.
+    static const int pool_call_env_mode = [] { const char* e = exp_env("INFV_POOL_CALL"); return e ? atoi(e) : -1; }();
+    constexpr size_t kPoolCallBudget = (size_t)16 << 30;
+    const size_t pool_call_bytes = (size_t)n_chunks * (size_t)plan->inf.rows * h->d * (sizeof(float) + 3 * sizeof(__bf16));
+    const int pool_call_mode = pool_call_env_mode >= 0 ? pool_call_env_mode : ((n_chunks >= 768 && pool_call_bytes <= kPoolCallBudget) ? 2 : 0);
+    if (chain_call_long() || pool_call_mode == 2) {   // hand-off counters of the call-long launches restart with the call (before ev_start: the pooling stream starts behind it)
         const size_t need_pd = ((size_t)n_chunks + 1) * sizeof(unsigned int);
         if (need_pd > h->pool_done.bytes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(h->pool_done.reserve(need_pd < 32768 ? 32768 : need_pd)); }
         HIP_TRY(hipMemsetAsync(h->pool_done.p, 0, need_pd, stream));
         const long cap = ((long)n_chunks + 64) & ~63l;
-        if (cap > h->gemm_flags_cap) {
+        if (chain_call_long() && cap > h->gemm_flags_cap) {
             HIP_TRY(hipDeviceSynchronize());
             const long ncap = cap < 8192 ? 8192 : cap;
             HIP_TRY(h->gemm_flags.reserve((size_t)(128 + 2 * ncap) * sizeof(unsigned int) + 1024));
             h->gemm_flags_cap = ncap;
         }
-        HIP_TRY(hipMemsetAsync(h->gemm_flags.p, 0, (size_t)(128 + 2 * h->gemm_flags_cap) * sizeof(unsigned int), stream));
-        HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));
+        if (chain_call_long()) {
+            HIP_TRY(hipMemsetAsync(h->gemm_flags.p, 0, (size_t)(128 + 2 * h->gemm_flags_cap) * sizeof(unsigned int), stream));
+            HIP_TRY(hipMemsetAsync(h->call_flags.p, 0, 512, stream));
+        }
     }
     HIP_TRY(hipEventRecord(h->ev_start, stream));
     HIP_TRY(hipMemsetAsync(h->mass_acc[0].p, 0, h->mass_acc[0].bytes, stream));   // slot of the call's first step
@@ -1505,8 +1520,9 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // ... and ONE pooling launch for the whole call: no launch boundaries on the HBM stream (with role S resident nothing but the
     // projection GEMM still needs an empty CU), rows and their bf16 planes for the whole call in HBM (402 + 604 MB at 2048 chunks),
     // the GEMM stream follows it through per-sub-batch completion counts
-    static const bool pool_call_env = [] { const char* e = exp_env("INFV_POOL_CALL"); return e && atoi(e) != 0; }();
-    const bool use_pool_call = use_call && use_pr2 && pool_call_env && pr_wgs == 0 && !(skip_mask() & 1);
+    // (mode 2: the one pooling launch WITHOUT the call-long role S, see above)
+    const bool pool_call_alone = pool_call_mode == 2 && persistent && n_batches > 0 && !host_serial();
+    const bool use_pool_call = ((use_call && pool_call_mode != 0) || pool_call_alone) && use_pr2 && pr_wgs == 0 && !(skip_mask() & 1);
     const bool planes_call = use_pool_call && h->proj_x6 && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks);
     // ... and ONE projection-GEMM launch: a few resident workgroups per XCD on a tile queue (gemm_x6_call_kernel).  Sub-batches it
     // covers: every one of >= 1024 rows (all but, possibly, a short last one: that one keeps its own launch behind the resident kernel)
@@ -1530,7 +1546,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         else *sk = project_splitk((int)M, h->d);
         *ss = M * ld;
     };
-    if (use_call) {
+    if (use_call || use_pool_call) {
         // every workspace the loop would grow (a growth synchronises the device: fatal beside a kernel that waits for the loop's work)
         const long ld = (long)h->L * h->dm + (long)h->L * h->H * Q;
         size_t needP = 0;
@@ -1725,10 +1741,14 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
         if (host_trace) host_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count());
         int c0, nb; batch_range(b, &c0, &nb);
         const int set = b % kPSets, rset = b % kRSets;
+        // (experiments) INFV_DROP_WAITS=<mask>: what the packets between two role-S launches cost.  1: no wait for the UC kernel of
+        // sub-batch b - 5 on the caller's stream (redundant: the GEMM of sub-batch b waited for it, and this stream waits for that GEMM);
+        // 2: no event record behind role S / no wait of the UC stream for it (WRONG results: timing only); 4: no wait for the GEMM (WRONG)
+        static const int drop_waits = [] { const char* e = exp_env("INFV_DROP_WAITS"); return e ? atoi(e) : 1; }();   // (round 6: bit 0 is the default -- 13.62 against 13.72 ms, tighter)
         if (!use_call) {
-            HIP_TRY(hipStreamWaitEvent(ls, h->ev_p[set], 0));
+            if (!(drop_waits & 4)) HIP_TRY(hipStreamWaitEvent(ls, h->ev_p[set], 0));
             // the ring slots this batch writes were last read by the UC kernel three batches ago (same set)
-            if (uc_pending[set]) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
+            if (uc_pending[set] && !(drop_waits & 1)) HIP_TRY(hipStreamWaitEvent(ls, h->ev_uc[set], 0));
         }
         const long slot0 = use_call ? call_slot0 + (long)(c0 - first_c) : pipe.counter;
         const float* r_rows = use_pool_call ? h->R_all.as<float>() + (size_t)(c0 - first_c) * rows * h->d : h->R_ws[rset].as<float>();   // the sub-batch's new rows
@@ -1805,7 +1825,7 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
                                          h->spin_limit, h->err_dev, ucs));
             }
             pipe.last_snew = h->P_ws[set].as<float>() + (size_t)v_cols_all; pipe.last_sk = sks[b]; pipe.last_ss = sss[b];
-        } else {
+        } else if (!(drop_waits & 2)) {
             HIP_TRY(hipEventRecord(h->ev_s[set], ls));
             HIP_TRY(hipStreamWaitEvent(ucs, h->ev_s[set], 0));
         }

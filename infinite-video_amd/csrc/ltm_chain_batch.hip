@@ -1658,6 +1658,23 @@ bool chain_batch_resident(int N, int S, int rows, int tabw, int n_blocks, int dr
     return (long)safe * cus >= n_blocks;
 }
 
+// flag_wait_kernel (shipped since round 6: the GEMM stream holds on the call-long pooling launch's per-sub-batch completion counts):
+// one wave, bounded, latches the handle's error word.
+__global__ void flag_wait_kernel(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error) {
+    if (threadIdx.x != 0) return;
+    for (int spins = 0;; ++spins) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        __builtin_amdgcn_s_sleep(32);
+        if ((spins & 1023) == 1023 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;   // the chain has already failed
+        if (spins > spin_limit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    }
+}
+hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream) {
+    INFV_LAUNCH(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
+    return hipGetLastError();
+}
+bool launch_flag_wait_available() { return true; }
+
 #ifdef INFV_EXPERIMENTS
 // ---- hand-offs of a call-long role-S launch.  GEMM stream -> role S: flag_set_kernel runs behind a sub-batch's projection GEMM (whose
 // end-of-kernel release has written its output back) and raises the count role S's loaders poll.  Role S -> UC stream:
@@ -1671,28 +1688,14 @@ hipError_t launch_chain_call_desc(ChainCallDesc* dst, const ChainCallDesc& v, hi
 __global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void flag_wait_kernel(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error) {
-    if (threadIdx.x != 0) return;
-    for (int spins = 0;; ++spins) {
-        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
-        __builtin_amdgcn_s_sleep(32);
-        if ((spins & 1023) == 1023 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;   // the chain has already failed
-        if (spins > spin_limit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
-    }
-}
 hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream) {
     INFV_LAUNCH(flag_set_kernel, dim3(1), dim3(64), 0, stream, flag, value);
-    return hipGetLastError();
-}
-hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream) {
-    INFV_LAUNCH(flag_wait_kernel, dim3(1), dim3(64), 0, stream, counter, target, spin_limit, error);
     return hipGetLastError();
 }
 
 #else
 hipError_t launch_chain_call_desc(ChainCallDesc*, const ChainCallDesc&, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_flag_set(unsigned int*, unsigned int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_flag_wait(const unsigned int*, unsigned int, int, unsigned int*, hipStream_t) { return hipErrorNotSupported; }
 #endif
 
 hipError_t launch_chain_batch(const ChainBatchArgs& a_in, hipStream_t stream) {

@@ -221,6 +221,7 @@ struct ChainBatchArgs {
 // role S -> UC stream / GEMM stream -> role S hand-offs of a call-long launch (ltm_chain_batch.hip)
 hipError_t launch_flag_set(unsigned int* flag, unsigned int value, hipStream_t stream);
 hipError_t launch_flag_wait(const unsigned int* counter, unsigned int target, int spin_limit, unsigned int* error, hipStream_t stream);
+bool launch_flag_wait_available();       // the flag kernels are compiled in (experiments build)
 bool chain_batch_supported(int N, int S, int rows, int tabw, int n_blocks);
 bool chain_batch2_applies(const ChainBatchArgs& a);        // the launch will run chain_batch3_kernel (scores rebuilt by alpha_rows2)
 bool chain_batch3_shape_ok(int draw_mode, int points_ok, int rows, int S, int Q);   // the shape runs chain_batch3_kernel (needs ChainBatchArgs.uf)

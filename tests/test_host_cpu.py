@@ -167,7 +167,8 @@ def _kernel_names(lib, tmp_path):
 def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     """A/B variants live in the experiments build only: the shipped code object has ONE persistent role-S kernel (16-row tiles,
     atomics exchange), ONE instantiation per pooling form and token type it can select, no LDS-DMA / mailbox / 8-row-tile
-    variants, none of round 5's call-long machinery (resident GEMM tile queue, flag hand-off kernels), none of the kernels deleted
+    variants, of round 5's call-long machinery only the one pooling launch per call and the flag_wait kernel that follows it (no
+    resident role S, no resident GEMM tile queue, no flag_set / descriptor kernels), none of the kernels deleted
     in round 4 (grid-stride fused pooling, rolling double-buffered pooling, round 2-3's chain_batch2)."""
     shipped, exp = _kernel_names("libinfv_ltm.so", tmp_path), _kernel_names("libinfv_ltm_exp.so", tmp_path)
     def having(names, frag):
@@ -178,7 +179,8 @@ def test_shipped_library_holds_only_the_kernels_it_can_launch(tmp_path):
     for gone in ("chain_batch2_kernel", "pool_rows_kernel", "pool_frames_db_kernel"):
         assert not having(shipped, gone) and not having(exp, gone), gone
     assert not having(shipped, "pool_rows2_dma_kernel") and not having(exp, "pool_rows2_dma_kernel")     # (racy LDS-DMA variant: deleted in round 5)
-    for exp_only in ("mailbox_to_part_kernel", "gemm_x6_call_kernel", "flag_wait_kernel", "flag_set_kernel",
+    assert having(shipped, "flag_wait_kernel")      # round 6: the GEMM stream holds on the call-long pooling launch's completion counts
+    for exp_only in ("mailbox_to_part_kernel", "gemm_x6_call_kernel", "flag_set_kernel",
                      "chain_call_desc_kernel", "gemm_call_desc_kernel"):
         assert not having(shipped, exp_only) and having(exp, exp_only), exp_only
     assert len(having(shipped, "pool_frames_kernel")) == 4          # {padded 512-thread, plain 256-thread} x {fp32, bf16 tokens}
@@ -385,5 +387,9 @@ def test_bench_reads_the_honest_ceiling_from_the_committed_pmc_pass():
     for k in ("gemm_x6_wide_kernel", "uc_fast_kernel", "alpha_rows2_kernel", "chain_batch3_kernel"):
         assert fab["per_kernel_high"][k] > 0, k
     assert "split3_rows_kernel" not in fab["per_kernel_high"]          # (once per call since round 5: the weights' planes)
+    # the pooling kernel's largest launch of the committed summary and the chunks it covered (round 6: one launch per long call)
+    traffic, src, chunks = bench.pmc_traffic_per_full_launch()
+    assert src.endswith("_pmc_summary.json") and chunks and chunks >= 42
+    assert abs(traffic / chunks - bench.BYTES_POOL_PER_CHUNK) / bench.BYTES_POOL_PER_CHUNK < 0.01
     lib = _lib.load()
     assert int(lib.infv_ltm_launch_count()) >= 0

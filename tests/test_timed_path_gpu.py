@@ -318,6 +318,8 @@ _VARIANTS = [
     {"INFV_PROJ_X6": "0", "INFV_GEMM_SLICES": "2"},            # (fp32-MFMA GEMM) launched as two column slices
     {"INFV_POOL_PRIO": "1", "INFV_UC_PRIO": "2", "INFV_ALPHA_PRIO": "2", "INFV_WG_STAMPS": "1"},   # wave priorities + residency stamps
     {"INFV_ALPHA_DIRECT": "1", "INFV_ALPHA_UPW": "5"},          # alpha_rows2_kernel's fallback staging (shapes beyond its register stage), 5 units per workgroup
+    {"INFV_POOL_CALL": "2"},                                   # ONE pooling launch for the call beside per-sub-batch role-S / GEMM launches: what calls of 768+ chunks ship since round 6, here forced on a short one
+    {"INFV_POOL_CALL": "2", "INFV_DROP_WAITS": "0"},           # ... with the (redundant) wait of the caller's stream for the UC kernel of five sub-batches ago, as up to round 5
     {"INFV_CHAIN_DMA": "1"},                                   # role S with the LDS-DMA loader (128 registers, round 6); the short last sub-batch keeps the register loader
 ]
 
@@ -371,10 +373,12 @@ def test_mailbox_exchange_variants(dev, tmp_path):
 
 
 @pytest.mark.parametrize("n_chunks,max_batch,split", [(33, 42, 0), (45, 7, 0), (70, 28, 37), (129, 42, 1), (97, 13, 50),
-                                                       (300, 42, 0), (64, 32, 63)])
+                                                       (300, 42, 0), (64, 32, 63), (800, 42, 0), (790, 30, 20)])
 def test_odd_call_lengths_sub_batches_and_continuations(dev, n_chunks, max_batch, split):
     """Call lengths that are no multiple of the sub-batch, short last sub-batches (split-K slabs), one-chunk calls and a
-    document continued by a second consolidate call (``new_doc=False``): every one must equal the per-chunk chain."""
+    document continued by a second consolidate call (``new_doc=False``): every one must equal the per-chunk chain.  800 / 790
+    chunks: calls long enough for the one pooling launch per call (768+ chunks, round 6) with a short last sub-batch / as the
+    continuation of a 20-chunk call."""
     k, q, projs, u, ws, qs = _video(dev, n_chunks)
     fast = _engine(dev, max_batch_chunks=max_batch)
     pieces = [(0, n_chunks)] if split == 0 else [(0, split), (split, n_chunks)]

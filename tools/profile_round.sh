@@ -5,12 +5,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-encode-video --no-secondary > $out/bench_trace.json 2> $out/trace.err
-# (the kernel-trace pass above runs the SHIPPED library with nothing set; the PMC passes run a 252-chunk video and force the
-# 42-chunk launches of the full-length run -- 6 full launches -- through a knob that only the experiments build reads)
-export INFV_LTM_LIBRARY=exp INFV_SUB_BATCH=42
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_fetch.json 2> $out/fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 252 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_write.json 2> $out/write.err
-unset INFV_SUB_BATCH INFV_LTM_LIBRARY
+# (the kernel-trace pass above and the PMC passes run the SHIPPED library with nothing set.  The PMC passes use a 768-chunk video: the
+# shortest call that takes the headline's path -- one pooling launch for the call, 42-chunk sub-batches for everything else; 18 full
+# sub-batches + a short one)
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --chunks 768 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_fetch.json 2> $out/fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --chunks 768 --no-cpu-baseline --no-encode-video --no-selfcheck --no-secondary > $out/bench_write.json 2> $out/write.err
 python3 - <<PY
 import csv,glob,collections,json
 out="$out"
