@@ -1521,8 +1521,12 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
     // projection GEMM still needs an empty CU), rows and their bf16 planes for the whole call in HBM (402 + 604 MB at 2048 chunks),
     // the GEMM stream follows it through per-sub-batch completion counts
     // (mode 2: the one pooling launch WITHOUT the call-long role S, see above)
-    const bool pool_call_alone = pool_call_mode == 2 && persistent && n_batches > 0 && !host_serial();
-    const bool use_pool_call = ((use_call && pool_call_mode != 0) || pool_call_alone) && use_pr2 && pr_wgs == 0 && !(skip_mask() & 1);
+    // (the pooling kernel maps a chunk to its sub-batch as chunk / sub: every sub-batch but the last must have `sub` chunks -- the tapered
+    //  schedules of the experiments build, short calls only, do not qualify)
+    bool uniform_batches = true;
+    for (int b = 0; b + 1 < n_batches; ++b) uniform_batches = uniform_batches && bstart[b + 1] - bstart[b] == sub;
+    const bool pool_call_alone = pool_call_mode == 2 && persistent && n_batches > 0 && !host_serial() && uniform_batches;
+    const bool use_pool_call = ((use_call && pool_call_mode != 0 && uniform_batches) || pool_call_alone) && use_pr2 && pr_wgs == 0 && !(skip_mask() & 1);
     const bool planes_call = use_pool_call && h->proj_x6 && h->d % 32 == 0 && !h->vproj_on_uc(n_chunks);
     // ... and ONE projection-GEMM launch: a few resident workgroups per XCD on a tile queue (gemm_x6_call_kernel).  Sub-batches it
     // covers: every one of >= 1024 rows (all but, possibly, a short last one: that one keeps its own launch behind the resident kernel)
