@@ -140,13 +140,13 @@ def _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast=Non
     return worst, flips
 
 
-@pytest.mark.parametrize("n_chunks,x6", [(64, True), (256, True), (2048, True), (256, False), (512, False)])
+@pytest.mark.parametrize("n_chunks,x6", [(64, True), (256, True), (2048, True), (256, False), (800, False)])
 def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
     """64 chunks: two sub-batches + a tail (large-M GEMM branch, persistent chain); 256 chunks: one 8-GPU
     shard; 2048 chunks with max_batch_chunks=42: exactly bench.py's call.  x6 (the default): the projection GEMM as six bf16 MFMA
     products of exact three-piece splits; not x6 (INFV_PROJ_X6=0): the fp32-MFMA GEMM of rounds 1-3 -- same goldens, same oracle,
-    same budgets (round 6: its long call is 512 chunks -- twelve 42-chunk sub-batches + a short one, past the wrap of the five
-    workspace sets -- instead of 2048: the GPU suite's wall time).  The observed flip counts are recorded (conftest.record_parity)."""
+    same budgets (round 6: its long call is 800 chunks -- nineteen 42-chunk sub-batches + a short one, past the wrap of the five
+    workspace sets, long enough for the one pooling launch per call -- instead of 2048: the GPU suite's wall time).  The observed flip counts are recorded (conftest.record_parity)."""
     k, q, projs, u, ws, qs = _video(dev, n_chunks)
     if not x6:
         monkeypatch.setenv("INFV_PROJ_X6", "0")
@@ -177,7 +177,7 @@ def test_bench_call_matches_per_chunk_chain(dev, n_chunks, x6, monkeypatch):
     # sub-batch with its own projection dispatch: all past chunk 128; about a minute of CPU) on the path bench.py times,
     # the DEFAULT (bf16x6) projection GEMM; the legacy fp32-MFMA variant (INFV_PROJ_X6=0) of the 2048-chunk call keeps
     # the first 128 chunks (three 42-chunk sub-batches)
-    n_or = n_chunks if (n_chunks <= 512 or x6) else 128
+    n_or = n_chunks if (n_chunks <= 800 or x6) else 128
     worst, oflips = _check_against_oracle(k, qs, ws, u, ctx, bins_all, probs_all, n_or, fast if n_or == n_chunks else None)
     record_parity(f"[timed path] x6={x6} {n_chunks} chunks vs the CPU oracle over {n_or}: max |ctx diff| {worst:.2e}, {oflips} draws differ")
 
