@@ -320,6 +320,7 @@ _VARIANTS = [
     {"INFV_ALPHA_DIRECT": "1", "INFV_ALPHA_UPW": "5"},          # alpha_rows2_kernel's fallback staging (shapes beyond its register stage), 5 units per workgroup
     {"INFV_POOL_CALL": "2"},                                   # ONE pooling launch for the call beside per-sub-batch role-S / GEMM launches: what calls of 768+ chunks ship since round 6, here forced on a short one
     {"INFV_POOL_CALL": "2", "INFV_DROP_WAITS": "0"},           # ... with the (redundant) wait of the caller's stream for the UC kernel of five sub-batches ago, as up to round 5
+    {"INFV_SMALL_TILES": "5"},                                 # the projection of the first and the last sub-batch as 128 x 128 tiles (what the last sub-batch of a 768+-chunk call ships, round 6)
     {"INFV_CHAIN_DMA": "1"},                                   # role S with the LDS-DMA loader (128 registers, round 6); the short last sub-batch keeps the register loader
 ]
 
