@@ -1721,7 +1721,6 @@ static int consolidate_impl(infv_ltm_handle h, const void* k_, const float* kbar
             pc.R_all = h->R_all.as<float>();
             if (planes_call) for (int i = 0; i < 3; ++i) pc.plane[i] = h->planes_all[i].p;
             pc.done = h->pool_done.as<unsigned int>();
-            { static const int rpw = [] { const char* e = exp_env("INFV_PR_ROWS"); return e ? atoi(e) : 1; }(); pc.rows_per_wg = rpw; }
             Timed t_(h->prof, INFV_KERNEL_POOL, pools);
             HIP_TRY(launch_pool_rows2_call(k + first_c * chunk_k, h->k_bf16, T, h->P, h->d, plan->inf.view(), pc, pools, pr_u, pr_pad));
         }

@@ -78,8 +78,6 @@ struct PoolCallDesc {
     float* R_all;                   // [n_chunks][rows][d] fp32
     void* plane[3];                 // bf16 planes, sub-batch b at element offset b * sub * rows * d, or nullptr
     unsigned int* done;             // [sub-batches] rows written (write-through) so far
-    int rows_per_wg;                // consecutive rows one workgroup walks (>= 1; divides the plan's rows per chunk): the per-workgroup costs -- scalar set-up, the
-                                    // drain of its write-through stores before it counts itself in, the dispatcher's turn-around -- are paid once per rows_per_wg rows
     int store_mode;                 // stores of the rows / planes when done == nullptr (a kernel boundary is the hand-off): 0 write-through (sc1), 1 plain, 2 nontemporal
 };
 hipError_t launch_pool_rows2_call(const void* k, int k_bf16, int T, int P, int d, const OperatorView& op, const PoolCallDesc& pc,

@@ -187,11 +187,9 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
     //  role S and the GEMM resident too -- every CU with exactly one resident kernel: the pooling finished its 51.5 GB in 11.2 ms
     //  (4.6 TB/s) and the call took 19-22 ms: beside a workgroup that streams without a pause the UC / alpha workgroups lived up to
     //  four times longer and role S's exchange slowed.  Short-lived workgroups that leave gaps are part of why the pipeline works.)
-    // (CALL: the workgroup walks pc.rows_per_wg consecutive rows -- of one chunk, hence of one sub-batch -- and counts them in together)
-    const int rpw_ = CALL ? (pc.rows_per_wg > 0 ? pc.rows_per_wg : 1) : 1;
-    const long rr_first = CALL ? (long)blockIdx.x * rpw_ : (long)blockIdx.x;
-    const long rr_end = CALL ? (rr_first + rpw_ < n_rows_total ? rr_first + rpw_ : n_rows_total) : n_rows_total;
-    for (long rr = rr_first; rr < rr_end; rr += CALL ? 1 : (long)gridDim.x) {
+    // (round 6 tried 2 / 4 / 8 consecutive rows per workgroup in the one-launch form -- set-up, store drain and dispatcher turn-around
+    //  paid once per n rows: 14.46 / 15.80 / 16.45 against 13.65 ms per video.  Shorter-lived pooling workgroups win.)
+    for (long rr = blockIdx.x; rr < n_rows_total; rr += CALL ? n_rows_total : (long)gridDim.x) {
         const long c = rr / op.rows;
         const int r = (int)(rr - c * op.rows);
         const int fb = op.row_begin[r], fe = op.row_end[r];
@@ -291,11 +289,10 @@ __global__ __launch_bounds__(1024) void pool_rows2_kernel(const void* __restrict
                     }
                 }
             }
-            if (pc.done != nullptr && rr + 1 == rr_end) {               // (nullptr: one launch per sub-batch, the kernel boundary is the hand-off)
-                // every row of this workgroup is written through: count them into their sub-batch's word (one chunk, one sub-batch)
+            if (pc.done != nullptr) {                                   // (nullptr: one launch per sub-batch, the kernel boundary is the hand-off)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) __hip_atomic_fetch_add(pc.done + cb, (unsigned int)(rr_end - rr_first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(pc.done + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -374,10 +371,6 @@ static hipError_t launch_pool_rows2_t(const void* k, int n_chunks, int T, int P,
     }
     unsigned grid = (unsigned)n_rows_total;
     if (max_wgs > 0 && grid > (unsigned)max_wgs) grid = (unsigned)max_wgs;
-    if (call != nullptr) {
-        if (pc.rows_per_wg < 1 || op.rows % pc.rows_per_wg != 0) pc.rows_per_wg = 1;       // (rows of one chunk per workgroup)
-        grid = (unsigned)((n_rows_total + pc.rows_per_wg - 1) / pc.rows_per_wg);
-    }
     const dim3 block(4 * slices * 64);
     static const int prio = [] { const char* e = exp_env("INFV_POOL_PRIO"); return e ? atoi(e) : 0; }();
     PoolCallDesc one;                                                         // rows + planes of ONE sub-batch: the call-long kernel without a completion count
